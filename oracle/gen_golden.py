@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.  TEST INFRASTRUCTURE.
+
+Runs only where /root/reference exists (never on the GPU box).  It imports the reference's own
+``clip/model.py``, ``tools/metrics.py`` and ``trainers/calibration/distanse_aware_calibration.py`` through
+``importlib`` (bypassing ``clip/__init__.py`` which needs torchvision), feeds them seeded synthetic weights /
+inputs from ``clip_calibration_amd.synthetic`` and stores inputs + expected outputs as small .npz fixtures.
+No reference source text is stored -- only tensors.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CLIP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from clip_calibration_amd import synthetic as syn  # noqa: E402
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+PLAIN = {"trainer": "CoOp", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0}
+MAPLE = {"trainer": "MaPLe", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0,
+         "maple_length": 2}
+
+
+def sd_checksum(sd):
+    return float(sum(v.double().abs().sum().item() for v in sd.values()))
+
+
+def ref_forward(ref_model, geom_name, seed, n_img, n_cls, capture=False):
+    """Run reference build_model + encode_image/encode_text/forward in fp32 (reading A) and fp16-on-CPU (reading B)."""
+    sd = syn.synthetic_state_dict(geom_name, seed=seed)
+    images = syn.synthetic_images(n_img, geom_name, seed=seed)
+    ids = syn.synthetic_token_ids(n_cls, geom_name, seed=seed)
+    out = {"images": images.numpy(), "ids": ids.numpy(), "sd_checksum": np.float64(sd_checksum(sd)), "seed": seed}
+
+    model16 = ref_model.build_model(dict(sd), dict(PLAIN))          # fp16 weights per convert_weights
+    model32 = ref_model.build_model(dict(sd), dict(PLAIN)).float()   # what clip.load does on CPU
+
+    caps = {}
+    if capture:
+        def hook(name):
+            def f(_m, _i, o):
+                caps[name] = _np(o)
+            return f
+        model32.visual.ln_pre.register_forward_hook(hook("v_ln_pre"))        # NLD
+        for i, blk in enumerate(model32.visual.transformer.resblocks):
+            blk.register_forward_hook(hook(f"v_block{i}"))                  # LND
+        for i, blk in enumerate(model32.transformer.resblocks):
+            blk.register_forward_hook(hook(f"t_block{i}"))                  # LND
+        model32.visual.conv1.register_forward_hook(hook("v_conv1"))          # [B,W,g,g]
+
+    with torch.no_grad():
+        img32 = model32.encode_image(images)
+        txt32 = model32.encode_text(ids)
+        lpi32, _ = model32(images, ids)
+        img16 = model16.encode_image(images)
+        txt16 = model16.encode_text(ids)
+        lpi16, _ = model16(images, ids)
+    out.update(image_features=_np(img32), text_features=_np(txt32), logits=_np(lpi32),
+               image_features_fp16=_np(img16), text_features_fp16=_np(txt16), logits_fp16=_np(lpi16))
+    for k, v in caps.items():
+        if k.startswith(("v_block", "t_block")):
+            v = np.ascontiguousarray(v.transpose(1, 0, 2))  # LND -> NLD
+        out["cap_" + k] = v
+    return sd, model32, out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    ref_model = _load("ref_model", "clip/model.py")
+    ref_metrics = _load("ref_metrics", "tools/metrics.py")
+    ref_dac = _load("ref_dac", "trainers/calibration/distanse_aware_calibration.py")
+
+    # ---------------- tiny geometry: weights + all intermediates ----------------
+    for gname, fname in (("tiny", "tiny_clip.npz"), ("tiny3", "tiny3_clip.npz")):
+        sd, m32, out = ref_forward(ref_model, gname, seed=0, n_img=3, n_cls=5, capture=True)
+        if gname == "tiny":  # weights committed for the smallest geometry; the others are pinned by seed + checksum
+            for k, v in sd.items():
+                out["sd:" + k] = v.half().numpy() if v.dim() > 0 else v.numpy()
+
+        # CoOp TextEncoder glue (trainers/classification/coop.py:56-67,128-144) evaluated with the reference's
+        # own sub-modules: transformer / ln_final / text_projection / token_embedding.
+        geom = syn.GEOMETRIES[gname]
+        n_ctx = 4
+        ids_c = syn.synthetic_token_ids(5, gname, seed=1, n_ctx_placeholders=n_ctx)
+        g = torch.Generator().manual_seed(77)
+        ctx = (0.02 * torch.randn(n_ctx, geom.transformer_width, generator=g)).half().float()
+        with torch.no_grad():
+            emb = m32.token_embedding(ids_c)
+            prompts = torch.cat([emb[:, :1], ctx.unsqueeze(0).expand(5, -1, -1), emb[:, 1 + n_ctx:]], dim=1)
+            x = prompts + m32.positional_embedding
+            x = m32.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+            x = m32.ln_final(x)
+            tf = x[torch.arange(5), ids_c.argmax(-1)] @ m32.text_projection
+        out.update(coop_ids=ids_c.numpy(), coop_ctx=ctx.numpy(), coop_prompts=_np(prompts), coop_text_features=_np(tf))
+
+        # MaPLe: reference VisionTransformer_MaPLe / ResidualAttentionBlock_MaPLe (clip/model.py:259-331,427-478)
+        if gname == "tiny":
+            mm = ref_model.build_model(dict(sd), dict(MAPLE)).float()
+            depth = 2  # PROMPT_DEPTH=2 -> one deep prompt ... use 2 deep prompts on a 2-layer tower: only layer 1 consumes
+            g = torch.Generator().manual_seed(78)
+            tw, vw = geom.transformer_width, geom.vision_width
+            pl = {"ctx": (0.02 * torch.randn(2, tw, generator=g)).half().float(),
+                  "proj.weight": (torch.randn(vw, tw, generator=g) * tw ** -0.5).half().float(),
+                  "proj.bias": (0.02 * torch.randn(vw, generator=g)).half().float()}
+            for i in range(depth):
+                pl[f"compound_prompts_text.{i}"] = (0.02 * torch.randn(2, tw, generator=g)).half().float()
+                pl[f"compound_prompt_projections.{i}.weight"] = (torch.randn(vw, tw, generator=g) * tw ** -0.5).half().float()
+                pl[f"compound_prompt_projections.{i}.bias"] = (0.02 * torch.randn(vw, generator=g)).half().float()
+            ids_m = syn.synthetic_token_ids(5, gname, seed=2, n_ctx_placeholders=2)
+            images = torch.from_numpy(out["images"])
+            with torch.no_grad():
+                emb = mm.token_embedding(ids_m)
+                prompts = torch.cat([emb[:, :1], pl["ctx"].unsqueeze(0).expand(5, -1, -1), emb[:, 3:]], dim=1)
+                shared = torch.nn.functional.linear(pl["ctx"], pl["proj.weight"], pl["proj.bias"])
+                deep_t = [pl[f"compound_prompts_text.{i}"] for i in range(depth)]
+                deep_v = [torch.nn.functional.linear(deep_t[i], pl[f"compound_prompt_projections.{i}.weight"],
+                                                     pl[f"compound_prompt_projections.{i}.bias"]) for i in range(depth)]
+                x = prompts + mm.positional_embedding
+                x = mm.transformer([x.permute(1, 0, 2), deep_t, 0])[0].permute(1, 0, 2)
+                x = mm.ln_final(x)
+                tfm = x[torch.arange(5), ids_m.argmax(-1)] @ mm.text_projection
+                imf = mm.visual(images, shared, deep_v)
+            out.update(maple_ids=ids_m.numpy(), maple_text_features=_np(tfm), maple_image_features=_np(imf),
+                       maple_shared_ctx=_np(shared))
+            for k, v in pl.items():
+                out["maple_pl:" + k] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+        print("wrote", fname, {k: np.shape(v) for k, v in out.items() if not k.startswith("sd:")})
+
+    # ---------------- full ViT-B/16 geometry: inputs by seed, outputs stored ----------------
+    _, _, out = ref_forward(ref_model, "ViT-B/16", seed=0, n_img=2, n_cls=8)
+    out.pop("images")  # regenerated from the seed; ids are tiny so they stay
+    np.savez_compressed(os.path.join(OUT, "vitb16_seed0.npz"), **out)
+    print("wrote vitb16_seed0.npz")
+
+    # ---------------- ECE (tools/metrics.py:90-130) ----------------
+    rng = np.random.default_rng(0)
+    cases = {}
+    def add(name, conf, pred, gt, bins):
+        cases[f"{name}:conf"] = conf
+        cases[f"{name}:pred"] = pred
+        cases[f"{name}:gt"] = gt
+        cases[f"{name}:bins"] = np.int64(bins)
+        cases[f"{name}:ece"] = np.float64(ref_metrics.ECE(conf, pred, gt, bins))
+    n = 2000
+    conf = rng.uniform(0.05, 1.0, n)
+    pred = rng.integers(0, 50, n)
+    gt = np.where(rng.uniform(size=n) < conf, pred, rng.integers(0, 50, n))
+    add("uniform10", conf, pred, gt, 10)
+    add("uniform15", conf, pred, gt, 15)
+    conf2 = conf.copy(); conf2[:37] = 1.0          # the digitize/histogram right-edge quirk
+    add("ones_quirk", conf2, pred, gt, 10)
+    conf3 = rng.uniform(0.9, 0.999, 300)            # 9 empty bins
+    add("empty_bins", conf3, pred[:300], gt[:300], 10)
+    add("single", np.array([0.73]), np.array([3]), np.array([3]), 10)
+    add("all_one", np.ones(16), pred[:16], pred[:16], 10)
+    conf4 = rng.uniform(0, 1, 500).astype(np.float32)  # float32 confidences straddling bin edges
+    conf4[:11] = np.linspace(0, 1, 11, dtype=np.float32)
+    add("edges_f32", conf4, pred[:500], gt[:500], 10)
+    np.savez_compressed(os.path.join(OUT, "ece_cases.npz"), **cases)
+    print("wrote ece_cases.npz")
+
+    # ---------------- DAC (distanse_aware_calibration.py) ----------------
+    # predict() hard-codes .cuda(); there is no GPU in this container, so .cuda() is shimmed to the identity for
+    # the duration of the call -- the arithmetic executed is still the reference's own lines 52-58.
+    dac = {}
+    torch_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for name, (cb, cn, dim, k) in {"c50": (50, 50, 128, 5), "c19": (19, 18, 64, 5), "k3": (8, 5, 32, 3)}.items():
+            def feats(n, base=None, jitter=0.0):
+                f = rng.normal(size=(n, dim)) if base is None else base + jitter * rng.normal(size=base.shape)
+                return f / np.linalg.norm(f, axis=1, keepdims=True)
+            base_zs, cur_zs = feats(cb), feats(cn)
+            base_tuned, cur_tuned = feats(cb, base_zs, 0.05), feats(cn, cur_zs, 0.05)
+            cur_tuned[0] = base_tuned[1] + 1e-3            # "base class aware" branch (distance < 0.05)
+            cal = ref_dac.DistanseAwareCalibration()
+            cal.fit(base_zs, cur_zs, base_tuned, cur_tuned, k)
+            logits = (100 * feats(64) @ cur_tuned.T)        # float64, as the evaluator's python lists give
+            pred_out = cal.predict(logits.copy())
+            dac.update({f"{name}:base_zs": base_zs, f"{name}:cur_zs": cur_zs, f"{name}:base_tuned": base_tuned,
+                        f"{name}:cur_tuned": cur_tuned, f"{name}:k": np.int64(k),
+                        f"{name}:class_confidence": cal.class_confidence, f"{name}:logits": logits,
+                        f"{name}:scaled_logits": pred_out})
+    finally:
+        torch.Tensor.cuda = torch_cuda
+    np.savez_compressed(os.path.join(OUT, "dac_cases.npz"), **dac)
+    print("wrote dac_cases.npz")
+
+
+if __name__ == "__main__":
+    main()
