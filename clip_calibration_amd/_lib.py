@@ -1,0 +1,112 @@
+"""ctypes binding of ``libclipmi.so`` (C ABI declared in ``include/clipmi.h``).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the shared object is missing or a symbol
+cannot be resolved this module raises at import time, and every wrapper raises ``ClipmiError`` on a non-zero
+return code with the library's own error text.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libclipmi.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
+
+ABI_VERSION = 1
+
+OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
+F16, F32 = 0, 1
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+
+
+class ClipmiError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str):
+        super().__init__(f"{what} failed: {detail or '?'} (code {code})")
+        self.code = code
+
+
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "embed_dim", "image_resolution", "patch_size", "vision_width", "vision_layers",
+        "context_length", "vocab_size", "text_width", "text_layers", "text_heads")]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_out", "b_out", "ln2_g", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj")]
+
+
+class VisionWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "conv_w", "class_embedding", "positional_embedding", "ln_pre_g", "ln_pre_b", "ln_post_g", "ln_post_b",
+        "proj_t")] + [("blocks", C.POINTER(BlockWeights))]
+
+
+class TextWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "token_embedding", "positional_embedding", "ln_final_g", "ln_final_b", "proj_t")] + [
+        ("blocks", C.POINTER(BlockWeights))]
+
+
+class PromptHook(C.Structure):
+    _fields_ = [("n_ctx", C.c_int32), ("n_deep", C.c_int32), ("shallow", C.c_void_p), ("deep", C.c_void_p)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+        f"g.build()'` (or `make -C clip_calibration_amd/csrc`). There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+_SIGNATURES = {
+    "clipmi_abi_version": (C.c_int, []),
+    "clipmi_strerror": (C.c_char_p, [_i]),
+    "clipmi_last_error": (C.c_char_p, []),
+    "clipmi_gemm_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_layernorm": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "clipmi_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "clipmi_calibrate_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "clipmi_ece_accumulate": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "clipmi_create": (_i, [C.POINTER(Geometry), C.POINTER(_vp)]),
+    "clipmi_destroy": (_i, [_vp]),
+    "clipmi_set_vision_weights": (_i, [_vp, C.POINTER(VisionWeights)]),
+    "clipmi_set_text_weights": (_i, [_vp, C.POINTER(TextWeights)]),
+    "clipmi_vision_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "clipmi_text_workspace_bytes": (_sz, [_vp, _i]),
+    "clipmi_encode_image": (_i, [_vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _vp]),
+    "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _vp]),
+    "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _vp]),
+    "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "clipmi_profile_mlp_gemm": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:  # pragma: no cover
+        raise ImportError(f"{LIB_PATH} does not export {_name}; rebuild the extension") from e
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.clipmi_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH}: ABI version {lib.clipmi_abi_version()} != {ABI_VERSION}; rebuild the extension")
+
+
+def last_error() -> str:
+    return (lib.clipmi_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise ClipmiError(rc, what, last_error() or (lib.clipmi_strerror(rc) or b"").decode())
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

@@ -1,0 +1,421 @@
+// C ABI of libclipmi.so (include/clipmi.h): error plumbing, the model handle and the tower drivers, i.e. the
+// sequence of kernel launches that stands in for VisionTransformer.forward / Transformer.forward / encode_text
+// (reference clip/model.py:394-424, 334-359, 600-613).  Host-side C++ only; kernels live in the other .hip files.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace clipmi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CLIPMI_ERR_HIP;
+  }
+  return CLIPMI_OK;
+}
+
+}  // namespace clipmi
+
+using namespace clipmi;
+
+struct clipmi_model {
+  clipmi_geometry g;
+  bool has_vision = false, has_text = false;
+  clipmi_vision_weights vw;
+  clipmi_text_weights tw;
+  std::vector<clipmi_block_weights> vblocks, tblocks;
+  int grid() const { return g.image_resolution / g.patch_size; }
+  int tokens0() const { return grid() * grid() + 1; }
+  int kpad() const { return round_up(3 * g.patch_size * g.patch_size, 64); }
+};
+
+namespace {
+
+// Workspace of one transformer tower over M = n_seq * L token rows of width D.
+struct TowerWs {
+  float* xres;    // [M, D]  fp32 residual stream
+  half_t* xn;     // [M, D]  LayerNorm output / generic fp16 row buffer
+  half_t* qkv;    // [M, 3D] (vision: aliased by the fp32 pre-ln_pre embeddings [M, D])
+  half_t* att;    // [M, D]
+  half_t* hid;    // [M, 4D] (vision: aliased by the im2col matrix)
+  int32_t* idx;   // [2 * n_seq] eot / gather rows (text)
+  size_t bytes;
+};
+
+TowerWs carve(void* base, int64_t M, int D, int n_seq) {
+  TowerWs w;
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    char* r = p ? p + off : nullptr;
+    off += align256(n);
+    return r;
+  };
+  w.xres = reinterpret_cast<float*>(take((size_t)M * D * 4));
+  w.xn = reinterpret_cast<half_t*>(take((size_t)M * D * 2));
+  w.qkv = reinterpret_cast<half_t*>(take((size_t)M * D * 6));
+  w.att = reinterpret_cast<half_t*>(take((size_t)M * D * 2));
+  w.hid = reinterpret_cast<half_t*>(take((size_t)M * D * 8));
+  w.idx = reinterpret_cast<int32_t*>(take((size_t)n_seq * 8));
+  w.bytes = off;
+  return w;
+}
+
+int check_block(const clipmi_block_weights& b) {
+  const void* ptrs[] = {b.ln1_g, b.ln1_b, b.w_qkv, b.b_qkv, b.w_out, b.b_out, b.ln2_g, b.ln2_b, b.w_fc, b.b_fc, b.w_proj, b.b_proj};
+  for (const void* p : ptrs) {
+    CLIPMI_REQUIRE(p != nullptr, CLIPMI_ERR_ARG, "block weights: null pointer");
+    CLIPMI_REQUIRE((uintptr_t)p % 16 == 0, CLIPMI_ERR_ARG, "block weights: pointers must be 16-byte aligned");
+  }
+  return CLIPMI_OK;
+}
+
+// One ResidualAttentionBlock (clip/model.py:185-188) over M = n_seq*L rows.
+int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, hipStream_t s) {
+  const int M = n_seq * L, H = D / 64;
+  int rc;
+  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+  GemmArgs a{};
+  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_qkv; a.ldw = D; a.bias = b.b_qkv; a.out = w.qkv; a.ldo = 3 * D;
+  a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
+  if ((rc = launch_gemm(a, s))) return rc;
+  if ((rc = launch_attention(w.qkv, w.att, n_seq, L, H, causal, s))) return rc;
+  a = GemmArgs{};
+  a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
+  a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+  if ((rc = launch_gemm(a, s))) return rc;
+  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+  a = GemmArgs{};
+  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_fc; a.ldw = D; a.bias = b.b_fc; a.out = w.hid; a.ldo = 4 * D;
+  a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
+  if ((rc = launch_gemm(a, s))) return rc;
+  a = GemmArgs{};
+  a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
+  a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+  return launch_gemm(a, s);
+}
+
+int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
+  if (!hook) return CLIPMI_OK;
+  CLIPMI_REQUIRE(hook->n_ctx > 0 && hook->n_deep >= 0 && hook->n_deep <= layers - 1, CLIPMI_ERR_SHAPE,
+                 "prompt hook: n_ctx=%d n_deep=%d invalid for %d layers", hook->n_ctx, hook->n_deep, layers);
+  CLIPMI_REQUIRE(hook->n_deep == 0 || hook->deep, CLIPMI_ERR_ARG, "prompt hook: deep prompts missing");
+  CLIPMI_REQUIRE(!vision || hook->shallow, CLIPMI_ERR_ARG, "prompt hook: the vision tower needs the shallow prompt");
+  return CLIPMI_OK;
+}
+
+// text blocks on w.xres (already holds embeddings + pos)
+int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, hipStream_t s) {
+  const int L = m->g.context_length, D = m->g.text_width;
+  int rc;
+  for (int i = 0; i < m->g.text_layers; ++i) {
+    if (hook && i > 0 && i - 1 < hook->n_deep) {
+      if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * hook->n_ctx * D, C, L, D, 1, hook->n_ctx, s))) return rc;
+    }
+    if ((rc = run_block(m->tblocks[i], w, C, L, D, 1, s))) return rc;
+  }
+  return CLIPMI_OK;
+}
+
+// ln_final on the EOT rows + text_projection (clip/model.py:607-611)
+int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, hipStream_t s) {
+  const int D = m->g.text_width, E = m->g.embed_dim;
+  int rc;
+  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, w.xn, CLIPMI_F16, D, C, D, 1e-5f, s)))
+    return rc;
+  GemmArgs a{};
+  a.A = w.xn; a.lda = D; a.W = (const half_t*)m->tw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
+  a.M = C; a.N = E; a.K = D; a.epilogue = CLIPMI_EPI_NONE;
+  return launch_gemm(a, s);
+}
+
+int text_prologue(clipmi_model* m, int n_prompts, const clipmi_prompt_hook* hook, void* ws, size_t ws_bytes, TowerWs* w) {
+  CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "null model");
+  CLIPMI_REQUIRE(m->has_text, CLIPMI_ERR_STATE, "text weights not bound (clipmi_set_text_weights)");
+  CLIPMI_REQUIRE(n_prompts >= 0, CLIPMI_ERR_SHAPE, "n_prompts=%d", n_prompts);
+  CLIPMI_REQUIRE((int64_t)n_prompts * m->g.context_length < (1ll << 31), CLIPMI_ERR_SHAPE, "too many prompt tokens");
+  int rc = check_hook(hook, m->g.text_layers, false);
+  if (rc) return rc;
+  if (hook) CLIPMI_REQUIRE(1 + hook->n_ctx <= m->g.context_length, CLIPMI_ERR_SHAPE, "prompt hook: n_ctx too large");
+  *w = carve(ws, (int64_t)n_prompts * m->g.context_length, m->g.text_width, n_prompts);
+  CLIPMI_REQUIRE(ws || n_prompts == 0, CLIPMI_ERR_ARG, "null workspace");
+  CLIPMI_REQUIRE(ws_bytes >= w->bytes, CLIPMI_ERR_WORKSPACE, "text workspace too small: %zu < %zu", ws_bytes, w->bytes);
+  CLIPMI_REQUIRE((uintptr_t)ws % 256 == 0, CLIPMI_ERR_ARG, "workspace must be 256-byte aligned");
+  return CLIPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clipmi_abi_version(void) { return CLIPMI_ABI_VERSION; }
+
+const char* clipmi_strerror(int code) {
+  switch (code) {
+    case CLIPMI_OK: return "ok";
+    case CLIPMI_ERR_ARG: return "invalid argument";
+    case CLIPMI_ERR_SHAPE: return "unsupported shape";
+    case CLIPMI_ERR_HIP: return "HIP runtime error";
+    case CLIPMI_ERR_WORKSPACE: return "workspace too small";
+    case CLIPMI_ERR_STATE: return "weights not bound";
+    default: return "unknown error";
+  }
+}
+
+const char* clipmi_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- operator level
+int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+                    void* out, int64_t ldo, int out_dtype, int M, int N, int K, int epilogue, clipmi_stream_t stream) {
+  CLIPMI_REQUIRE(epilogue >= CLIPMI_EPI_NONE && epilogue <= CLIPMI_EPI_BIAS_RESIDUAL, CLIPMI_ERR_ARG, "gemm: bad epilogue %d", epilogue);
+  if (M == 0) return CLIPMI_OK;
+  GemmArgs a{};
+  a.A = (const half_t*)A; a.lda = lda; a.W = (const half_t*)W; a.ldw = ldw; a.bias = bias; a.residual = residual;
+  a.out = out; a.ldo = ldo; a.out_dtype = out_dtype; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue;
+  return launch_gemm(a, (hipStream_t)stream);
+}
+
+int clipmi_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx, const float* gamma,
+                     const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
+                     clipmi_stream_t stream) {
+  return launch_layernorm(x, x_dtype, in_stride, gather_idx, gamma, beta, y, y_dtype, out_stride, rows, D, eps, (hipStream_t)stream);
+}
+
+int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal, clipmi_stream_t stream) {
+  return launch_attention((const half_t*)qkv, (half_t*)out, N, L, H, causal, (hipStream_t)stream);
+}
+
+int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad, clipmi_stream_t stream) {
+  return launch_patchify(image, image_dtype, (half_t*)col, B, R, P, Kpad, (hipStream_t)stream);
+}
+
+int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, clipmi_stream_t stream) {
+  return launch_l2_normalize(in, in_dtype, out, rows, E, (hipStream_t)stream);
+}
+
+int clipmi_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits, float* conf,
+                  int32_t* pred, int B, int C, int E, clipmi_stream_t stream) {
+  return launch_logits(img_n, txt_n, scale, dac_conf, logits, conf, pred, B, C, E, (hipStream_t)stream);
+}
+
+int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
+  return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
+}
+
+int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins, int n_bins,
+                          clipmi_stream_t stream) {
+  return launch_ece_accumulate(conf, pred, labels, n, bins, n_bins, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- model level
+int clipmi_create(const clipmi_geometry* geom, clipmi_model** out) {
+  CLIPMI_REQUIRE(geom && out, CLIPMI_ERR_ARG, "create: null pointer");
+  const clipmi_geometry& g = *geom;
+  CLIPMI_REQUIRE(g.vision_width > 0 && g.vision_width % 64 == 0 && g.text_width > 0 && g.text_width % 64 == 0, CLIPMI_ERR_SHAPE,
+                 "create: widths must be multiples of 64 (head_dim 64): vision %d text %d", g.vision_width, g.text_width);
+  CLIPMI_REQUIRE(g.text_heads * 64 == g.text_width, CLIPMI_ERR_SHAPE, "create: text_heads*64 != text_width");
+  CLIPMI_REQUIRE(g.patch_size > 0 && g.image_resolution % g.patch_size == 0, CLIPMI_ERR_SHAPE, "create: resolution %% patch != 0");
+  CLIPMI_REQUIRE(g.embed_dim > 0 && g.embed_dim % 16 == 0, CLIPMI_ERR_SHAPE, "create: embed_dim must be a multiple of 16");
+  CLIPMI_REQUIRE(g.vision_layers > 0 && g.text_layers > 0 && g.context_length > 0 && g.vocab_size > 0, CLIPMI_ERR_SHAPE,
+                 "create: non-positive geometry field");
+  clipmi_model* m = new (std::nothrow) clipmi_model();
+  CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "create: out of host memory");
+  m->g = g;
+  *out = m;
+  return CLIPMI_OK;
+}
+
+int clipmi_destroy(clipmi_model* m) {
+  delete m;
+  return CLIPMI_OK;
+}
+
+int clipmi_set_vision_weights(clipmi_model* m, const clipmi_vision_weights* w) {
+  CLIPMI_REQUIRE(m && w && w->blocks, CLIPMI_ERR_ARG, "set_vision_weights: null pointer");
+  const void* ptrs[] = {w->conv_w, w->class_embedding, w->positional_embedding, w->ln_pre_g, w->ln_pre_b, w->ln_post_g, w->ln_post_b, w->proj_t};
+  for (const void* p : ptrs) CLIPMI_REQUIRE(p && (uintptr_t)p % 16 == 0, CLIPMI_ERR_ARG, "set_vision_weights: null/unaligned pointer");
+  for (int i = 0; i < m->g.vision_layers; ++i) {
+    int rc = check_block(w->blocks[i]);
+    if (rc) return rc;
+  }
+  m->vblocks.assign(w->blocks, w->blocks + m->g.vision_layers);
+  m->vw = *w;
+  m->vw.blocks = m->vblocks.data();
+  m->has_vision = true;
+  return CLIPMI_OK;
+}
+
+int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w) {
+  CLIPMI_REQUIRE(m && w && w->blocks, CLIPMI_ERR_ARG, "set_text_weights: null pointer");
+  const void* ptrs[] = {w->token_embedding, w->positional_embedding, w->ln_final_g, w->ln_final_b, w->proj_t};
+  for (const void* p : ptrs) CLIPMI_REQUIRE(p && (uintptr_t)p % 16 == 0, CLIPMI_ERR_ARG, "set_text_weights: null/unaligned pointer");
+  for (int i = 0; i < m->g.text_layers; ++i) {
+    int rc = check_block(w->blocks[i]);
+    if (rc) return rc;
+  }
+  m->tblocks.assign(w->blocks, w->blocks + m->g.text_layers);
+  m->tw = *w;
+  m->tw.blocks = m->tblocks.data();
+  m->has_text = true;
+  return CLIPMI_OK;
+}
+
+size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx) {
+  if (!m || batch < 0 || n_ctx < 0) return 0;
+  return carve(nullptr, (int64_t)batch * (m->tokens0() + n_ctx), m->g.vision_width, batch).bytes;
+}
+
+size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
+  if (!m || n_prompts < 0) return 0;
+  return carve(nullptr, (int64_t)n_prompts * m->g.context_length, m->g.text_width, n_prompts).bytes;
+}
+
+int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
+                        void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+  CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "encode_image: null model");
+  CLIPMI_REQUIRE(m->has_vision, CLIPMI_ERR_STATE, "vision weights not bound (clipmi_set_vision_weights)");
+  CLIPMI_REQUIRE(batch >= 0, CLIPMI_ERR_SHAPE, "encode_image: batch=%d", batch);
+  if (batch == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(image && out && workspace, CLIPMI_ERR_ARG, "encode_image: null pointer");
+  int rc = check_hook(hook, m->g.vision_layers, true);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const clipmi_geometry& g = m->g;
+  const int G = m->grid(), L0 = m->tokens0(), n_ctx = hook ? hook->n_ctx : 0, L = L0 + n_ctx;
+  const int D = g.vision_width, E = g.embed_dim, Kpad = m->kpad();
+  CLIPMI_REQUIRE((int64_t)batch * L < (1ll << 31) / 4, CLIPMI_ERR_SHAPE, "encode_image: batch too large for one call");
+  CLIPMI_REQUIRE(Kpad * 2 <= D * 8, CLIPMI_ERR_SHAPE, "encode_image: im2col row does not fit the aliased MLP buffer");
+  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch);
+  CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "vision workspace too small: %zu < %zu", workspace_bytes, w.bytes);
+  CLIPMI_REQUIRE((uintptr_t)workspace % 256 == 0, CLIPMI_ERR_ARG, "workspace must be 256-byte aligned");
+
+  half_t* col = w.hid;                             // [B*G*G, Kpad]
+  float* x0 = reinterpret_cast<float*>(w.qkv);     // [B*L, D] embeddings before ln_pre
+  if ((rc = launch_patchify(image, image_dtype, col, batch, g.image_resolution, g.patch_size, Kpad, s))) return rc;
+  GemmArgs a{};
+  a.A = col; a.lda = Kpad; a.W = (const half_t*)m->vw.conv_w; a.ldw = Kpad; a.out = x0; a.ldo = D; a.out_dtype = CLIPMI_F32;
+  a.M = batch * G * G; a.N = D; a.K = Kpad; a.epilogue = EPI_PATCH_POS;
+  a.pos = m->vw.positional_embedding; a.patches = G * G; a.tokens = L;
+  if ((rc = launch_gemm(a, s))) return rc;
+  if ((rc = launch_cls_and_ctx_rows(x0, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, batch, L0,
+                                    n_ctx, D, s)))
+    return rc;
+  if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, w.xres, CLIPMI_F32, D, batch * L, D, 1e-5f, s)))
+    return rc;
+  for (int i = 0; i < g.vision_layers; ++i) {
+    if (hook && i > 0 && i - 1 < hook->n_deep) {
+      if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
+    }
+    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, s))) return rc;
+  }
+  // ln_post on the class token only, then @ proj (clip/model.py:419-422)
+  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, w.xn, CLIPMI_F16, D, batch, D,
+                             1e-5f, s)))
+    return rc;
+  a = GemmArgs{};
+  a.A = w.xn; a.lda = D; a.W = (const half_t*)m->vw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
+  a.M = batch; a.N = E; a.K = D; a.epilogue = CLIPMI_EPI_NONE;
+  return launch_gemm(a, s);
+}
+
+int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, const clipmi_prompt_hook* hook,
+                       void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+  TowerWs w;
+  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  if (n_prompts == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(x && y, CLIPMI_ERR_ARG, "text_blocks: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = m->g.context_length, D = m->g.text_width;
+  if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, D, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, hook, s))) return rc;
+  return launch_cast_f32(w.xres, y, dtype, (int64_t)n_prompts * L * D, s);
+}
+
+int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
+                        const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+  TowerWs w;
+  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  if (n_prompts == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(prompts && eot && out, CLIPMI_ERR_ARG, "text_encoder: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = m->g.context_length, D = m->g.text_width;
+  if ((rc = launch_add_pos(prompts, dtype, m->tw.positional_embedding, w.xres, n_prompts, L, D, s))) return rc;
+  if ((rc = launch_eot_rows(eot, w.idx + n_prompts, n_prompts, L, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, hook, s))) return rc;
+  return run_text_tail(m, w, n_prompts, out, s);
+}
+
+int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace, size_t workspace_bytes,
+                       clipmi_stream_t stream) {
+  TowerWs w;
+  int rc = text_prologue(m, n_prompts, nullptr, workspace, workspace_bytes, &w);
+  if (rc) return rc;
+  if (n_prompts == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(ids && out, CLIPMI_ERR_ARG, "encode_text: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = m->g.context_length, D = m->g.text_width;
+  if ((rc = launch_embed_tokens(ids, m->tw.token_embedding, m->tw.positional_embedding, w.xres, w.idx, n_prompts, L, D,
+                                m->g.vocab_size, s)))
+    return rc;
+  if ((rc = launch_eot_rows(w.idx, w.idx + n_prompts, n_prompts, L, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, nullptr, s))) return rc;
+  return run_text_tail(m, w, n_prompts, out, s);
+}
+
+int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspace, size_t workspace_bytes, float* ms_out,
+                            clipmi_stream_t stream) {
+  CLIPMI_REQUIRE(m && ms_out && workspace, CLIPMI_ERR_ARG, "profile: null pointer");
+  CLIPMI_REQUIRE(m->has_vision, CLIPMI_ERR_STATE, "vision weights not bound");
+  CLIPMI_REQUIRE(batch > 0 && iters > 0, CLIPMI_ERR_SHAPE, "profile: batch/iters must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const int L = m->tokens0(), D = m->g.vision_width;
+  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch);
+  CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "profile: workspace too small");
+  const clipmi_block_weights& b = m->vblocks[0];
+  GemmArgs a{};
+  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_fc; a.ldw = D; a.bias = b.b_fc; a.out = w.hid; a.ldo = 4 * D;
+  a.out_dtype = CLIPMI_F16; a.M = batch * L; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    set_error("profile: hipEventCreate failed");
+    return CLIPMI_ERR_HIP;
+  }
+  double total = 0.0;
+  int rc = CLIPMI_OK;
+  for (int i = 0; i < iters && rc == CLIPMI_OK; ++i) {
+    (void)hipEventRecord(e0, s);
+    rc = launch_gemm(a, s);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) {
+      set_error("profile: hipEventSynchronize failed");
+      rc = CLIPMI_ERR_HIP;
+      break;
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    total += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc == CLIPMI_OK) *ms_out = (float)(total / iters);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Internal declarations shared by the libclipmi.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/clipmi.h"
+
+namespace clipmi {
+
+typedef _Float16 half_t;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CLIPMI_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define CLIPMI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
+
+#define CLIPMI_REQUIRE(cond, code, ...)        \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::clipmi::set_error(__VA_ARGS__);        \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+// Extra epilogue used only by the vision tower: scatter patch rows into the token matrix and add the
+// positional embedding (clip/model.py:396-402).
+enum { EPI_PATCH_POS = 100 };
+
+struct GemmArgs {
+  const half_t* A; int64_t lda;
+  const half_t* W; int64_t ldw;
+  const float* bias;
+  const float* residual;
+  void* out; int64_t ldo; int out_dtype;
+  int M, N, K, epilogue;
+  // EPI_PATCH_POS: out row = (m / patches) * tokens + (m % patches) + 1, plus pos[(m % patches) + 1][n]
+  const float* pos; int patches; int tokens;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx, const float* gamma,
+                     const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
+                     hipStream_t s);
+int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
+int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
+// x0[b, 0, :] = cls + pos[0]; x0[b, tokens0 + j, :] = shallow[j] (MaPLe)     (clip/model.py:398-402,459-460)
+int launch_cls_and_ctx_rows(float* x0, const float* cls, const float* pos, const float* shallow, int B, int tokens0,
+                            int n_ctx, int D, hipStream_t s);
+// x[n, first + j, :] = prompt[j, :]  for j < n_ctx       (clip/model.py:301-328)
+int launch_overwrite_tokens(float* x, const float* prompt, int N, int L, int D, int first, int n_ctx, hipStream_t s);
+// xres[c,l,:] = float(src[c,l,:]) + (pos ? pos[l,:] : 0)
+int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int D, hipStream_t s);
+// xres[c,l,:] = table[ids[c,l],:] + pos[l,:] ; eot[c] = argmax_l ids[c,l]     (clip/model.py:601-603,611)
+int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* xres, int32_t* eot, int C,
+                        int L, int D, int vocab, hipStream_t s);
+int launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);  // rows[c] = c*L + eot[c]
+int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
+int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s);
+int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,
+                  float* conf, int32_t* pred, int B, int C, int E, hipStream_t s);
+int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
+int launch_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins,
+                          int n_bins, hipStream_t s);
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+}  // namespace clipmi

@@ -1,0 +1,388 @@
+"""Drop-in boundary: ``build_model(state_dict, design_details)`` and the attribute surface the reference's trainers
+consume from it (reference clip/model.py:656-699).
+
+The returned object is an ``nn.Module`` whose parameters carry the OpenAI checkpoint key names and the reference's
+dtype policy (``convert_weights``, clip/model.py:632-653), so ``state_dict()`` / ``load_state_dict`` / ``.float()`` /
+``.to(device)`` / ``named_parameters()`` behave as trainers expect -- but no forward arithmetic runs in torch: every
+``forward`` launches the HIP towers of ``libclipmi.so`` through the C ABI.  torch owns memory and streams only.
+Running any forward on a CPU tensor raises; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import F16, F32, check, lib
+from .synthetic import ClipGeometry, geometry_from_state_dict
+
+_DT = {torch.float16: F16, torch.float32: F32}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# parameter holders with the checkpoint's names
+# --------------------------------------------------------------------------------------------------------------------
+class LayerNorm(nn.Module):
+    """Callable LN with fp32 statistics whatever the activation dtype (reference clip/model.py:153-159)."""
+
+    def __init__(self, width: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(width))
+        self.bias = nn.Parameter(torch.zeros(width))
+        self.eps = 1e-5
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.layernorm(x, self.weight.detach().float(), self.bias.detach().float(), self.eps)
+
+
+class _Linear(nn.Module):
+    def __init__(self, n_in: int, n_out: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n_out, n_in))
+        self.bias = nn.Parameter(torch.zeros(n_out))
+
+
+class _Attn(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = _Linear(width, width)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.c_fc = _Linear(width, 4 * width)
+        self.c_proj = _Linear(4 * width, width)
+
+
+class _Block(nn.Module):
+    """Parameters of one ResidualAttentionBlock (clip/model.py:167-188); the arithmetic is in csrc/capi.hip run_block."""
+
+    def __init__(self, width: int):
+        super().__init__()
+        self.attn = _Attn(width)
+        self.ln_1 = LayerNorm(width)
+        self.mlp = _Mlp(width)
+        self.ln_2 = LayerNorm(width)
+
+
+class _Conv(nn.Module):
+    def __init__(self, width: int, patch: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(width, 3, patch, patch))
+
+
+_FP16_SUFFIXES = ("attn.in_proj_weight", "attn.in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight",
+                  "c_fc.bias", "c_proj.weight", "c_proj.bias", "conv1.weight")
+_FP16_NAMES = ("visual.proj", "text_projection")
+
+
+def _policy_dtype(name: str) -> torch.dtype:
+    """convert_weights (clip/model.py:632-653): fp16 for Conv/Linear/MHA weights+biases and the two projections,
+    fp32 for LayerNorm, class/positional/token embeddings and logit_scale."""
+    if name in _FP16_NAMES or name.endswith(_FP16_SUFFIXES):
+        return torch.float16
+    return torch.float32
+
+
+class TextTransformer(nn.Module):
+    """``clip_model.transformer``: callable on LND activations (coop.py:58-60) or on MaPLe's ``[x, deep_prompts, counter]``
+    list (maple.py:64-66); causal mask inside (clip/model.py:585-591)."""
+
+    def __init__(self, owner: "CLIP", width: int, layers: int):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.ModuleList([_Block(width) for _ in range(layers)])
+        object.__setattr__(self, "_owner", owner)  # not a sub-module (avoids a reference cycle in module traversal)
+
+    def forward(self, x):
+        owner: CLIP = self._owner
+        if isinstance(x, (list, tuple)):
+            xt, deep, counter = x
+            n_ctx = owner.design_details.get("maple_length", deep[0].shape[0] if len(deep) else 0)
+            y = owner._text_blocks(xt, list(deep), n_ctx)
+            used = min(len(deep), self.layers - 1)
+            return [y, deep, counter + used]
+        return owner._text_blocks(x, None, 0)
+
+
+class VisionTransformer(nn.Module):
+    """``clip_model.visual``: image [B,3,R,R] -> [B,E] (clip/model.py:394-424); with (shared_ctx, deep_prompts) the MaPLe
+    variant (clip/model.py:447-478)."""
+
+    def __init__(self, owner: "CLIP", g: ClipGeometry):
+        super().__init__()
+        self.input_resolution = g.image_resolution
+        self.output_dim = g.embed_dim
+        self.conv1 = _Conv(g.vision_width, g.vision_patch_size)
+        self.class_embedding = nn.Parameter(torch.empty(g.vision_width))
+        self.positional_embedding = nn.Parameter(torch.empty(g.vision_tokens, g.vision_width))
+        self.ln_pre = LayerNorm(g.vision_width)
+        self.transformer = nn.Module()
+        self.transformer.resblocks = nn.ModuleList([_Block(g.vision_width) for _ in range(g.vision_layers)])
+        self.transformer.width, self.transformer.layers = g.vision_width, g.vision_layers
+        self.ln_post = LayerNorm(g.vision_width)
+        self.proj = nn.Parameter(torch.empty(g.vision_width, g.embed_dim))
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, x: torch.Tensor, shared_ctx: Optional[torch.Tensor] = None,
+                compound_deeper_prompts: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        owner: CLIP = self._owner
+        return owner.image_features_f32(x, shared_ctx, compound_deeper_prompts).to(owner.dtype)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+class CLIP(nn.Module):
+    """Attribute surface of the reference ``CLIP`` (clip/model.py:481-629), HIP inside."""
+
+    def __init__(self, geom: ClipGeometry, design_details: Optional[dict] = None):
+        super().__init__()
+        self.geometry = geom
+        self.design_details = dict(design_details or {"trainer": "CoOp"})
+        self.context_length = geom.context_length
+        self.vocab_size = geom.vocab_size
+        self.visual = VisionTransformer(self, geom)
+        self.transformer = TextTransformer(self, geom.transformer_width, geom.transformer_layers)
+        self.token_embedding = nn.Embedding(geom.vocab_size, geom.transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(geom.context_length, geom.transformer_width))
+        self.ln_final = LayerNorm(geom.transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(geom.transformer_width, geom.embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * float(np.log(1 / 0.07)))
+        self._handle: Optional[int] = None
+        self._bound = None          # keeps the packed tensors + ctypes arrays alive
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    # ---- nn.Module protocol -----------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._bound = None          # tensors moved / re-typed: re-pack lazily
+        self._ws = {}
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._bound = None
+        return res
+
+    def rebind(self) -> None:
+        """Call after modifying tower parameters in place (the packed fp16/fp32 copies are otherwise reused)."""
+        self._bound = None
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib.clipmi_destroy(self._handle)
+        except Exception:
+            pass
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.visual.conv1.weight.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.visual.conv1.weight.device
+
+    # ---- weight binding ---------------------------------------------------------------------------------------
+    def _ensure_bound(self):
+        if self._bound is not None:
+            return
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("clipmi: the model must be on a ROCm GPU before it is run (model.to('cuda')); "
+                               "there is no CPU path")
+        g = self.geometry
+        if self._handle is None:
+            geo = _lib.Geometry(g.embed_dim, g.image_resolution, g.vision_patch_size, g.vision_width, g.vision_layers,
+                                g.context_length, g.vocab_size, g.transformer_width, g.transformer_layers,
+                                g.transformer_heads)
+            h = C.c_void_p()
+            check(lib.clipmi_create(C.byref(geo), C.byref(h)), "clipmi_create")
+            self._handle = h.value
+        keep: List[torch.Tensor] = []
+
+        def f16(t):  # GEMM operand: fp16, contiguous (aliases the parameter when it already is)
+            t = t.detach().to(torch.float16).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def f32(t):
+            t = t.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def blocks(mods) -> "C.Array":
+            arr = (_lib.BlockWeights * len(mods))()
+            for i, b in enumerate(mods):
+                arr[i] = _lib.BlockWeights(
+                    f32(b.ln_1.weight), f32(b.ln_1.bias), f16(b.attn.in_proj_weight), f32(b.attn.in_proj_bias),
+                    f16(b.attn.out_proj.weight), f32(b.attn.out_proj.bias), f32(b.ln_2.weight), f32(b.ln_2.bias),
+                    f16(b.mlp.c_fc.weight), f32(b.mlp.c_fc.bias), f16(b.mlp.c_proj.weight), f32(b.mlp.c_proj.bias))
+            return arr
+
+        v = self.visual
+        k = 3 * g.vision_patch_size ** 2
+        kpad = (k + 63) // 64 * 64
+        conv = torch.zeros(g.vision_width, kpad, dtype=torch.float16, device=dev)
+        conv[:, :k] = v.conv1.weight.detach().reshape(g.vision_width, k).to(torch.float16)
+        keep.append(conv)
+        vb = blocks(v.transformer.resblocks)
+        vw = _lib.VisionWeights(conv.data_ptr(), f32(v.class_embedding), f32(v.positional_embedding),
+                                f32(v.ln_pre.weight), f32(v.ln_pre.bias), f32(v.ln_post.weight), f32(v.ln_post.bias),
+                                f16(v.proj.detach().t()), vb)
+        check(lib.clipmi_set_vision_weights(self._handle, C.byref(vw)), "clipmi_set_vision_weights")
+        tb = blocks(self.transformer.resblocks)
+        tw = _lib.TextWeights(f32(self.token_embedding.weight), f32(self.positional_embedding),
+                              f32(self.ln_final.weight), f32(self.ln_final.bias),
+                              f16(self.text_projection.detach().t()), tb)
+        check(lib.clipmi_set_text_weights(self._handle, C.byref(tw)), "clipmi_set_text_weights")
+        self._bound = (keep, vb, tb)
+
+    def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(kind)
+        if ws is None or ws.numel() < nbytes or ws.device != self.device:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[kind] = ws
+        return ws
+
+    def _hook(self, n_ctx: int, shallow: Optional[torch.Tensor], deep: Optional[Sequence[torch.Tensor]], max_deep: int):
+        """clipmi_prompt_hook; prompts go through .half() exactly as the reference does (clip/model.py:306,323,459)."""
+        keep = []
+        ps = pd = None
+        if shallow is not None:
+            s = shallow.detach().to(self.device).half().float().contiguous()
+            keep.append(s)
+            ps = s.data_ptr()
+        deep = list(deep or [])[:max_deep]
+        if deep:
+            d = torch.stack([t.detach().to(self.device).half().float() for t in deep]).contiguous()
+            keep.append(d)
+            pd = d.data_ptr()
+        return _lib.PromptHook(n_ctx, len(deep), ps, pd), keep
+
+    # ---- towers -------------------------------------------------------------------------------------------------
+    def image_features_f32(self, image: torch.Tensor, shared_ctx: Optional[torch.Tensor] = None,
+                           deep_prompts: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """VisionTransformer.forward with fp32 output (un-normalised)."""
+        self._ensure_bound()
+        g = self.geometry
+        image = ops._dev(image, "image", (torch.float16, torch.float32))
+        if image.dim() != 4 or tuple(image.shape[1:]) != (3, g.image_resolution, g.image_resolution):
+            raise ValueError(f"encode_image: expected [B,3,{g.image_resolution},{g.image_resolution}], got {tuple(image.shape)}")
+        B = image.shape[0]
+        out = torch.empty(B, g.embed_dim, dtype=torch.float32, device=image.device)
+        hook_ref, keep, n_ctx = None, None, 0
+        if shared_ctx is not None:
+            n_ctx = shared_ctx.shape[0]
+            hook, keep = self._hook(n_ctx, shared_ctx, deep_prompts, g.vision_layers - 1)
+            hook_ref = C.byref(hook)
+        nbytes = lib.clipmi_vision_workspace_bytes(self._handle, B, n_ctx)
+        ws = self._workspace("vision", nbytes)
+        check(lib.clipmi_encode_image(self._handle, image.data_ptr(), _DT[image.dtype], B, hook_ref, out.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), ops._stream()), "clipmi_encode_image")
+        return out
+
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        """clip/model.py:597-598."""
+        return self.visual(image.type(self.dtype))
+
+    def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int) -> torch.Tensor:
+        self._ensure_bound()
+        g = self.geometry
+        x_lnd = ops._dev(x_lnd, "x", (torch.float16, torch.float32))
+        if x_lnd.dim() != 3 or x_lnd.shape[0] != g.context_length or x_lnd.shape[2] != g.transformer_width:
+            raise ValueError(f"transformer: expected LND [{g.context_length}, C, {g.transformer_width}], got {tuple(x_lnd.shape)}")
+        Cn = x_lnd.shape[1]
+        x = x_lnd.permute(1, 0, 2).contiguous()       # layout change only; the library is token-major
+        y = torch.empty_like(x)
+        hook_ref, keep = None, None
+        if deep:
+            hook, keep = self._hook(n_ctx, None, deep, g.transformer_layers - 1)
+            hook_ref = C.byref(hook)
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
+        check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
+                                     ws.numel(), ops._stream()), "clipmi_text_blocks")
+        return y.permute(1, 0, 2)
+
+    def text_encoder_f32(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor,
+                         deep_prompts: Optional[Sequence[torch.Tensor]] = None, n_ctx: int = 0) -> torch.Tensor:
+        """TextEncoder.forward fused (coop.py:56-67; maple.py:60-74): prompts [C,77,D] (no pos-emb) -> fp32 [C,E]."""
+        self._ensure_bound()
+        g = self.geometry
+        prompts = ops._dev(prompts, "prompts", (torch.float16, torch.float32))
+        if tuple(prompts.shape[1:]) != (g.context_length, g.transformer_width):
+            raise ValueError(f"text_encoder: expected [C,{g.context_length},{g.transformer_width}], got {tuple(prompts.shape)}")
+        Cn = prompts.shape[0]
+        eot = tokenized_prompts.to(prompts.device).argmax(dim=-1).to(torch.int32).contiguous()  # index plumbing
+        out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=prompts.device)
+        hook_ref, keep = None, None
+        if deep_prompts:
+            hook, keep = self._hook(n_ctx, None, deep_prompts, g.transformer_layers - 1)
+            hook_ref = C.byref(hook)
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
+        check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, hook_ref,
+                                      out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "clipmi_text_encoder")
+        return out
+
+    def text_features_f32(self, text: torch.Tensor) -> torch.Tensor:
+        self._ensure_bound()
+        g = self.geometry
+        text = ops._dev(text, "text", (torch.int64,))
+        if text.dim() != 2 or text.shape[1] != g.context_length:
+            raise ValueError(f"encode_text: expected ids [C,{g.context_length}], got {tuple(text.shape)}")
+        Cn = text.shape[0]
+        out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=text.device)
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
+        check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     ops._stream()), "clipmi_encode_text")
+        return out
+
+    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+        """clip/model.py:600-613."""
+        return self.text_features_f32(text).to(self.dtype)
+
+    def forward(self, image: torch.Tensor, text: torch.Tensor):
+        """clip/model.py:615-629: (logits_per_image, logits_per_text)."""
+        img_n = ops.l2_normalize(self.image_features_f32(image))
+        txt_n = ops.l2_normalize(self.text_features_f32(text))
+        scale = float(self.logit_scale.detach().exp())
+        lpi, _, _ = ops.logits_fused(img_n, txt_n, scale, None, want_conf_pred=False)
+        lpt, _, _ = ops.logits_fused(txt_n, img_n, scale, None, want_conf_pred=False)
+        return lpi.to(self.dtype), lpt.to(self.dtype)
+
+    def profile_mlp_gemm_ms(self, batch: int, iters: int = 20) -> float:
+        self._ensure_bound()
+        ws = self._workspace("vision", lib.clipmi_vision_workspace_bytes(self._handle, batch, 0))
+        ms = C.c_float()
+        check(lib.clipmi_profile_mlp_gemm(self._handle, batch, iters, ws.data_ptr(), ws.numel(), C.byref(ms), ops._stream()),
+              "clipmi_profile_mlp_gemm")
+        return float(ms.value)
+
+
+def convert_weights(model: nn.Module) -> None:
+    """Apply the reference dtype policy in place (clip/model.py:632-653)."""
+    for name, p in model.named_parameters():
+        p.data = p.data.to(_policy_dtype(name))
+
+
+def build_model(state_dict: Dict[str, torch.Tensor], design_details: Optional[dict] = None) -> CLIP:
+    """Same contract as the reference factory (clip/model.py:656-699): geometry from tensor shapes, fp16 weight
+    conversion, strict load with a printed non-strict fallback, eval mode.  ViT towers only."""
+    geom = geometry_from_state_dict(state_dict)
+    model = CLIP(geom, design_details)
+    for key in ("input_resolution", "context_length", "vocab_size"):
+        if key in state_dict:
+            del state_dict[key]
+    convert_weights(model)
+    try:
+        model.load_state_dict(state_dict)
+    except Exception:
+        missing, _ = model.load_state_dict(state_dict, strict=False)
+        print("Weights not found for some missing keys: ", missing)
+    return model.eval()

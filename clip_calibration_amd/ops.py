@@ -1,0 +1,146 @@
+"""Operator-level Python entry points: torch tensors in, HIP kernels through the C ABI, torch tensors out.
+
+torch is used for device memory and streams only; every wrapper checks device / dtype / contiguity and raises if the
+input is not a ROCm tensor -- nothing here computes on the CPU or with torch ops.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import F16, F32, check, lib
+
+_DT = {torch.float16: F16, torch.float32: F32}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtypes=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"clipmi: `{name}` must be a tensor on the GPU (got {getattr(t, 'device', type(t))}); "
+                           "the HIP path has no CPU fallback")
+    if dtypes is not None and t.dtype not in dtypes:
+        raise TypeError(f"clipmi: `{name}` has dtype {t.dtype}, expected one of {dtypes}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtypes) -> Tuple[Optional[torch.Tensor], Optional[int]]:
+    if t is None:
+        return None, None
+    t = _dev(t, name, dtypes)
+    return t, t.data_ptr()
+
+
+def gemm_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+             residual: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_NONE,
+             out_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``epi(a[M,K] @ w[N,K]^T)`` -- nn.Linear and friends (reference clip/model.py:174-176,183,422,611)."""
+    a = _dev(a, "a", (torch.float16,))
+    w = _dev(w, "w", (torch.float16,))
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
+    bias, pb = _opt(bias, "bias", (torch.float32,))
+    residual, pr = _opt(residual, "residual", (torch.float32,))
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    check(lib.clipmi_gemm_f16(a.data_ptr(), K, w.data_ptr(), K, pb, pr, out.data_ptr(), N, _DT[out.dtype],
+                              M, N, K, epilogue, _stream()), "clipmi_gemm_f16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None, gather_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32-statistics LayerNorm over the last dim (reference clip/model.py:153-159)."""
+    x = _dev(x, "x", (torch.float16, torch.float32))
+    gamma = _dev(gamma, "gamma", (torch.float32,))
+    beta = _dev(beta, "beta", (torch.float32,))
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    out_dtype = out_dtype or x.dtype
+    if gather_rows is not None:
+        gather_rows = _dev(gather_rows, "gather_rows", (torch.int32,))
+        rows = gather_rows.numel()
+        y = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+        pg = gather_rows.data_ptr()
+    else:
+        rows = x2.shape[0]
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+        pg = None
+    check(lib.clipmi_layernorm(x2.data_ptr(), _DT[x.dtype], D, pg, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                               _DT[out_dtype], D, rows, D, eps, _stream()), "clipmi_layernorm")
+    return y
+
+
+def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, n_head: int, causal: bool) -> torch.Tensor:
+    """qkv fp16 [n_seq*seq_len, 3*64*n_head] -> fp16 [n_seq*seq_len, 64*n_head] (SURVEY a-5a)."""
+    qkv = _dev(qkv, "qkv", (torch.float16,))
+    D = 64 * n_head
+    if qkv.shape != (n_seq * seq_len, 3 * D):
+        raise ValueError(f"attention: qkv shape {tuple(qkv.shape)} != {(n_seq * seq_len, 3 * D)}")
+    out = torch.empty(n_seq * seq_len, D, dtype=torch.float16, device=qkv.device)
+    check(lib.clipmi_attention(qkv.data_ptr(), out.data_ptr(), n_seq, seq_len, n_head, int(bool(causal)), _stream()),
+          "clipmi_attention")
+    return out
+
+
+def patchify(image: torch.Tensor, patch: int, kpad: Optional[int] = None) -> torch.Tensor:
+    image = _dev(image, "image", (torch.float16, torch.float32))
+    B, ch, R, R2 = image.shape
+    if ch != 3 or R != R2:
+        raise ValueError(f"patchify: expected [B,3,R,R], got {tuple(image.shape)}")
+    kpad = kpad or (3 * patch * patch + 63) // 64 * 64
+    g = R // patch
+    col = torch.empty(B * g * g, kpad, dtype=torch.float16, device=image.device)
+    check(lib.clipmi_patchify(image.data_ptr(), _DT[image.dtype], col.data_ptr(), B, R, patch, kpad, _stream()),
+          "clipmi_patchify")
+    return col
+
+
+def l2_normalize(f: torch.Tensor) -> torch.Tensor:
+    """``f / f.norm(dim=-1, keepdim=True)`` in fp32 (reference zsclip.py:99)."""
+    f = _dev(f, "features", (torch.float16, torch.float32))
+    rows, E = f.shape
+    out = torch.empty(rows, E, dtype=torch.float32, device=f.device)
+    check(lib.clipmi_l2_normalize(f.data_ptr(), _DT[f.dtype], out.data_ptr(), rows, E, _stream()), "clipmi_l2_normalize")
+    return out
+
+
+def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: Optional[torch.Tensor] = None,
+                 want_conf_pred: bool = True):
+    """(scale*img_n) @ txt_n^T  [+ DAC row scale]  [+ softmax top-1 conf / pred]; see include/clipmi.h."""
+    img_n = _dev(img_n, "img_n", (torch.float32,))
+    txt_n = _dev(txt_n, "txt_n", (torch.float32,))
+    B, E = img_n.shape
+    Cn = txt_n.shape[0]
+    if txt_n.shape[1] != E:
+        raise ValueError("logits: feature widths differ")
+    dac_conf, pd = _opt(dac_conf, "dac_conf", (torch.float32,))
+    if dac_conf is not None and dac_conf.numel() != Cn:
+        raise ValueError("logits: dac_conf must have one entry per class")
+    logits = torch.empty(B, Cn, dtype=torch.float32, device=img_n.device)
+    conf = pred = None
+    pc = pp = None
+    if want_conf_pred:
+        conf = torch.empty(B, dtype=torch.float32, device=img_n.device)
+        pred = torch.empty(B, dtype=torch.int32, device=img_n.device)
+        pc, pp = conf.data_ptr(), pred.data_ptr()
+    check(lib.clipmi_logits(img_n.data_ptr(), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(), pc, pp, B, Cn, E,
+                            _stream()), "clipmi_logits")
+    return logits, conf, pred
+
+
+def ece_accumulate(conf: torch.Tensor, pred: torch.Tensor, labels: torch.Tensor, bins: torch.Tensor, n_bins: int) -> None:
+    conf = _dev(conf, "conf", (torch.float32,))
+    pred = _dev(pred, "pred", (torch.int32,))
+    labels = _dev(labels, "labels", (torch.int64,))
+    bins = _dev(bins, "bins", (torch.float64,))
+    if bins.numel() != 3 * (n_bins + 1):
+        raise ValueError("ece_accumulate: bins must hold 3*(n_bins+1) float64")
+    check(lib.clipmi_ece_accumulate(conf.data_ptr(), pred.data_ptr(), labels.data_ptr(), conf.numel(), bins.data_ptr(),
+                                    n_bins, _stream()), "clipmi_ece_accumulate")

@@ -1,0 +1,115 @@
+"""CoOp (reference trainers/classification/coop.py:47-222) -- inference forward only."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..model import CLIP
+
+
+class TextEncoder(nn.Module):
+    """coop.py:47-67.  ``forward(prompts, tokenized_prompts)``: the reference adds the positional embedding, runs
+    ``clip_model.transformer``, ``ln_final``, gathers the EOT row and multiplies by ``text_projection``; here the same
+    chain is one fused device call (clipmi_text_encoder)."""
+
+    def __init__(self, clip_model: CLIP):
+        super().__init__()
+        object.__setattr__(self, "clip_model", clip_model)
+        self.dtype = clip_model.dtype
+
+    def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor, compound_prompts_deeper_text=None,
+                n_ctx: int = 0) -> torch.Tensor:
+        return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx)
+
+
+class PromptLearner(nn.Module):
+    """coop.py:70-144 with CLASS_TOKEN_POSITION == 'end' (the shipped configs): prompts = [SOS | ctx | class tokens, EOS, pad].
+    ``tokenized_prompts`` are the ids of ``"X X ... X {classname}."`` (coop.py:107-112)."""
+
+    def __init__(self, clip_model: CLIP, tokenized_prompts: torch.Tensor, n_ctx: int = 16, csc: bool = False,
+                 ctx_init_ids: Optional[torch.Tensor] = None, seed: int = 0):
+        super().__init__()
+        dtype = clip_model.dtype
+        dev = clip_model.device
+        ctx_dim = clip_model.ln_final.weight.shape[0]
+        n_cls = tokenized_prompts.shape[0]
+        tokenized_prompts = tokenized_prompts.to(dev)
+        with torch.no_grad():
+            if ctx_init_ids is not None:  # CTX_INIT: embedding of the given words (coop.py:82-90)
+                emb = clip_model.token_embedding(ctx_init_ids.to(dev)).type(dtype)
+                n_ctx = ctx_init_ids.shape[-1] - 2 if ctx_init_ids.dim() == 2 else n_ctx
+                ctx_vectors = emb[0, 1:1 + n_ctx, :].clone()
+            else:
+                g = torch.Generator().manual_seed(seed)
+                shape = (n_cls, n_ctx, ctx_dim) if csc else (n_ctx, ctx_dim)
+                ctx_vectors = (0.02 * torch.randn(*shape, generator=g)).to(dev, dtype)
+            embedding = clip_model.token_embedding(tokenized_prompts).type(dtype)
+        self.ctx = nn.Parameter(ctx_vectors)
+        self.register_buffer("token_prefix", embedding[:, :1, :])            # SOS
+        self.register_buffer("token_suffix", embedding[:, 1 + n_ctx:, :])    # class tokens, EOS, padding
+        self.n_cls, self.n_ctx = n_cls, n_ctx
+        self.tokenized_prompts = tokenized_prompts
+        self.class_token_position = "end"
+
+    def forward(self) -> torch.Tensor:
+        ctx = self.ctx
+        if ctx.dim() == 2:
+            ctx = ctx.unsqueeze(0).expand(self.n_cls, -1, -1)
+        return torch.cat([self.token_prefix, ctx.to(self.token_prefix.dtype), self.token_suffix], dim=1)  # layout only
+
+
+class CustomCLIP(nn.Module):
+    """coop.py:192-222.  eval ``forward(image) -> (logits, image_features, text_features)``.
+
+    The reference re-runs the 12-layer text tower on every batch although ``ctx`` is frozen at test time; the text
+    features are cached here and recomputed only when ``ctx`` changes (same outputs; precedent in the reference:
+    ProDA's set_classifier, proda.py:315-333).  ``logit_scale=1.0`` gives the cosine-logit base model of
+    trainers/calibration/base_model/coop.py:222-224."""
+
+    def __init__(self, clip_model: CLIP, tokenized_prompts: torch.Tensor, n_ctx: int = 16, csc: bool = False,
+                 logit_scale: Optional[float] = None, cache_text_features: bool = True, **kw):
+        super().__init__()
+        self.prompt_learner = PromptLearner(clip_model, tokenized_prompts, n_ctx, csc, **kw)
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.image_encoder = clip_model.visual
+        self.text_encoder = TextEncoder(clip_model)
+        self.logit_scale = clip_model.logit_scale
+        self.dtype = clip_model.dtype
+        object.__setattr__(self, "clip_model", clip_model)
+        self._fixed_scale = logit_scale
+        self.cache_text_features = cache_text_features
+        self._cache_key = None
+        self._cache = None
+
+    @property
+    def scale(self) -> float:
+        return float(self._fixed_scale) if self._fixed_scale is not None else float(self.logit_scale.detach().exp())
+
+    def _text_inputs(self):
+        return self.prompt_learner(), None, 0
+
+    @torch.no_grad()
+    def text_features(self) -> torch.Tensor:
+        params = [p for p in self.prompt_learner.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self.cache_text_features and key == self._cache_key and self._cache is not None:
+            return self._cache
+        prompts, deep, n_ctx = self._text_inputs()
+        tf = ops.l2_normalize(self.text_encoder(prompts, self.tokenized_prompts, deep, n_ctx))
+        self._cache_key, self._cache = key, tf
+        return tf
+
+    def _image_features(self, image: torch.Tensor) -> torch.Tensor:
+        return self.clip_model.image_features_f32(image)
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, label=None, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):
+        text_features = self.text_features()
+        image_features = ops.l2_normalize(self._image_features(image))
+        logits, conf, pred = ops.logits_fused(image_features, text_features, self.scale, dac_conf, want_conf_pred)
+        if want_conf_pred:
+            return logits, image_features, text_features, conf, pred
+        return logits, image_features, text_features

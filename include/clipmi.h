@@ -1,0 +1,209 @@
+/*
+ * clipmi.h -- C ABI of libclipmi.so: the MI355X (gfx950) CLIP inference-and-calibration hot path.
+ *
+ * The reference (ml-stat-Sustech/CLIP_Calibration) is pure Python and has no FFI of its own; its "operator
+ * API" for this path is the attribute surface of the object returned by clip.build_model (reference
+ * clip/model.py:656-699) plus DistanseAwareCalibration.predict and the ECE metric.  Each entry point below
+ * names the reference interface it replaces.  Conventions:
+ *
+ *   - every pointer is a DEVICE pointer owned by the caller (torch-ROCm tensors in the Python host code)
+ *     unless the parameter is documented as "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *     never synchronises the device; nothing is allocated or freed inside a launch call (graph-capture safe);
+ *   - weights are BORROWED: the handle stores the pointers given to clipmi_set_*_weights, the caller keeps the
+ *     tensors alive and re-binds after moving them;
+ *   - the return value is CLIPMI_OK (0) or a negative error code; nothing throws across the boundary;
+ *     clipmi_last_error() returns a thread-local detail string for the most recent failure;
+ *   - activations are token-major ("NLD"): row (n*L + l) of a [N*L, D] matrix.
+ *
+ * dtype codes: CLIPMI_F16 = IEEE half, CLIPMI_F32 = float.  All GEMMs run on v_mfma_f32_16x16x32_f16 with fp32
+ * accumulation; LayerNorm, softmax, residual stream, L2 norms and the final logits are fp32.
+ */
+#ifndef CLIPMI_H
+#define CLIPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIPMI_ABI_VERSION 1
+
+typedef void* clipmi_stream_t; /* hipStream_t */
+
+enum {
+  CLIPMI_OK = 0,
+  CLIPMI_ERR_ARG = -1,         /* null pointer / bad enum */
+  CLIPMI_ERR_SHAPE = -2,       /* shape the kernels do not support (see each call) */
+  CLIPMI_ERR_HIP = -3,         /* a HIP runtime call failed (launch error, no device) */
+  CLIPMI_ERR_WORKSPACE = -4,   /* workspace too small */
+  CLIPMI_ERR_STATE = -5        /* weights not bound */
+};
+
+enum { CLIPMI_F16 = 0, CLIPMI_F32 = 1 };
+
+enum {
+  CLIPMI_EPI_NONE = 0,          /* out = acc */
+  CLIPMI_EPI_BIAS = 1,          /* out = acc + bias[n] */
+  CLIPMI_EPI_BIAS_QUICKGELU = 2,/* t = acc + bias[n]; out = t * sigmoid(1.702 t)   (clip/model.py:162-164) */
+  CLIPMI_EPI_BIAS_RESIDUAL = 3  /* out = residual[m,n] + acc + bias[n]             (clip/model.py:186-187) */
+};
+
+int clipmi_abi_version(void);
+const char* clipmi_strerror(int code);
+const char* clipmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Operator level (stateless).  These are the kernels; the tower drivers below are sequences of them.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* nn.Linear / in_proj / out_proj / c_fc / c_proj / `x @ proj` (clip/model.py:174-176,183,422,611):
+ * out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W fp16 row-major with leading dimensions lda, ldw (elements);
+ * bias fp32[N] or NULL; residual fp32 [M,N] (ld = ldo) or NULL; out fp16 or fp32 (out_dtype), ld = ldo.
+ * Requires K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0; M, N otherwise arbitrary. */
+int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    const float* residual, void* out, int64_t ldo, int out_dtype,
+                    int M, int N, int K, int epilogue, clipmi_stream_t stream);
+
+/* LayerNorm subclass with fp32 statistics (clip/model.py:153-159): y[r,:] = (x[row(r),:] - mean) * rsqrt(var+eps)
+ * * gamma + beta.  row(r) = gather_idx ? gather_idx[r] : r, addressed with in_stride (elements).  D % 4 == 0,
+ * D <= 4096. */
+int clipmi_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx,
+                     const float* gamma, const float* beta, void* y, int y_dtype, int64_t out_stride,
+                     int rows, int D, float eps, clipmi_stream_t stream);
+
+/* nn.MultiheadAttention core after the packed in-projection (clip/model.py:181-183; SURVEY a-5a):
+ * qkv fp16 [N*L, 3*D] (q | k | v, head h at columns h*64..h*64+63 of each third), out fp16 [N*L, D] =
+ * merge_heads(softmax(q k^T / 8 + mask) v).  head_dim is 64 (D == 64*H).  causal != 0 applies the text
+ * tower's mask (clip/model.py:585-591). */
+int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal, clipmi_stream_t stream);
+
+/* image.type(dtype) + the im2col half of conv1 (clip/model.py:598,395-397): image [B,3,R,R] (fp32 or fp16,
+ * NCHW) -> col fp16 [B*(R/P)^2, Kpad], column c*P*P + ky*P + kx, zero padded up to Kpad (a multiple of 64). */
+int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad,
+                    clipmi_stream_t stream);
+
+/* Row L2 normalisation  f / ||f||  (zsclip.py:99; coop.py:212-213): in (fp16|fp32) [rows,E] -> out fp32. */
+int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, clipmi_stream_t stream);
+
+/* Fused  logits = (scale * img_n) @ txt_n^T  (zsclip.py:100-101, coop.py:215-217, tempscaling.py:53-56)
+ * + DistanseAwareCalibration.predict (distanse_aware_calibration.py:49-58: logits[i,:] *= conf[argmax_i])
+ * + softmax top-1 (vl_calibrator.py:91, vl_evaluator.py:68,83): conf[i] = max_c softmax(logits[i,:]),
+ * pred[i] = argmax.  img_n [B,E], txt_n [C,E] fp32, ALREADY L2-normalised.  dac_conf fp32[C] or NULL.
+ * logits fp32 [B,C] (required), conf fp32[B], pred int32[B] (either may be NULL).  E % 16 == 0. */
+int clipmi_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf,
+                  float* logits, float* conf, int32_t* pred, int B, int C, int E, clipmi_stream_t stream);
+
+/* The row pass of clipmi_logits alone, on logits that already exist -- DistanseAwareCalibration.predict
+ * (distanse_aware_calibration.py:49-58) + softmax top-1: pred = argmax_c logits[i,:]; if dac_conf != NULL the row is
+ * multiplied in place by dac_conf[pred]; conf[i] = max_c softmax(row).  conf / pred may be NULL. */
+int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C,
+                          clipmi_stream_t stream);
+
+/* Device-side accumulation of the ECE statistics (tools/metrics.py:90-130) -- SURVEY f-1.  bins: float64
+ * [3*(n_bins+1)] = per-bin (count, sum_conf, sum_correct), bin n_bins collects conf == 1.0 (the digitize
+ * quirk).  Accumulates over calls; zero it with hipMemsetAsync.  The final reduction to a scalar is host
+ * code (clip_calibration_amd.metrics.ece_from_bins). */
+int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n,
+                          double* bins, int n_bins, clipmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Model level.  One handle per CLIP model per GPU.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct clipmi_model clipmi_model;
+
+typedef struct clipmi_geometry {
+  int32_t embed_dim;        /* E */
+  int32_t image_resolution; /* R */
+  int32_t patch_size;       /* P */
+  int32_t vision_width;     /* Dv (multiple of 64) */
+  int32_t vision_layers;
+  int32_t context_length;   /* 77 */
+  int32_t vocab_size;
+  int32_t text_width;       /* Dt */
+  int32_t text_layers;
+  int32_t text_heads;       /* Dt / 64 */
+} clipmi_geometry;
+
+/* ResidualAttentionBlock parameters (clip/model.py:167-188).  GEMM weights fp16 [out,in] row-major exactly as in
+ * the checkpoint; biases and LayerNorm parameters fp32. */
+typedef struct clipmi_block_weights {
+  const float* ln1_g; const float* ln1_b;
+  const void* w_qkv;  const float* b_qkv;   /* attn.in_proj_weight [3D,D], in_proj_bias [3D] */
+  const void* w_out;  const float* b_out;   /* attn.out_proj [D,D] */
+  const float* ln2_g; const float* ln2_b;
+  const void* w_fc;   const float* b_fc;    /* mlp.c_fc [4D,D] */
+  const void* w_proj; const float* b_proj;  /* mlp.c_proj [D,4D] */
+} clipmi_block_weights;
+
+typedef struct clipmi_vision_weights {
+  const void* conv_w;                /* visual.conv1.weight as fp16 [Dv, Kpad], Kpad = roundup(3*P*P, 64), zero padded */
+  const float* class_embedding;      /* [Dv] */
+  const float* positional_embedding; /* [(R/P)^2 + 1, Dv] */
+  const float* ln_pre_g; const float* ln_pre_b;
+  const float* ln_post_g; const float* ln_post_b;
+  const void* proj_t;                /* visual.proj^T as fp16 [E, Dv] */
+  const clipmi_block_weights* blocks;/* host array [vision_layers] (copied by the call) */
+} clipmi_vision_weights;
+
+typedef struct clipmi_text_weights {
+  const float* token_embedding;      /* [vocab, Dt] fp32 */
+  const float* positional_embedding; /* [context_length, Dt] */
+  const float* ln_final_g; const float* ln_final_b;
+  const void* proj_t;                /* text_projection^T as fp16 [E, Dt] */
+  const clipmi_block_weights* blocks;/* host array [text_layers] (copied by the call) */
+} clipmi_text_weights;
+
+/* MaPLe prompt injection (clip/model.py:287-331,447-478; maple.py:170-187).  `shallow` (vision only) is
+ * appended after the positional embedding; deep[i] overwrites, before block i+1, the LAST n_ctx tokens (vision)
+ * or tokens 1..n_ctx (text).  fp32, already rounded through fp16 by the caller (the reference's .half()). */
+typedef struct clipmi_prompt_hook {
+  int32_t n_ctx;
+  int32_t n_deep;
+  const float* shallow;  /* [n_ctx, D] or NULL */
+  const float* deep;     /* [n_deep, n_ctx, D] or NULL */
+} clipmi_prompt_hook;
+
+int clipmi_create(const clipmi_geometry* geom, clipmi_model** out);
+int clipmi_destroy(clipmi_model* m);
+int clipmi_set_vision_weights(clipmi_model* m, const clipmi_vision_weights* w);
+int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w);
+
+/* Bytes of scratch the caller must pass to the tower calls for `batch` images / `n_prompts` prompts. */
+size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx);
+size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts);
+
+/* CLIP.encode_image / VisionTransformer.forward (clip/model.py:597-598,394-424; MaPLe :447-478 when hook != NULL):
+ * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns). */
+int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch,
+                        const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
+                        clipmi_stream_t stream);
+
+/* `clip_model.transformer(x)` as the trainers' TextEncoder uses it (coop.py:58-60, maple.py:64-66): the causal
+ * blocks only.  x fp16|fp32 [C, L, Dt] token-major in, y same dtype/shape out (x == y allowed). */
+int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts,
+                       const clipmi_prompt_hook* hook, void* workspace, size_t workspace_bytes,
+                       clipmi_stream_t stream);
+
+/* TextEncoder.forward (coop.py:56-67, maple.py:60-74): prompts (fp16|fp32) [C,L,Dt] WITHOUT positional embedding,
+ * eot int32[C] = tokenized_prompts.argmax(-1)  ->  out fp32 [C,E] = ln_final(blocks(prompts + pos))[eot] @ text_projection. */
+int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
+                        const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
+                        clipmi_stream_t stream);
+
+/* CLIP.encode_text (clip/model.py:600-613): ids int64 [C,L] -> out fp32 [C,E]; EOT row = argmax(ids), computed on device. */
+int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace,
+                       size_t workspace_bytes, clipmi_stream_t stream);
+
+/* Timing aid for bench.py: runs `iters` launches of the MLP up-projection GEMM of the vision tower
+ * (M = batch*tokens, N = 4*Dv, K = Dv, bias+QuickGELU epilogue) on `stream`, each bracketed by hipEvents on that
+ * stream, and returns the mean launch duration in milliseconds through *ms_out.  Synchronises the stream. */
+int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspace, size_t workspace_bytes,
+                            float* ms_out, clipmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPMI_H */

@@ -1,0 +1,130 @@
+"""CPU-only checks: the C-ABI library loads, exports every symbol include/clipmi.h declares, fails loudly without a
+GPU; host-side metric logic; the boundary's state_dict surface."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from clip_calibration_amd import _lib, metrics, synthetic as syn
+from clip_calibration_amd.model import build_model
+from conftest import load_golden
+from oracle import clip_oracle as orc
+
+
+def _header_functions():
+    src = open(_lib.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(clipmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"libclipmi.so does not export {name}"
+    assert sorted(_lib.exported_symbols()) == declared, "python binding and header disagree"
+    assert _lib.lib.clipmi_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every entry point must fail loudly (error code + message), never compute."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc = _lib.lib.clipmi_l2_normalize(ctypes.c_void_p(256), 1, ctypes.c_void_p(512), 4, 64, None)
+    assert rc == _lib.ERR_HIP and _lib.last_error()
+    sd = syn.synthetic_state_dict("tiny")
+    model = build_model(dict(sd), {"trainer": "CoOp"})
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model.encode_image(torch.zeros(1, 3, 64, 64))
+    from clip_calibration_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.l2_normalize(torch.zeros(2, 16))
+
+
+def test_argument_validation_needs_no_gpu():
+    L = _lib.lib
+    assert L.clipmi_gemm_f16(None, 64, None, 64, None, None, None, 64, 0, 4, 4, 64, 0, None) == _lib.ERR_ARG
+    p = ctypes.c_void_p(4096)
+    assert L.clipmi_gemm_f16(p, 48, p, 48, None, None, p, 8, 0, 8, 8, 48, 0, None) == _lib.ERR_SHAPE   # K % 64
+    assert "K=48" in _lib.last_error()
+    assert L.clipmi_gemm_f16(p, 64, p, 64, None, None, p, 8, 0, 8, 8, 64, 9, None) == _lib.ERR_ARG      # bad epilogue
+    assert L.clipmi_layernorm(p, 1, 6, None, p, p, p, 1, 6, 1, 6, 1e-5, None) == _lib.ERR_SHAPE       # D % 4
+    assert L.clipmi_logits(p, p, 1.0, None, p, None, None, 4, 4, 10, None) == _lib.ERR_SHAPE            # E % 16
+    geo = _lib.Geometry(512, 224, 16, 770, 12, 77, 49408, 512, 12, 8)
+    h = ctypes.c_void_p()
+    assert L.clipmi_create(ctypes.byref(geo), ctypes.byref(h)) == _lib.ERR_SHAPE                          # width % 64
+    geo = _lib.Geometry(512, 224, 16, 768, 12, 77, 49408, 512, 12, 8)
+    assert L.clipmi_create(ctypes.byref(geo), ctypes.byref(h)) == _lib.OK
+    assert L.clipmi_encode_image(h, p, 1, 1, None, p, p, 1 << 30, None) == _lib.ERR_STATE                # unbound weights
+    assert L.clipmi_vision_workspace_bytes(h, 256, 0) == pytest.approx(22 * 256 * 197 * 768, rel=1e-3)
+    assert L.clipmi_destroy(h) == _lib.OK
+
+
+def test_boundary_state_dict_surface():
+    sd = syn.synthetic_state_dict("tiny")
+    model = build_model(dict(sd), {"trainer": "CoOp", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0})
+    assert not model.training
+    got = model.state_dict()
+    assert list(got) and set(got) == set(sd)
+    # dtype policy of convert_weights (clip/model.py:632-653)
+    assert got["visual.conv1.weight"].dtype == torch.float16
+    assert got["visual.transformer.resblocks.0.attn.in_proj_weight"].dtype == torch.float16
+    assert got["transformer.resblocks.1.mlp.c_proj.bias"].dtype == torch.float16
+    assert got["visual.proj"].dtype == got["text_projection"].dtype == torch.float16
+    for k in ("visual.ln_pre.weight", "visual.class_embedding", "positional_embedding", "token_embedding.weight",
+              "ln_final.bias", "logit_scale", "visual.transformer.resblocks.0.ln_1.weight"):
+        assert got[k].dtype == torch.float32, k
+    for k, v in sd.items():
+        assert torch.equal(got[k].float(), v.float()), k   # synthetic weights are fp16-exact
+    assert model.dtype == torch.float16
+    assert model.float().dtype == torch.float32
+    assert model.visual.input_resolution == 64 and model.visual.output_dim == 128
+    assert model.ln_final.weight.shape[0] == 128 and model.positional_embedding.shape == (77, 128)
+    assert float(model.logit_scale.detach().exp()) == pytest.approx(100.0, rel=1e-3)
+    # frozen-parameter protocol used by the trainers (coop.py:252-258)
+    for name, p in model.named_parameters():
+        p.requires_grad_(False)
+    missing_ok = dict(sd)
+    del missing_ok["visual.proj"]
+    del missing_ok["logit_scale"]
+    m2 = build_model(missing_ok | {"visual.proj": sd["visual.proj"]}, None)   # non-strict fallback prints and continues
+    assert float(m2.logit_scale) == pytest.approx(np.log(1 / 0.07))
+    with pytest.raises(ValueError):
+        build_model({k: v for k, v in sd.items() if k != "visual.proj"}, None)   # ModifiedResNet: out of scope
+
+
+def test_host_ece_matches_reference_goldens():
+    g = load_golden("ece_cases.npz")
+    for n in sorted({k.split(":")[0] for k in g}):
+        conf, pred, gt, bins = g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], int(g[f"{n}:bins"])
+        # float32 confidences: the reference's np.mean accumulates in float32, this module in float64
+        tol = 1e-12 if conf.dtype == np.float64 else 2e-7
+        assert metrics.ECE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:ece"]), abs=tol), n
+        which = metrics.digitize_bins(conf, bins)
+        assert np.array_equal(which, np.digitize(conf, np.linspace(0, 1, bins + 1)) - 1)
+
+
+def test_host_ece_property():
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.floats(0.0, 1.0, width=32), min_size=1, max_size=200), st.integers(1, 20), st.integers(0, 2 ** 31))
+    def prop(confs, bins, seed):
+        rng = np.random.default_rng(seed)
+        conf = np.asarray(confs, dtype=np.float32)
+        pred = rng.integers(0, 5, conf.size)
+        gt = rng.integers(0, 5, conf.size)
+        assert metrics.ECE(conf, pred, gt, bins) == pytest.approx(orc.ece(conf, pred, gt, bins), abs=1e-6)
+
+    prop()
+
+
+def test_dac_fit_host():
+    from clip_calibration_amd.dac import DistanseAwareCalibration
+    g = load_golden("dac_cases.npz")
+    for n in ("c50", "c19", "k3"):
+        cal = DistanseAwareCalibration()
+        cal.fit(g[f"{n}:base_zs"], g[f"{n}:cur_zs"], g[f"{n}:base_tuned"], g[f"{n}:cur_tuned"], int(g[f"{n}:k"]))
+        np.testing.assert_allclose(cal.class_confidence, g[f"{n}:class_confidence"], rtol=1e-13)

@@ -1,0 +1,245 @@
+"""Model-level parity on a real MI355X: the HIP towers behind ``build_model`` against (a) fixtures produced by the
+reference itself (tests/golden) and (b) the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): logits within 1e-3 of the fp32 CPU path.  As SURVEY §7 derives, that bound is
+meaningful on COSINE logits (the reference's own fp16 path sits 2.9e-4 from its fp32 path on cosines, i.e. 0.03 at
+scale 100), so every check below compares cosine logits (= logits / exp(logit_scale)) with atol 1e-3, and scaled
+logits with the same bound times the scale.  |dECE| < 1e-3 absolute."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from clip_calibration_amd import synthetic as syn  # noqa: E402
+from oracle import clip_oracle as orc  # noqa: E402  (checker only)
+
+COS_TOL = 1e-3
+PLAIN = {"trainer": "CoOp", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0}
+
+
+def _build(gname, dd=None, seed=0):
+    from clip_calibration_amd.model import build_model
+    sd = syn.synthetic_state_dict(gname, seed=seed)
+    return sd, build_model(dict(sd), dict(dd or PLAIN)).cuda()
+
+
+def _cos(a, b):
+    a = a / np.linalg.norm(a, axis=-1, keepdims=True)
+    b = b / np.linalg.norm(b, axis=-1, keepdims=True)
+    return a @ b.T
+
+
+def _feat_close(got, ref, what):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, what
+    assert np.isfinite(got).all(), what
+    # direction: every row within 1e-3 in cosine-logit terms against every reference row
+    assert np.abs(_cos(got, ref) - _cos(ref, ref)).max() < COS_TOL, what
+    # magnitude: un-normalised features agree to 0.5 % of the largest entry
+    assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max(), what
+
+
+@pytest.mark.parametrize("gname,fname", [("tiny", "tiny_clip.npz"), ("tiny3", "tiny3_clip.npz")])
+def test_golden_tiny(gname, fname):
+    g = load_golden(fname)
+    sd, model = _build(gname)
+    images = torch.from_numpy(g["images"]).cuda()
+    ids = torch.from_numpy(g["ids"]).cuda()
+    with torch.no_grad():
+        img = model.image_features_f32(images)
+        txt = model.text_features_f32(ids)
+        lpi, lpt = model(images, ids)
+        enc_i = model.encode_image(images)
+        enc_t = model.encode_text(ids)
+    _feat_close(img.cpu().numpy(), g["image_features"], "image features")
+    _feat_close(txt.cpu().numpy(), g["text_features"], "text features")
+    assert enc_i.dtype == enc_t.dtype == model.dtype == torch.float16   # reference: output dtype = model.dtype
+    scale = float(sd["logit_scale"].exp())
+    assert np.abs(lpi.float().cpu().numpy() / scale - g["logits"] / scale).max() < COS_TOL + 2e-3   # fp16 output rounding of +-100
+    assert np.abs(lpt.float().cpu().numpy().T / scale - g["logits"] / scale).max() < COS_TOL + 2e-3
+    # fp32 logits through the fused kernel
+    from clip_calibration_amd import ops
+    lg, conf, pred = ops.logits_fused(ops.l2_normalize(img), ops.l2_normalize(txt), scale)
+    assert np.abs(lg.cpu().numpy() / scale - g["logits"] / scale).max() < COS_TOL
+    assert np.array_equal(pred.cpu().numpy(), g["logits"].argmax(1))
+
+
+@pytest.mark.parametrize("gname,fname", [("tiny", "tiny_clip.npz"), ("tiny3", "tiny3_clip.npz")])
+def test_golden_coop_text_encoder_both_call_styles(gname, fname):
+    g = load_golden(fname)
+    sd, model = _build(gname)
+    ids = torch.from_numpy(g["coop_ids"]).cuda()
+    prompts = torch.from_numpy(g["coop_prompts"]).cuda()
+    # (a) the mirror of trainers/classification/coop.py TextEncoder (fused device call)
+    from clip_calibration_amd.trainers import TextEncoder
+    tf = TextEncoder(model)(prompts, ids)
+    _feat_close(tf.cpu().numpy(), g["coop_text_features"], "fused text encoder")
+    # (b) the reference's own TextEncoder.forward statements, unchanged, on the attribute surface (coop.py:56-67)
+    dtype = model.dtype
+    with torch.no_grad():
+        x = prompts.type(dtype) + model.positional_embedding.type(dtype)
+        x = x.permute(1, 0, 2)
+        x = model.transformer(x)
+        x = x.permute(1, 0, 2)
+        x = model.ln_final(x).type(dtype)
+        x = x[torch.arange(x.shape[0]), ids.argmax(dim=-1)] @ model.text_projection
+    got = x.float().cpu().numpy()
+    assert np.abs(_cos(got, g["coop_text_features"]) - _cos(g["coop_text_features"], g["coop_text_features"])).max() < 3e-3  # fp16 activations at the boundary
+    # CoOp prompt assembly mirror
+    from clip_calibration_amd.trainers import PromptLearner
+    pl = PromptLearner(model, ids, n_ctx=g["coop_ctx"].shape[0])
+    with torch.no_grad():
+        pl.ctx.copy_(torch.from_numpy(g["coop_ctx"]).cuda())
+    assert np.array_equal(pl().float().cpu().numpy(), torch.from_numpy(g["coop_prompts"]).half().float().numpy())
+
+
+def test_golden_maple():
+    g = load_golden("tiny_clip.npz")
+    dd = dict(PLAIN, trainer="MaPLe", maple_length=2)
+    sd, model = _build("tiny", dd)
+    pl = {k[len("maple_pl:"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("maple_pl:")}
+    ids = torch.from_numpy(g["maple_ids"])
+    images = torch.from_numpy(g["images"]).cuda()
+    prompts, shared, deep_t, deep_v = orc.maple_prompt_learner(sd, ids, pl)   # tiny host projections
+    with torch.no_grad():
+        tf = model.text_encoder_f32(prompts.cuda(), ids.cuda(), [t.cuda() for t in deep_t], 2)
+        imf = model.image_features_f32(images, shared.cuda(), [t.cuda() for t in deep_v])
+        # reference call style: visual(image, shared_ctx, deep) and transformer([x, deep, 0]) (maple.py:64-66,207)
+        imf2 = model.visual(images.half(), shared.cuda().half(), [t.cuda() for t in deep_v])
+        x = (prompts.cuda().half() + model.positional_embedding.half()).permute(1, 0, 2)
+        out = model.transformer([x, [t.cuda() for t in deep_t], 0])
+    _feat_close(tf.cpu().numpy(), g["maple_text_features"], "maple text")
+    _feat_close(imf.cpu().numpy(), g["maple_image_features"], "maple image")
+    assert imf2.dtype == torch.float16 and torch.allclose(imf2.float(), imf, atol=2e-2, rtol=2e-2)
+    assert isinstance(out, list) and out[0].shape == x.shape and out[2] == 1   # 2-layer tower consumes one deep prompt
+    # the trainer mirror end to end
+    from clip_calibration_amd.trainers import MaPLeCLIP
+    mc = MaPLeCLIP(model, ids, n_ctx=2, prompt_depth=3)
+    with torch.no_grad():
+        mc.prompt_learner.ctx.copy_(pl["ctx"].cuda())
+        mc.prompt_learner.proj.weight.copy_(pl["proj.weight"].cuda()); mc.prompt_learner.proj.bias.copy_(pl["proj.bias"].cuda())
+        for i in range(2):
+            mc.prompt_learner.compound_prompts_text[i].copy_(pl[f"compound_prompts_text.{i}"].cuda())
+            mc.prompt_learner.compound_prompt_projections[i].weight.copy_(pl[f"compound_prompt_projections.{i}.weight"].cuda())
+            mc.prompt_learner.compound_prompt_projections[i].bias.copy_(pl[f"compound_prompt_projections.{i}.bias"].cuda())
+        logits, imgf, txtf = mc(images)
+    want = 100.0 * _cos(g["maple_image_features"], g["maple_text_features"])
+    assert np.abs(logits.cpu().numpy() - want).max() < 100 * COS_TOL
+
+
+def test_golden_vitb16():
+    g = load_golden("vitb16_seed0.npz")
+    sd, model = _build("ViT-B/16")
+    images = syn.synthetic_images(2, "ViT-B/16", seed=0).cuda()
+    ids = torch.from_numpy(g["ids"]).cuda()
+    with torch.no_grad():
+        img = model.image_features_f32(images)
+        txt = model.text_features_f32(ids)
+    _feat_close(img.cpu().numpy(), g["image_features"], "ViT-B/16 image features")
+    _feat_close(txt.cpu().numpy(), g["text_features"], "ViT-B/16 text features")
+    cos = _cos(img.cpu().numpy(), txt.cpu().numpy())
+    assert np.abs(cos - g["logits"] / 100.0).max() < COS_TOL
+    # and we are no further from fp32 than the reference's own fp16 path is (x2 slack)
+    ref16_err = np.abs(g["logits_fp16"] - g["logits"]).max() / 100.0
+    assert np.abs(cos - g["logits"] / 100.0).max() < max(2 * ref16_err, 2e-4)
+    # fp32-converted model (clip_model.float(), coop.py:243) gives the same answer and fp32 outputs
+    model.float()
+    with torch.no_grad():
+        e = model.encode_image(images)
+    assert e.dtype == torch.float32 and torch.allclose(e, img, atol=1e-6)
+
+
+@pytest.mark.parametrize("B", [1, 5, 32])
+def test_zeroshot_pipeline_vs_oracle(B):
+    """BASELINE config 1: ViT-B/16, C=100 prompts, synthetic batch; logits, (conf, pred) and ECE vs the CPU path."""
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
+    C = 100
+    sd, model = _build("ViT-B/16")
+    ids = syn.synthetic_token_ids(C, "ViT-B/16", seed=0)
+    images = syn.synthetic_images(B, "ViT-B/16", seed=B)
+    zs = ZeroshotCLIP(model, ids)
+    logits, imf, txf, conf, pred = zs.model_inference(images.cuda(), want_conf_pred=True)
+    # oracle
+    with torch.no_grad():
+        txt_ref = orc.l2_normalize(orc.encode_text(sd, ids))
+        lg_ref, img_ref, _ = orc.zeroshot_inference(sd, images, txt_ref)
+    assert np.abs(txf.cpu().numpy() @ txt_ref.numpy().T - (txt_ref @ txt_ref.t()).numpy()).max() < COS_TOL
+    assert np.abs(logits.cpu().numpy() - lg_ref.numpy()).max() < 100 * COS_TOL
+    assert np.abs(imf.cpu().numpy().astype(np.float64) ** 2).sum(1) == pytest.approx(1.0, abs=1e-5)
+    labels = syn.synthetic_labels(torch.from_numpy(lg_ref.numpy().argmax(1)), C, seed=B)
+    ece_ref, c_ref, p_ref = orc.calibrated_ece(lg_ref.numpy(), labels.numpy())
+    ev = DeviceCalibrationEvaluator(10)
+    ev.process(conf, pred, labels.cuda())
+    res = ev.evaluate()
+    assert abs(res["ece"] / 100.0 - ece_ref) < 1e-3
+    # predictions may legitimately flip only where the top-2 cosine gap is inside the tolerance
+    flips = np.nonzero(pred.cpu().numpy() != p_ref)[0]
+    for i in flips:
+        top2 = np.sort(lg_ref.numpy()[i])[-2:]
+        assert top2[1] - top2[0] < 2 * 100 * COS_TOL
+
+
+def test_coop_dac_tempscaling_pipeline_vs_oracle():
+    """BASELINE config 3 (scaled down in C): CoOp prompts -> cached text features; DAC fit on the four text-feature
+    sets; cosine base model + TempScaling scalar; DAC per-sample scale fused into the logits kernel."""
+    from clip_calibration_amd.trainers import CoOpCLIP, ZeroshotCLIP, CustomCLIPCalibration
+    from clip_calibration_amd.dac import DistanseAwareCalibration
+    C, B, n_ctx = 40, 16, 16
+    sd, model = _build("ViT-B/16")
+    ids_zs_base = syn.synthetic_token_ids(C, "ViT-B/16", seed=10)
+    ids_zs_new = syn.synthetic_token_ids(C, "ViT-B/16", seed=11)
+    ids_coop_base = syn.synthetic_token_ids(C, "ViT-B/16", seed=10, n_ctx_placeholders=n_ctx)
+    ids_coop_new = syn.synthetic_token_ids(C, "ViT-B/16", seed=11, n_ctx_placeholders=n_ctx)
+    images = syn.synthetic_images(B, "ViT-B/16", seed=7)
+    coop_new = CoOpCLIP(model, ids_coop_new, n_ctx=n_ctx, logit_scale=1.0, seed=3)       # cosine base model
+    coop_base = CoOpCLIP(model, ids_coop_base, n_ctx=n_ctx, logit_scale=1.0, seed=3)
+    ctx = coop_new.prompt_learner.ctx.detach().float().cpu()
+    # oracle text features
+    with torch.no_grad():
+        t_new = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_coop_new, ctx), ids_coop_new))
+        t_base = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_coop_base, ctx), ids_coop_base))
+        z_new = orc.l2_normalize(orc.encode_text(sd, ids_zs_new))
+        z_base = orc.l2_normalize(orc.encode_text(sd, ids_zs_base))
+    got_new = coop_new.text_features()
+    assert coop_new.text_features() is got_new                                   # cached while ctx is unchanged
+    assert np.abs(got_new.cpu().numpy() @ t_new.numpy().T - (t_new @ t_new.t()).numpy()).max() < COS_TOL
+    # DAC fit on device-produced features vs oracle-produced features
+    zs_new = ZeroshotCLIP(model, ids_zs_new); zs_base = ZeroshotCLIP(model, ids_zs_base)
+    cal = DistanseAwareCalibration()
+    cal.fit(zs_base.text_features.cpu().numpy(), zs_new.text_features.cpu().numpy(),
+            coop_base.text_features().cpu().numpy(), got_new.cpu().numpy(), 5)
+    conf_ref = orc.dac_fit(z_base.numpy(), z_new.numpy(), t_base.numpy(), t_new.numpy(), 5)
+    np.testing.assert_allclose(cal.class_confidence, conf_ref, rtol=5e-3)
+    # TempScaling wrapper: scale 100 on cosine logits, DAC fused
+    calib = CustomCLIPCalibration(coop_new).cuda()
+    dacc = cal.class_confidence_device("cuda")
+    logits, imf, txf, conf, pred = calib(images.cuda(), dac_conf=dacc, want_conf_pred=True)
+    with torch.no_grad():
+        lg_ref, _, _ = orc.clip_logits(orc.encode_image(sd, images), t_new, np.exp(4.6052))
+    lg_ref_dac = orc.dac_predict(lg_ref.numpy(), conf_ref)
+    assert np.abs(logits.cpu().numpy() - lg_ref_dac).max() < 100 * COS_TOL * 1.5
+    labels = syn.synthetic_labels(torch.from_numpy(lg_ref_dac.argmax(1)), C, seed=1)
+    ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy(), labels.numpy(), conf_ref)
+    from clip_calibration_amd.metrics import ECE
+    assert abs(ECE(conf.cpu().numpy(), pred.cpu().numpy(), labels.numpy()) - ece_ref) < 1e-3
+    # ctx update invalidates the cache
+    with torch.no_grad():
+        coop_new.prompt_learner.ctx.add_(0.01)
+    assert coop_new.text_features() is not got_new
+
+
+def test_stress_residual_magnitudes():
+    """Scaled-up residual branches (real CLIP has large outlier channels): still finite and within tolerance."""
+    from clip_calibration_amd.model import build_model
+    sd = syn.synthetic_state_dict("tiny", seed=5, gain=6.0)
+    model = build_model(dict(sd), dict(PLAIN)).cuda()
+    images = syn.synthetic_images(4, "tiny", seed=5)
+    with torch.no_grad():
+        got = model.image_features_f32(images.cuda()).cpu().numpy()
+        ref = orc.encode_image(sd, images).numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(_cos(got, ref) - _cos(ref, ref)).max() < 2e-3

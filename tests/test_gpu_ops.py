@@ -1,0 +1,206 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle.  Needs a real MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from oracle import clip_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from clip_calibration_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _ops
+
+
+def _cuda(t):
+    return t.cuda()
+
+
+# tolerance notes: operands are fp16-exact on both sides, accumulation is fp32 on both sides; what differs is the
+# summation order and (for fp16 outputs) one final rounding of 2^-11 relative.
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 192, 128), (197 * 3, 768, 768), (1000, 2304, 768),
+                                    (333, 512, 3072), (50432, 768, 768), (7, 64, 64), (1, 4, 64)])
+@pytest.mark.parametrize("epi", ["none", "bias", "gelu", "residual"])
+def test_gemm(ops, M, N, K, epi):
+    if M == 50432 and epi not in ("gelu", "residual"):
+        pytest.skip("full-size case runs once per output dtype")
+    from clip_calibration_amd import _lib
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = (torch.randn(M, K, generator=g)).half()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g)
+    ref = a.float() @ w.float().t()
+    if epi == "none":
+        out = ops.gemm_f16(_cuda(a), _cuda(w), epilogue=_lib.EPI_NONE, out_dtype=torch.float32)
+        tol = 2e-4
+    elif epi == "bias":
+        ref = ref + bias
+        out = ops.gemm_f16(_cuda(a), _cuda(w), _cuda(bias), epilogue=_lib.EPI_BIAS, out_dtype=torch.float16)
+        tol = 2e-3
+    elif epi == "gelu":
+        ref = orc.quick_gelu(ref + bias)
+        out = ops.gemm_f16(_cuda(a), _cuda(w), _cuda(bias), epilogue=_lib.EPI_BIAS_QUICKGELU, out_dtype=torch.float16)
+        tol = 2e-3
+    else:
+        ref = ref + bias + res
+        r = _cuda(res)
+        out = ops.gemm_f16(_cuda(a), _cuda(w), _cuda(bias), residual=r, epilogue=_lib.EPI_BIAS_RESIDUAL,
+                           out_dtype=torch.float32, out=r)   # in place, as the towers use it
+        tol = 2e-4
+    got = out.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from clip_calibration_amd._lib import ClipmiError
+    a = torch.zeros(8, 48, dtype=torch.float16, device="cuda")
+    w = torch.zeros(8, 48, dtype=torch.float16, device="cuda")
+    with pytest.raises(ClipmiError):
+        ops.gemm_f16(a, w)          # K % 64 != 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_f16(a.cpu(), w)    # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("rows,D", [(1, 64), (5, 128), (197 * 4, 768), (77 * 3, 512), (33, 1024), (9, 192), (3, 2048)])
+@pytest.mark.parametrize("dt_in,dt_out", [(torch.float32, torch.float16), (torch.float32, torch.float32),
+                                          (torch.float16, torch.float16)])
+def test_layernorm(ops, rows, D, dt_in, dt_out):
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(dt_in)
+    gamma = 1 + 0.1 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    ref = orc.layer_norm(x.float(), gamma, beta)
+    got = ops.layernorm(_cuda(x), _cuda(gamma), _cuda(beta), out_dtype=dt_out).float().cpu()
+    tol = 2e-3 if dt_out == torch.float16 else 2e-5
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=tol, atol=tol * 4)
+
+
+def test_layernorm_gather(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(40, 128, generator=g)
+    idx = torch.tensor([3, 39, 0, 17], dtype=torch.int32)
+    gamma, beta = torch.ones(128), torch.zeros(128)
+    ref = orc.layer_norm(x[idx.long()], gamma, beta)
+    got = ops.layernorm(_cuda(x), _cuda(gamma), _cuda(beta), gather_rows=_cuda(idx)).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=1e-5)
+
+
+def _attn_ref(qkv, n, l, h, causal):
+    d = 64 * h
+    q, k, v = qkv.float().reshape(n, l, 3 * d).split(d, dim=-1)
+    q = q.reshape(n, l, h, 64).transpose(1, 2)
+    k = k.reshape(n, l, h, 64).transpose(1, 2)
+    v = v.reshape(n, l, h, 64).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + orc.causal_mask(l)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n * l, d)
+
+
+@pytest.mark.parametrize("n,l,h,causal", [(2, 197, 12, False), (3, 77, 8, True), (2, 17, 2, False), (1, 10, 3, False),
+                                          (2, 199, 12, False), (1, 257, 16, False), (1, 577, 4, False), (2, 77, 1, True),
+                                          (1, 32, 1, True), (1, 1, 1, False), (1, 225, 2, True)])
+@pytest.mark.parametrize("tr", ["1", "0"])
+def test_attention(ops, n, l, h, causal, tr, monkeypatch):
+    g = torch.Generator().manual_seed(n * 1000 + l + h)
+    qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
+    ref = _attn_ref(qkv, n, l, h, causal)
+    got = ops.attention(_cuda(qkv), n, l, h, causal).float().cpu()
+    err = (got - ref).abs().max().item()
+    # P and V are fp16 operands of the PV product: ~2^-11 relative on values of size O(1)
+    assert err < 4e-3, f"max err {err}"
+
+
+def test_attention_peaked_rows(ops):
+    """softmax with a dominant key (forces large score ranges through the online rescale across key groups)."""
+    n, l, h = 1, 197, 2
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(n * l, 3 * 64 * h, generator=g)
+    qkv[:, :128] *= 6.0   # large queries -> peaked distributions
+    qkv[150, 128:256] *= 5.0  # one dominant key in the last key group
+    qkv = qkv.half()
+    ref = _attn_ref(qkv, n, l, h, False)
+    got = ops.attention(_cuda(qkv), n, l, h, False).float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 8e-3
+
+
+@pytest.mark.parametrize("B,R,P,dt", [(2, 224, 16, torch.float32), (3, 64, 16, torch.float16), (2, 28, 14, torch.float32),
+                                      (1, 336, 14, torch.float32), (2, 64, 32, torch.float32)])
+def test_patchify(ops, B, R, P, dt):
+    g = torch.Generator().manual_seed(R)
+    img = torch.randn(B, 3, R, R, generator=g).to(dt)
+    col = ops.patchify(_cuda(img), P).cpu()
+    gsz = R // P
+    ref = img.float().reshape(B, 3, gsz, P, gsz, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gsz * gsz, 3 * P * P).half()
+    k = 3 * P * P
+    assert col.shape == (B * gsz * gsz, (k + 63) // 64 * 64)
+    assert torch.equal(col[:, :k], ref)
+    assert (col[:, k:] == 0).all()
+
+
+def test_l2_and_logits_dac_conf_pred(ops):
+    g = load_golden("dac_cases.npz")
+    rng = np.random.default_rng(1)
+    for B, C, E in [(64, 50, 128), (256, 1000, 512), (17, 37, 64), (5, 3, 16)]:
+        img = torch.from_numpy(rng.normal(size=(B, E)).astype(np.float32))
+        txt = torch.from_numpy(rng.normal(size=(C, E)).astype(np.float32))
+        dacc = torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32))
+        img_n = ops.l2_normalize(_cuda(img))
+        txt_n = ops.l2_normalize(_cuda(txt.half()))     # fp16 input path
+        np.testing.assert_allclose(img_n.cpu().numpy(), orc.l2_normalize(img).numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(txt_n.cpu().numpy(), orc.l2_normalize(txt.half().float()).numpy(), rtol=1e-6, atol=1e-7)
+        ref_logits, _, _ = orc.clip_logits(img, txt.half().float(), 100.0)
+        # plain logits
+        lg, conf, pred = ops.logits_fused(img_n, txt_n, 100.0)
+        np.testing.assert_allclose(lg.cpu().numpy(), ref_logits.numpy(), atol=2e-4)   # |logit| <= 100, fp32 dot of 512
+        probs = orc.softmax_probs(lg.cpu().numpy().astype(np.float64))
+        c_ref, p_ref = orc.conf_pred(probs)
+        assert np.array_equal(pred.cpu().numpy(), p_ref)
+        np.testing.assert_allclose(conf.cpu().numpy(), c_ref, rtol=2e-5)
+        # DAC fused
+        lg2, conf2, pred2 = ops.logits_fused(img_n, txt_n, 100.0, _cuda(dacc))
+        ref2 = orc.dac_predict(lg.cpu().numpy(), dacc.numpy())
+        np.testing.assert_allclose(lg2.cpu().numpy(), ref2, rtol=1e-6, atol=1e-6)
+        c2, p2 = orc.conf_pred(orc.softmax_probs(ref2.astype(np.float64)))
+        assert np.array_equal(pred2.cpu().numpy(), p2)
+        np.testing.assert_allclose(conf2.cpu().numpy(), c2, rtol=2e-5)
+    # the reference's own DAC outputs (golden): numpy in / numpy out predict()
+    from clip_calibration_amd.dac import DistanseAwareCalibration
+    for n in ("c50", "c19", "k3"):
+        cal = DistanseAwareCalibration()
+        cal.fit(g[f"{n}:base_zs"], g[f"{n}:cur_zs"], g[f"{n}:base_tuned"], g[f"{n}:cur_tuned"], int(g[f"{n}:k"]))
+        np.testing.assert_allclose(cal.class_confidence, g[f"{n}:class_confidence"], rtol=1e-13)
+        out = cal.predict(g[f"{n}:logits"])
+        assert out.dtype == np.float32
+        np.testing.assert_allclose(out, g[f"{n}:scaled_logits"], rtol=2e-7, atol=0)
+
+
+def test_ece_device_accumulation(ops):
+    from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
+    from clip_calibration_amd.metrics import ECE
+    g = load_golden("ece_cases.npz")
+    for n in sorted({k.split(":")[0] for k in g}):
+        conf, pred, gt, bins = g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], int(g[f"{n}:bins"])
+        conf32 = conf.astype(np.float32)
+        want = orc.ece(conf32, pred, gt, bins)       # the device sees float32 confidences
+        ev = DeviceCalibrationEvaluator(bins)
+        half = len(conf) // 2                         # two calls: accumulation across batches
+        for sl in (slice(0, half), slice(half, None)):
+            if conf32[sl].size:
+                ev.process(torch.from_numpy(conf32[sl]).cuda(), torch.from_numpy(pred[sl].astype(np.int32)).cuda(),
+                           torch.from_numpy(gt[sl].astype(np.int64)).cuda())
+        res = ev.evaluate()
+        assert res["ece"] / 100.0 == pytest.approx(want, abs=1e-6), n
+        assert res["total"] == len(conf)
+        assert ECE(conf32, pred, gt, bins) == pytest.approx(want, abs=1e-6)
