@@ -237,12 +237,8 @@ int launch_t(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hi
 
 // CLIPMI_ATTN_NO_TR=1 selects the register-transposed V image instead of ds_read_b64_tr_b16 (A/B + bring-up aid).
 static bool use_tr() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CLIPMI_ATTN_NO_TR");
-    v = (e && e[0] == '1') ? 0 : 1;
-  }
-  return v == 1;
+  const char* e = getenv("CLIPMI_ATTN_NO_TR");
+  return !(e && e[0] == '1');
 }
 
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {

@@ -42,6 +42,7 @@ struct clipmi_model {
   int grid() const { return g.image_resolution / g.patch_size; }
   int tokens0() const { return grid() * grid() + 1; }
   int kpad() const { return round_up(3 * g.patch_size * g.patch_size, 64); }
+  size_t col_bytes(int batch) const { return (size_t)batch * grid() * grid() * kpad() * 2; }
 };
 
 namespace {
@@ -57,7 +58,7 @@ struct TowerWs {
   size_t bytes;
 };
 
-TowerWs carve(void* base, int64_t M, int D, int n_seq) {
+TowerWs carve(void* base, int64_t M, int D, int n_seq, size_t hid_min_bytes = 0) {
   TowerWs w;
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -70,7 +71,8 @@ TowerWs carve(void* base, int64_t M, int D, int n_seq) {
   w.xn = reinterpret_cast<half_t*>(take((size_t)M * D * 2));
   w.qkv = reinterpret_cast<half_t*>(take((size_t)M * D * 6));
   w.att = reinterpret_cast<half_t*>(take((size_t)M * D * 2));
-  w.hid = reinterpret_cast<half_t*>(take((size_t)M * D * 8));
+  const size_t hid_bytes = (size_t)M * D * 8;
+  w.hid = reinterpret_cast<half_t*>(take(hid_bytes > hid_min_bytes ? hid_bytes : hid_min_bytes));
   w.idx = reinterpret_cast<int32_t*>(take((size_t)n_seq * 8));
   w.bytes = off;
   return w;
@@ -277,7 +279,7 @@ int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w) {
 
 size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx) {
   if (!m || batch < 0 || n_ctx < 0) return 0;
-  return carve(nullptr, (int64_t)batch * (m->tokens0() + n_ctx), m->g.vision_width, batch).bytes;
+  return carve(nullptr, (int64_t)batch * (m->tokens0() + n_ctx), m->g.vision_width, batch, m->col_bytes(batch)).bytes;
 }
 
 size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
@@ -299,8 +301,7 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
   const int G = m->grid(), L0 = m->tokens0(), n_ctx = hook ? hook->n_ctx : 0, L = L0 + n_ctx;
   const int D = g.vision_width, E = g.embed_dim, Kpad = m->kpad();
   CLIPMI_REQUIRE((int64_t)batch * L < (1ll << 31) / 4, CLIPMI_ERR_SHAPE, "encode_image: batch too large for one call");
-  CLIPMI_REQUIRE(Kpad * 2 <= D * 8, CLIPMI_ERR_SHAPE, "encode_image: im2col row does not fit the aliased MLP buffer");
-  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch);
+  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch, m->col_bytes(batch));
   CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "vision workspace too small: %zu < %zu", workspace_bytes, w.bytes);
   CLIPMI_REQUIRE((uintptr_t)workspace % 256 == 0, CLIPMI_ERR_ARG, "workspace must be 256-byte aligned");
 
@@ -386,7 +387,7 @@ int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspa
   CLIPMI_REQUIRE(batch > 0 && iters > 0, CLIPMI_ERR_SHAPE, "profile: batch/iters must be positive");
   hipStream_t s = (hipStream_t)stream;
   const int L = m->tokens0(), D = m->g.vision_width;
-  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch);
+  const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch, m->col_bytes(batch));
   CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "profile: workspace too small");
   const clipmi_block_weights& b = m->vblocks[0];
   GemmArgs a{};

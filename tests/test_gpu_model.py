@@ -93,7 +93,7 @@ def test_golden_coop_text_encoder_both_call_styles(gname, fname):
     pl = PromptLearner(model, ids, n_ctx=g["coop_ctx"].shape[0])
     with torch.no_grad():
         pl.ctx.copy_(torch.from_numpy(g["coop_ctx"]).cuda())
-    assert np.array_equal(pl().float().cpu().numpy(), torch.from_numpy(g["coop_prompts"]).half().float().numpy())
+    assert np.array_equal(pl().detach().float().cpu().numpy(), torch.from_numpy(g["coop_prompts"]).half().float().numpy())
 
 
 def test_golden_maple():

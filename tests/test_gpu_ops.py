@@ -112,6 +112,7 @@ def _attn_ref(qkv, n, l, h, causal):
                                           (1, 32, 1, True), (1, 1, 1, False), (1, 225, 2, True)])
 @pytest.mark.parametrize("tr", ["1", "0"])
 def test_attention(ops, n, l, h, causal, tr, monkeypatch):
+    monkeypatch.setenv("CLIPMI_ATTN_NO_TR", "0" if tr == "1" else "1")   # both V staging paths
     g = torch.Generator().manual_seed(n * 1000 + l + h)
     qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
     ref = _attn_ref(qkv, n, l, h, causal)
