@@ -1,0 +1,74 @@
+"""N>1 host logic on CPU: world_size-2 gloo processes shard a batch, all-gather embeddings, merge ECE bins."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from clip_calibration_amd import metrics, parallel
+from oracle import clip_oracle as orc
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_global, ragged, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        emb = torch.from_numpy(rng.normal(size=(n_global, 32)).astype(np.float32))
+        emb = orc.l2_normalize(emb)
+        txt = orc.l2_normalize(torch.from_numpy(rng.normal(size=(11, 32)).astype(np.float32)))
+        labels = rng.integers(0, 11, n_global)
+        lo, hi = parallel.shard_bounds(n_global, rank, world)
+        local = emb[lo:hi].clone()
+        full = parallel.all_gather_ragged(local, n_global) if ragged else parallel.all_gather_embeddings(local)
+        assert torch.equal(full, emb), "gather must reproduce the unsharded batch bitwise"
+        # every rank computes the shared logits on the gathered embeddings -> identical on all ranks
+        logits = (100.0 * full) @ txt.t()
+        probs = orc.softmax_probs(logits.numpy().astype(np.float64))
+        conf, pred = orc.conf_pred(probs)
+        # each rank accumulates ECE statistics for ITS rows only, then one all-reduce merges them
+        bins = torch.from_numpy(metrics.bin_statistics(conf[lo:hi], pred[lo:hi], labels[lo:hi], 10)).reshape(-1)
+        parallel.merge_ece_bins(bins)
+        ece = metrics.ece_from_bins(bins.numpy(), 10)
+        want = orc.ece(conf, pred, labels, 10)
+        assert abs(ece - want) < 1e-12
+        np.save(os.path.join(out_dir, f"logits{rank}.npy"), logits.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,ragged", [(16, False), (17, True), (3, True)])
+def test_shard_gather_merge_world2(tmp_path, n_global, ragged):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_global, ragged, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "logits0.npy")
+    b = np.load(tmp_path / "logits1.npy")
+    assert np.array_equal(a, b)
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 256, 1024, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(4, 2, 2)
+
+
+def test_single_process_is_identity():
+    t = torch.arange(6.0).reshape(3, 2)
+    assert parallel.all_gather_embeddings(t) is t
+    assert parallel.all_gather_ragged(t, 3) is t
