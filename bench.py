@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--model", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-classes", type=int, default=100, help="BASELINE configs[0]: Caltech101-sized prompt set")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -50,7 +51,13 @@ def cpu_baseline(sd, geom_name, n_cls, batch, budget_s):
     from clip_calibration_amd import synthetic as syn
     from oracle import clip_oracle as orc  # timed baseline + checker only
 
-    cores = os.cpu_count() or 1
+    # torch CPU kernels collapse when oversubscribed (256 logical CPUs on the GPU box -> 0.5 img/s): take the CPUs
+    # this process may actually run on, capped at 32, and report that count.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
     ids = syn.synthetic_token_ids(n_cls, geom_name, seed=0)
     images = syn.synthetic_images(batch, geom_name, seed=0)
@@ -186,17 +193,19 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, cores, sample, lg_ref, cpu_images, cpu_labels = cpu_baseline(sd, args.model, Cn, args.cpu_batch, args.cpu_seconds)
+        v, cores, sample, lg_ref, cpu_images, cpu_labels = cpu_baseline(sd, args.model, args.cpu_classes, args.cpu_batch,
+                                                                         args.cpu_seconds)
         out["cpu_baseline"] = {"value": v, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample}
         # parity on exactly that sample: HIP path vs oracle
+        zs_cpu = ZeroshotCLIP(model, syn.synthetic_token_ids(args.cpu_classes, args.model, seed=0))
         with torch.no_grad():
-            lg, _, _, conf, pred = zs.model_inference(cpu_images.to(dev), want_conf_pred=True)
+            lg, _, _, conf, pred = zs_cpu.model_inference(cpu_images.to(dev), want_conf_pred=True)
         from clip_calibration_amd.metrics import ECE
         from oracle import clip_oracle as orc
         ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy(), cpu_labels.numpy())
         out["parity"] = {"max_abs_cosine_logit_err": float(np.abs(lg.cpu().numpy() - lg_ref.numpy()).max() / scale),
                          "ece_delta": abs(ECE(conf.cpu().numpy(), pred.cpu().numpy(), cpu_labels.numpy()) - ece_ref),
-                         "sample": f"{args.cpu_batch} images x {Cn} prompts"}
+                         "sample": f"{args.cpu_batch} images x {args.cpu_classes} prompts"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

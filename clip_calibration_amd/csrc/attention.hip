@@ -46,6 +46,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
   const int64_t ld = 3 * (int64_t)D;
   const int n = blockIdx.x / H, h = blockIdx.x - n * H;
   const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
 
   const int q0 = (blockIdx.y * (nthr >> 6) + wave) * 32;
   const bool active = q0 < L;  // wave-uniform
@@ -93,15 +94,14 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
       const int pw = it * 64;                           // wave-uniform slot base
       const int p = pw + lane;
       const int row = p >> 3, cs = p & 7;
-      int key = kb0 + row; key = key < L ? key : L - 1;  // clamp: finite data, masked below
-      const half_t* krow = base + (int64_t)key * ld + D;
-      __builtin_amdgcn_global_load_lds(CLIPMI_GLOBAL_PTR(krow + ((cs ^ ((row >> 1) & 7)) << 3)),
-                                       CLIPMI_LDS_PTR(Ks + pw * 16), 16, 0, 0);
+      const int key = kb0 + row;                      // rows >= L are outside the descriptor: they read as zero
+      const int koff = (key * (int)ld + D) * 2;
+      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + pw * 16, koff + ((cs ^ ((row >> 1) & 7)) << 4), 0);
       if constexpr (TR) {
-        __builtin_amdgcn_global_load_lds(CLIPMI_GLOBAL_PTR(krow + D + ((cs ^ (((row >> 1) & 1) << 2)) << 3)),
-                                         CLIPMI_LDS_PTR(Vs + pw * 16), 16, 0, 0);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, Vs + pw * 16, koff + D * 2 + ((cs ^ (((row >> 1) & 1) << 2)) << 4), 0);
       } else {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(krow + D + cs * 8);
+        const int kc = key < L ? key : L - 1;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (int64_t)kc * ld + 2 * D + cs * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) *reinterpret_cast<half_t*>(Vs + (cs * 8 + e) * VT_STRIDE + row * 2) = v[e];
       }

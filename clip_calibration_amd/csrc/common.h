@@ -17,6 +17,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CLIPMI_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define CLIPMI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// LDS-DMA through the buffer path (buffer_load_dwordx4 ... lds): 16 B per lane from rsrc.base + voff + soff into
+// lds_base + lane*16.  Preferred over global_load_lds: hipcc treats the latter as a FLAT access that may touch LDS and
+// then waits lgkmcnt(0) before every ds_read consumer (no counted waits); the MUBUF form keeps counted lgkmcnt and
+// gives hardware bounds checking (bytes at or beyond num_records read as 0).  Build the descriptor from wave-uniform
+// values only (kernel arguments, blockIdx).
+#ifdef __HIPCC__
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+  const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffll ? 0xffffffffu : (uint32_t)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+// A plain (non-template) function on purpose: when the builtin sits directly inside a kernel template with
+// value-dependent operands, hipcc's host pass silently drops the kernel's host stub (undefined symbol at dlopen).
+__device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, const void* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, CLIPMI_LDS_PTR(lds), 16, voff, soff, 0, 0);
+}
+#define CLIPMI_BUFFER_LOAD_LDS16(rsrc, lds, voff, soff) ::clipmi::buffer_load_lds16((rsrc), (lds), (voff), (soff))
+#endif
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
 

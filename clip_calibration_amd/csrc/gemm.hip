@@ -11,16 +11,16 @@
 // consecutive n for one m -> 8/16-byte epilogue accesses on row-major [M,N].
 // Workgroup ids are remapped so that the workgroups resident on one XCD sweep the n-tiles of the same m-tile
 // (the activation tile is then fetched once into that XCD's L2).
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.h"
 
 namespace clipmi {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;     // one operand tile, 16 KiB
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // activations + weights
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;  // 64 KiB -> 2 workgroups per CU
+constexpr int BK = 64;
 
 struct KArgs {
   const half_t* A; int64_t lda;
@@ -31,94 +31,93 @@ struct KArgs {
   int M, N, K;
   const float* pos; int patches; int tokens;
   int tiles_n; int nwg;
+  int stagger;   // > 0: second-residency workgroups of the first dispatch round sleep stagger x 8128 cycles
 };
 
-__device__ __forceinline__ float quick_gelu(float t) { return t / (1.0f + __expf(-1.702f * t)); }
+// Tile configuration: BM x BN workgroup tile (m = activation rows, n = weight rows), WGM x WGN waves.
+template <int BM_, int BN_, int WGM_, int WGN_, int OCC_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, OCC = OCC_;
+  static constexpr int NW = WGM * WGN, NT = NW * 64;
+  static constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
+  static constexpr int TM = WTM / 16, TN = WTN / 16;     // 16x16 MFMA tiles per wave
+  static constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2;
+  static constexpr int STAGE = XBYTES + WBYTES, SMEM = 2 * STAGE;
+  static constexpr int XI = BM * 8 / NT, WI = BN * 8 / NT;  // global_load_lds instructions per thread per stage
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "bad tile");
+  static_assert((NT / 8) % 16 == 0, "staging swizzle assumes NT/8 rows per instruction is a multiple of 16");
+};
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave & 1, wave_n = wave >> 1;
+// x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): one v_exp_f32 + one v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float quick_gelu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * t));
+}
 
-  // bijective XCD-aware remap: blockIdx % 8 labels the XCD; give each label a contiguous range of tiles
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tile_m = wg / a.tiles_n;
-  const int tile_n = wg - tile_m * a.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // ---- staging addresses: thread t, instruction i writes LDS 16-B slot p = i*256 + t of the tile;
-  //      slot p holds row p>>3, data chunk (p&7) ^ ((row>>1)&7)  (XOR swizzle, applied on the source)
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  const half_t* xsrc[4];
-  const half_t* wsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int mr = m0 + i * 32 + srow; mr = mr < a.M ? mr : a.M - 1;   // clamp: rows >= M are never stored
-    int nr = n0 + i * 32 + srow; nr = nr < a.N ? nr : a.N - 1;
-    xsrc[i] = a.A + (int64_t)mr * a.lda + schunk * 8;
-    wsrc[i] = a.W + (int64_t)nr * a.ldw + schunk * 8;
-  }
-  const int lds_wave_off = wave * 1024;  // 64 lanes x 16 B
-
-  auto stage = [&](int buf, int kt) {
-    char* xs = smem + buf * STAGE_BYTES + lds_wave_off;
-    char* ws = xs + TILE_BYTES;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(CLIPMI_GLOBAL_PTR(xsrc[i] + k0), CLIPMI_LDS_PTR(xs + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(CLIPMI_GLOBAL_PTR(wsrc[i] + k0), CLIPMI_LDS_PTR(ws + i * 4096), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment read offsets (bytes inside an operand tile): lane reads row (lane&15) of its 16-row tile,
-  //      data chunk ks*4 + (lane>>4), stored at chunk ^ ((row>>1)&7)
+// fp16 outputs: each wave transposes its tile through a private LDS patch (32 rows x 64 cols at a time) so that the
+// global stores are 16 B per lane and 128 contiguous bytes per row, instead of 8-byte pieces of 32-byte row segments.
+// The caller must have passed a workgroup barrier after the last main-loop LDS read.
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
+                                                    int wave_n, int lane, int wave, char* smem) {
+  constexpr int TM = T::TM, TN = T::TN;
+  static_assert(T::WTN == 64 && TM % 2 == 0, "staged epilogue assumes 64-column wave tiles");
+  constexpr int ROWB = T::WTN * 2 + 16;  // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
+  char* patch = smem + wave * (32 * ROWB);
   const int r16 = lane & 15, g4 = lane >> 4;
-  const int swz = (r16 >> 1) & 7;
-  int foff[2];
-  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
-  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
-  const int xbase = wave_m * 64 * 128;
-  const int wbase = TILE_BYTES + wave_n * 64 * 128;
-
-  f32x4 acc[4][4];
+  f32x4 bias[TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* st = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 xf[4], wf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  for (int i = 0; i < TN; ++i) {
+    bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != CLIPMI_EPI_NONE) {
+      const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+      if (n < a.N) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
     }
   }
-
-  // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m*64 + j*16 + (lane&15)][n = n0 + wave_n*64 + i*16 + (lane>>4)*4 + e]
+  half_t* out = static_cast<half_t*>(a.out);
+  const int rrow = lane >> 3, rcol = lane & 7;
+  const int n_st = n0 + wave_n * T::WTN + rcol * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wave_m * 64 + j * 16 + r16;
+  for (int jc = 0; jc < TM / 2; ++jc) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        f32x4 v = acc[i][jc * 2 + jj] + bias[i];
+        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
+            f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      }
+    }
+    // same wave, LDS is in order: the reads below see the writes above
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = t * 8 + rrow;
+      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+      const int m = m0 + wave_m * T::WTM + jc * 32 + row;
+      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
+    }
+  }
+}
+
+template <typename T, int EPI, bool OUT_F32>
+__device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
+                                         int lane, int wave, char* smem) {
+  constexpr int TM = T::TM, TN = T::TN;
+  if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
+    if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {   // wave-uniform
+      __syncthreads();                           // every wave is done with the main-loop LDS image
+      epilogue_f16_staged<T, EPI>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+      return;
+    }
+  }
+  const int r16 = lane & 15, g4 = lane >> 4;
+  // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m*WTM + j*16 + (lane&15)][n = n0 + wave_n*WTN + i*16 + (lane>>4)*4 + e]
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wave_m * T::WTM + j * 16 + r16;
     if (m >= a.M) continue;
     int64_t orow = m;
     const float* posrow = nullptr;
@@ -129,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const KArgs a) {
       posrow = a.pos + (int64_t)t * a.N;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
       if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL) {
@@ -161,19 +160,415 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const KArgs a) {
   }
 }
 
-template <int EPI, bool OUT_F32>
-int launch_one(const KArgs& k, hipStream_t s) {
+template <typename T, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+
+  // bijective XCD-aware remap: blockIdx % 8 labels the XCD; give each label a contiguous range of tiles
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tile_m = wg / a.tiles_n;
+  const int tile_n = wg - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // De-synchronise the two workgroups that share a CU: without it they run in lockstep (same start, same tile
+  // time) and both sit in their HBM/VALU-bound epilogue while the matrix pipe idles.  Speed only, never correctness.
+  if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // ---- staging addresses: thread t, instruction i writes LDS 16-B slot p = i*NT + t of the tile;
+  //      slot p holds row p>>3, data chunk (p&7) ^ ((row>>1)&7)  (XOR swizzle, applied on the source)
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  // buffer descriptors start at the tile's first row: rows at or beyond M / N are out of range and read as zero
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int xoff[T::XI], woff[T::WI];
+#pragma unroll
+  for (int i = 0; i < T::XI; ++i) xoff[i] = ((i * (NT / 8) + srow) * (int)a.lda + schunk * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < T::WI; ++i) woff[i] = ((i * (NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;  // 64 lanes x 16 B
+
+  auto stage = [&](int buf, int kt) {
+    char* xs = smem + buf * T::STAGE + lds_wave_off;
+    char* ws = xs + T::XBYTES;
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  // ---- fragment read offsets (bytes inside an operand tile): lane reads row (lane&15) of its 16-row tile,
+  //      data chunk ks*4 + (lane>>4), stored at chunk ^ ((row>>1)&7)
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * T::WTM * 128;
+  const int wbase = T::XBYTES + wave_n * T::WTN * 128;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* st = smem + (kt & 1) * T::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+}
+
+template <typename T, int EPI, bool OUT_F32>
+int launch_tile(KArgs k, hipStream_t s) {
   static bool attr_set = false;
-  auto fn = gemm_f16_kernel<EPI, OUT_F32>;
+  auto fn = gemm_f16_kernel<T, EPI, OUT_F32>;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM) != hipSuccess) {
       (void)hipGetLastError();
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(256), SMEM_BYTES, s, k);
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), T::SMEM, s, k);
   return check_launch("gemm_f16_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ring variant: BK = 32 stages in a 4-slot LDS ring, loads issued THREE stages ahead and retired with a counted
+// s_waitcnt vmcnt(N) + raw s_barrier (cdna_hip_programming.md §5 "Pipelining across barriers"): the L2->LDS stream
+// never drains.  LDS rows are 64 B (4 chunks); chunk c of row r is stored at c ^ G[(r>>2)&3], G = {0,2,3,1}, which
+// makes the 16-row x 64-B ds_read_b128 fragment reads conflict-free for all four 16-lane groups.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NS_>
+struct Ring {
+  static constexpr int BKR = 32, NS = NS_;
+  static constexpr int XB = T::BM * 64, WB = T::BN * 64, STAGE = XB + WB, SMEM = NS * STAGE;
+  static constexpr int XI = T::BM * 4 / T::NT, WI = T::BN * 4 / T::NT, G = XI + WI;
+  static_assert((T::BM * 4) % T::NT == 0 && (T::BN * 4) % T::NT == 0 && (T::NT / 4) % 16 == 0, "bad ring tile");
+};
+
+__device__ __forceinline__ int ring_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int NS, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_ring_kernel(const KArgs a) {
+  using R = Ring<T, NS>;
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tile_m = wg / a.tiles_n;
+  const int tile_n = wg - tile_m * a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // De-synchronise the two workgroups that share a CU: without it they run in lockstep (same start, same tile
+  // time) and both sit in their HBM/VALU-bound epilogue while the matrix pipe idles.  Speed only, never correctness.
+  if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // staging: instruction i, thread t -> LDS slot p = i*NT + t = row (p>>2), stored chunk (p&3); source chunk = stored ^ swz(row)
+  const int srow = tid >> 2;
+  const int schunk = (tid & 3) ^ ring_swz(srow);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int xoff[R::XI], woff[R::WI];
+#pragma unroll
+  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+  auto stage = [&](int kt) {
+    char* xs = smem + (kt % R::NS) * R::STAGE + lds_wave_off;
+    char* ws = xs + R::XB;
+    const int k0 = kt * R::BKR * 2;
+#pragma unroll
+    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
+  const int xbase = wave_m * T::WTM * 64 + foff;
+  const int wbase = R::XB + wave_n * T::WTN * 64 + foff;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / R::BKR;
+  constexpr int PD = NS - 1;            // prefetch distance (stages in flight beyond the one being computed: PD - 1)
+#pragma unroll
+  for (int p = 0; p < PD; ++p)
+    if (p < nk) stage(p);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;      // stages issued after kt that may stay in flight (at most PD - 1)
+    if (PD >= 3 && ahead >= 2) wait_vmcnt<2 * R::G>();
+    else if (ahead >= 1) wait_vmcnt<R::G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();       // stage kt visible to all waves; slot (kt+PD)%NS no longer read by anyone
+    if (kt + PD < nk) stage(kt + PD);
+    const char* st = smem + (kt % R::NS) * R::STAGE;
+    f16x8 xf[TM], wf[TN];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 1024);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 1024);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+}
+
+template <typename T, int NS, int EPI, bool OUT_F32>
+int launch_ring(KArgs k, hipStream_t s) {
+  using R = Ring<T, NS>;
+  static bool attr_set = false;
+  auto fn = gemm_ring_kernel<T, NS, EPI, OUT_F32>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
+  return check_launch("gemm_ring_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined variant (the default for large problems): 256 x 256 tile, 8 waves of 128(m) x 64(n), BK = 32 stages in
+// the 4-slot ring, loads three stages ahead.  Each stage is two clusters of 16 MFMAs (m-tiles 0-3, then 4-7, against
+// the stage's 4 n-tile fragments); the LDS reads of a cluster are issued one cluster ahead into a second register
+// set, so a wave's ds_read latency hides under its own MFMAs, and the single barrier of a stage sits between the two
+// clusters with the operands of the following cluster already in registers.
+//   iteration kt:  read xb(kt) | MFMA a(kt) | wait stage kt+1, barrier | issue stage kt+3 | read xa,w(kt+1) | MFMA b(kt)
+// ---------------------------------------------------------------------------------------------------------------
+using TPipe = Tile<256, 256, 2, 4, 2>;
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const KArgs a) {
+  using T = TPipe;
+  using R = Ring<T, 4>;
+  constexpr int NT = T::NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tile_m = wg / a.tiles_n;
+  const int tile_n = wg - tile_m * a.tiles_n;
+  const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
+
+  const int srow = tid >> 2;
+  const int schunk = (tid & 3) ^ ring_swz(srow);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int xoff[R::XI], woff[R::WI];
+#pragma unroll
+  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+  auto stage = [&](int kt) {
+    char* xs = smem + (kt & 3) * R::STAGE + lds_wave_off;
+    char* ws = xs + R::XB;
+    const int k0 = kt * R::BKR * 2;
+#pragma unroll
+    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
+  const char* xrd = smem + wave_m * T::WTM * 64 + foff;
+  const char* wrd = smem + R::XB + wave_n * T::WTN * 64 + foff;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / R::BKR;   // even (K % 64 == 0)
+  f16x8 xa[4], xb[4], w0[4], w1[4];
+
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  if (nk > 2) wait_vmcnt<2 * R::G>();
+  else if (nk > 1) wait_vmcnt<R::G>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const f16x8*>(xrd + j * 1024);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w0[i] = *reinterpret_cast<const f16x8*>(wrd + i * 1024);
+
+  // FULL = true: steady state (stages kt+1..kt+3 all exist) -> straight-line code, so that hipcc's waitcnt pass
+  // can count the LDS reads instead of draining them at every basic-block merge.
+  auto step = [&](auto full_tag, int kt, f16x8 (&wc)[4], f16x8 (&wn)[4]) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int so = (kt & 3) * R::STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xb[j] = *reinterpret_cast<const f16x8*>(xrd + so + (4 + j) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], xa[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (FULL || kt + 1 < nk) {
+      if (FULL || kt + 2 < nk) wait_vmcnt<R::G>();   // stage kt+2 may stay in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();          // stage kt+1 visible; nobody still reads slot (kt+3)&3
+      if (FULL || kt + 3 < nk) stage(kt + 3);
+      const int sn = ((kt + 1) & 3) * R::STAGE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const f16x8*>(xrd + sn + j * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const f16x8*>(wrd + sn + i * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], xb[j], acc[i][4 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int kt = 0;
+  for (; kt + 4 < nk; kt += 2) {   // both steps of the pair are in steady state
+    step(std::true_type{}, kt, w0, w1);
+    step(std::true_type{}, kt + 1, w1, w0);
+  }
+  for (; kt < nk; kt += 2) {
+    step(std::false_type{}, kt, w0, w1);
+    step(std::false_type{}, kt + 1, w1, w0);
+  }
+  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+}
+
+template <int EPI, bool OUT_F32>
+int launch_pipe(KArgs k, hipStream_t s) {
+  using T = TPipe;
+  using R = Ring<T, 4>;
+  static bool attr_set = false;
+  auto fn = gemm_pipe_kernel<EPI, OUT_F32>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
+  return check_launch("gemm_pipe_kernel");
+}
+
+using T128 = Tile<128, 128, 2, 2, 2>;      // 4 waves of 64x64, 64 KiB LDS, 2 workgroups / CU
+using T256w16 = Tile<256, 256, 4, 4, 4>;   // 16 waves of 64x64, 128 KiB LDS, 1 workgroup / CU, 4 waves / SIMD
+using T256w8 = Tile<256, 256, 2, 4, 2>;    // 8 waves of 128x64
+using T256x128 = Tile<256, 128, 4, 2, 2>;  // 8 waves of 64x64, 96 KiB LDS
+using T128x256o4 = Tile<128, 256, 2, 4, 4>;  // 8 waves of 64x64, <=128 VGPRs so two workgroups share a CU
+using T256x128o4 = Tile<256, 128, 4, 2, 4>;
+
+// CLIPMI_GEMM_VARIANT = 0..8 forces a tile configuration (tuning / test aid).  Default (measured on MI355X at
+// M = 50432, profiles/r01_gemm_variants.txt):
+//   - problems too small to give every CU a 256 x 256 tile, and problems whose 256^2 tile count is a small
+//     non-integer multiple of the CU count (N = 768: 591 tiles = 2.3 rounds), run the 128 x 128 tile with two
+//     workgroups per CU (finer quantisation, epilogue of one workgroup under the main loop of the other);
+//   - everything else runs the pipelined 256 x 256 kernel (half the L2->LDS bytes per flop).
+int pick_variant(const KArgs& k) {
+  const char* e = getenv("CLIPMI_GEMM_VARIANT");
+  if (e && e[0] >= '0' && e[0] <= '8') return e[0] - '0';
+  const int64_t tiles = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256);
+  if (tiles < 256) return 0;
+  const int64_t rounds = tiles / 256, rem = tiles % 256;
+  if (rounds < 4 && rem > 0 && rem < 160) return 0;   // a mostly empty last round costs more than the smaller tile
+  return 8;
+}
+
+template <int EPI, bool OUT_F32>
+int launch_one(const KArgs& k, hipStream_t s) {
+  switch (pick_variant(k)) {
+    case 1: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
+    case 2: return launch_tile<T256w8, EPI, OUT_F32>(k, s);
+    case 3: return launch_tile<T256x128, EPI, OUT_F32>(k, s);
+    case 4: return launch_ring<T256w16, 4, EPI, OUT_F32>(k, s);
+    case 5: return launch_ring<T256w8, 4, EPI, OUT_F32>(k, s);
+    case 6: return launch_ring<T128x256o4, 3, EPI, OUT_F32>(k, s);   // 72 KiB -> 2 workgroups / CU
+    case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
+    case 8: return launch_pipe<EPI, OUT_F32>(k, s);
+    default: return launch_tile<T128, EPI, OUT_F32>(k, s);
+  }
 }
 
 }  // namespace
@@ -196,11 +591,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.A = a.A; k.lda = a.lda; k.W = a.W; k.ldw = a.ldw; k.bias = a.bias; k.residual = a.residual;
   k.out = a.out; k.ldo = a.ldo; k.M = a.M; k.N = a.N; k.K = a.K;
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
-  const int tiles_m = (a.M + BM - 1) / BM;
-  k.tiles_n = (a.N + BN - 1) / BN;
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
+  k.tiles_n = 0; k.nwg = 0;
+  {
+    const char* e = getenv("CLIPMI_GEMM_STAGGER");
+    k.stagger = e ? atoi(e) : 0;
+  }
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:

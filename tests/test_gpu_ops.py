@@ -61,6 +61,15 @@ def test_gemm(ops, M, N, K, epi):
     assert err <= tol * scale, f"max err {err} vs scale {scale}"
 
 
+@pytest.mark.parametrize("variant", [str(v) for v in range(9)])
+@pytest.mark.parametrize("M,N,K,epi", [(200, 192, 128, "gelu"), (1000, 2304, 768, "bias"), (333, 512, 3072, "residual"),
+                                        (50432, 768, 768, "residual"), (513, 260, 64, "none"), (5000, 3072, 768, "gelu")])
+def test_gemm_tile_variants(ops, monkeypatch, variant, M, N, K, epi):
+    """Every tile/pipeline variant the dispatcher can pick (CLIPMI_GEMM_VARIANT) computes the same thing."""
+    monkeypatch.setenv("CLIPMI_GEMM_VARIANT", variant)
+    test_gemm(ops, M, N, K, epi)
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from clip_calibration_amd._lib import ClipmiError
     a = torch.zeros(8, 48, dtype=torch.float16, device="cuda")
