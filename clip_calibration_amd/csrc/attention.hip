@@ -28,6 +28,114 @@ __device__ __forceinline__ f16x4 tr_read(const char* p) {
   return __builtin_bit_cast(f16x4, t);
 }
 
+// One key block (NKT*32 keys already in LDS) against this wave's 32 queries: S^T = K Q^T, online softmax over
+// groups of GROUP key tiles, O^T += V^T P^T.  kread / vread are the lane's LDS read bases for the block.
+//
+// The softmax is VALU-issue bound (the first version spent ~44 issue cycles per score), so the per-score work is cut
+// to: one v_max (raw scores; the 1/8 * log2(e) factor is folded into the exponent FMA), one v_fma + one v_exp, and
+// the fp16 pack.  Masking code exists only in tiles that can contain a dead key (wave-uniform test); fully dead
+// causal tiles are skipped.  Row sums come out of the matrix pipe: a third "V^T" tile of all ones accumulates
+// sum_k P[k][q] in lacc alongside O, from the same fp16-rounded P that multiplies V.
+template <int NKT, int GROUP, bool TR>
+__device__ __forceinline__ void attend_block(const char* const (&kread)[4], const char* const (&vread)[2], const f16x8 (&qf)[4],
+                                             int kb0, int L, int causal, int q0, int q, int hh, float& m_run,
+                                             f32x16 (&oacc)[2], f32x16& lacc) {
+  constexpr float C = 0.125f * LOG2E;  // softmax(s/8) = 2^(C s - C max)
+  const f16x8 ones = f16x8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+#pragma unroll
+  for (int g0 = 0; g0 < NKT; g0 += GROUP) {
+    f32x16 s[GROUP];
+    bool live[GROUP];   // wave-uniform: tile has at least one key this wave may attend to
+    // ---- S^T = K Q^T
+#pragma unroll
+    for (int t = 0; t < GROUP; ++t) {
+      const int kt = g0 + t;
+      live[t] = false;
+      if (kt < NKT) {
+        const int k_lo = kb0 + kt * 32;
+        live[t] = (k_lo < L) && !(causal && k_lo > q0 + 31);
+        if (live[t]) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 kf = *reinterpret_cast<const f16x8*>(kread[ks] + kt * 4096);
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
+          }
+          const bool partial = (k_lo + 32 > L) || (causal && k_lo + 31 > q0);   // wave-uniform
+          if (partial) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int key = k_lo + (e & 3) + 8 * (e >> 2) + 4 * hh;
+              const bool dead = (key >= L) || (causal && key > q);
+              s[t][e] = dead ? NEG_BIG : s[t][e];
+            }
+          }
+        }
+      }
+    }
+    // ---- group max of the raw scores
+    float mloc = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < GROUP; ++t) {
+      if (g0 + t < NKT && live[t]) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
+    const float mc = m_new * C;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    lacc[0] *= alpha;   // every row of the ones-tile holds the same sum; only register 0 is read
+    // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
+#pragma unroll
+    for (int t = 0; t < GROUP; ++t) {
+      const int kt = g0 + t;
+      if (kt < NKT && live[t]) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          f16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[t][8 * ss + j], C, -mc));
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            f16x4 lo, hi;
+            if constexpr (TR) {
+              lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
+              hi = tr_read(vread[dt] + kt * 4096 + ss * 2048 + 1024);
+            } else {
+              lo = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32);
+              hi = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32 + 16);
+            }
+            const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
+          }
+          lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2], float l_run, int hh) {
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[dt][rr * 4 + e] * inv);
+      *reinterpret_cast<f16x4*>(orow + dt * 32 + rr * 8 + hh * 4) = o;
+    }
+}
+
 template <int NKT, int GROUP, bool TR>
 __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                            int L, int H, int causal, int nkb) {
@@ -62,14 +170,17 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
+  float m_run = NEG_BIG;
+  f32x16 lacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
 
   // lane-constant LDS read bases; everything else is an immediate offset
   const int kswz = (r32 >> 1) & 7;
-  const char* kread[4];
+  const char* kread_[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kread[ks] = Ks + r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
-  const char* vread[2];
+  for (int ks = 0; ks < 4; ++ks) kread_[ks] = Ks + r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  const char* vread_[2];
   if constexpr (TR) {
     // ds_read_b64_tr_b16: per 16-lane group a block of 4 rows (keys k0..k0+3) x 16 columns (d0..d0+15); lane 4q+p
     // of the group supplies the address of row q, columns 4p..4p+3 and receives column (lane&15) of the 4 rows.
@@ -78,12 +189,14 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
     const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
     const int fq = (qq >> 1) & 1;
     const int lane_base = hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
-    vread[0] = Vs + lane_base + fq * 64;          // dt = 0: chunk bit 2 = 0 ^ fq
-    vread[1] = Vs + lane_base + (1 - fq) * 64;    // dt = 1: chunk bit 2 = 1 ^ fq
+    vread_[0] = Vs + lane_base + fq * 64;          // dt = 0: chunk bit 2 = 0 ^ fq
+    vread_[1] = Vs + lane_base + (1 - fq) * 64;    // dt = 1: chunk bit 2 = 1 ^ fq
   } else {
-    vread[0] = Vs + r32 * VT_STRIDE + hh * 8;
-    vread[1] = Vs + (32 + r32) * VT_STRIDE + hh * 8;
+    vread_[0] = Vs + r32 * VT_STRIDE + hh * 8;
+    vread_[1] = Vs + (32 + r32) * VT_STRIDE + hh * 8;
   }
+  const char* const kread[4] = {kread_[0], kread_[1], kread_[2], kread_[3]};
+  const char* const vread[2] = {vread_[0], vread_[1]};
 
   for (int kb = 0; kb < nkb; ++kb) {
     const int kb0 = kb * KEYS;
@@ -110,108 +223,135 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
     __syncthreads();
 
     if (active) {
-      // key tiles are consumed in groups of GROUP with an online-softmax rescale between groups: GROUP*16 live
-      // score registers instead of NKT*16
-#pragma unroll
-      for (int g0 = 0; g0 < NKT; g0 += GROUP) {
-        f32x16 s[GROUP];
-        // ---- S^T = K Q^T
-#pragma unroll
-        for (int t = 0; t < GROUP; ++t) {
-          const int kt = g0 + t;
-          if (kt < NKT) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              const f16x8 kf = *reinterpret_cast<const f16x8*>(kread[ks] + kt * 4096);
-              s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
-            }
-          }
-        }
-        // ---- scale, mask, group max
-        float mloc = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < GROUP; ++t) {
-          const int kt = g0 + t;
-          if (kt < NKT) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int key = kb0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-              float v = s[t][e] * (0.125f * LOG2E);  // log2-domain scores
-              const bool dead = (key >= L) || (causal && key > q);
-              v = dead ? NEG_BIG : v;
-              s[t][e] = v;
-              mloc = fmaxf(mloc, v);
-            }
-          }
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lsum = 0.f;
-#pragma unroll
-        for (int t = 0; t < GROUP; ++t) {
-          const int kt = g0 + t;
-          if (kt < NKT) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const float p = __builtin_amdgcn_exp2f(s[t][e] - m_new);
-              s[t][e] = p;
-              lsum += p;
-            }
-          }
-        }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int t = 0; t < GROUP; ++t) {
-          const int kt = g0 + t;
-          if (kt < NKT) {
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-              f16x8 pf;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[t][8 * ss + j];
-#pragma unroll
-              for (int dt = 0; dt < 2; ++dt) {
-                f16x4 lo, hi;
-                if constexpr (TR) {
-                  lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
-                  hi = tr_read(vread[dt] + kt * 4096 + ss * 2048 + 1024);
-                } else {
-                  lo = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32);
-                  hi = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32 + 16);
-                }
-                const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
+      attend_block<NKT, GROUP, TR>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
     }
   }
 
-  if (active && q < L) {
-    const float inv = 1.0f / l_run;
-    half_t* orow = out + ((int64_t)n * L + q) * D + h * 64;
+  if (active && q < L) store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant for sequences that fit one key block (L <= NKT*32; every CLIP tower at 224 px and the text
+// tower): one workgroup per CU walks the (sequence, head) items; K/V of item i+1 are DMA'd into the second half of a
+// double-buffered LDS image (and its Q fragments loaded into a spare register set) while item i is computed, so
+// the HBM/L2 latency of the operands never sits on the critical path.  Per item: vmcnt(0) (loads issued a whole item
+// ago) -> barrier -> issue loads for the next item -> compute -> store.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKT, int GROUP>
+__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                                   int L, int H, int causal, int n_items) {
+  constexpr int KEYS = NKT * 32;
+  constexpr int OPB = KEYS * 128;      // one operand image
+  constexpr int BUF = 2 * OPB;         // K + V
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthr >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int D = H * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const int q0 = wave * 32;
+  const bool active = q0 < L;
+  const int q = q0 + r32;
+  const int qc = q < L ? q : L - 1;
+
+  const int kswz = (r32 >> 1) & 7;
+  int kro[4], vro[2];   // lane-constant byte offsets inside a buffer
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[dt][rr * 4 + e] * inv);
-        *reinterpret_cast<f16x4*>(orow + dt * 32 + rr * 8 + hh * 4) = o;
-      }
+  for (int ks = 0; ks < 4; ++ks) kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  {
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int fq = (qq >> 1) & 1;
+    const int lane_base = OPB + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+    vro[0] = lane_base + fq * 64;
+    vro[1] = lane_base + (1 - fq) * 64;
   }
+
+  auto item_base = [&](int item) {
+    const int n = item / H, h = item - n * H;
+    return qkv + (int64_t)n * L * ld + h * 64;
+  };
+  auto stage = [&](int item, int buf) {
+    const int h = item % H;
+    const half_t* base = item_base(item);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
+    char* Ks = smem + buf * BUF;
+    for (int it = wave; it < KEYS / 8; it += nwaves) {
+      const int pw = it * 64;
+      const int p = pw + lane;
+      const int row = p >> 3, cs = p & 7;
+      const int koff = (row * (int)ld + D) * 2;      // rows >= L are outside the descriptor: zero
+      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + pw * 16, koff + ((cs ^ ((row >> 1) & 7)) << 4), 0);
+      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + OPB + pw * 16, koff + D * 2 + ((cs ^ (((row >> 1) & 1) << 2)) << 4), 0);
+    }
+  };
+  auto load_q = [&](int item, f16x8 (&dst)[4]) {
+    const half_t* base = item_base(item);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const f16x8*>(base + (int64_t)qc * ld + ks * 16 + hh * 8);
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  f16x8 qf[4], qn[4];
+  stage(item, 0);
+  load_q(item, qf);
+  int buf = 0;
+  for (; item < n_items; item += gridDim.x, buf ^= 1) {
+    const int next = item + gridDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this item's K/V visible to all waves; everybody is done with the other buffer
+    if (next < n_items) {
+      stage(next, buf ^ 1);
+      load_q(next, qn);
+    }
+    if (active) {
+      const char* b = smem + buf * BUF;
+      const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
+      const char* const vread[2] = {b + vro[0], b + vro[1]};
+      f32x16 oacc[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+      float m_run = NEG_BIG;
+      f32x16 lacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+      attend_block<NKT, GROUP, true>(kread, vread, qf, 0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      if (q < L) {
+        const int n = item / H, h = item - n * H;
+        store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+  }
+}
+
+template <int NKT, int GROUP>
+int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
+  constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto fn = attention_persist_kernel<NKT, GROUP>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      (void)hipGetLastError();
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    attr_set = true;
+  }
+  const int nqt = (L + 31) / 32;
+  const int nw = nqt < 4 ? 4 : nqt;                  // <= 7 here
+  const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
+  const int n_items = N * H;
+  const int grid = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items);
+  return check_launch("attention_persist_kernel");
 }
 
 template <int NKT, int GROUP, bool TR>
@@ -248,6 +388,11 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   CLIPMI_REQUIRE((int64_t)N * H < (1ll << 31), CLIPMI_ERR_SHAPE, "attention: grid too large");
   CLIPMI_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, CLIPMI_ERR_ARG, "attention: unaligned pointer");
   const bool tr = use_tr();
+  const char* np = getenv("CLIPMI_ATTN_NO_PERSIST");
+  if (tr && !(np && np[0] == '1')) {
+    if (L <= 96) return launch_persist<3, 3>(qkv, out, N, L, H, causal, s);
+    if (L <= 224) return launch_persist<7, 4>(qkv, out, N, L, H, causal, s);
+  }
   if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
   return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);
 }

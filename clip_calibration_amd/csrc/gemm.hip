@@ -22,6 +22,8 @@ namespace {
 
 constexpr int BK = 64;
 
+int pick_band(int tiles_n, int bn, int K);
+
 struct KArgs {
   const half_t* A; int64_t lda;
   const half_t* W; int64_t ldw;
@@ -31,7 +33,7 @@ struct KArgs {
   int M, N, K;
   const float* pos; int patches; int tokens;
   int tiles_n; int nwg;
-  int stagger;   // > 0: second-residency workgroups of the first dispatch round sleep stagger x 8128 cycles
+  int band;      // n-tiles per band of the tile traversal (see tile_coords)
 };
 
 // Tile configuration: BM x BN workgroup tile (m = activation rows, n = weight rows), WGM x WGN waves.
@@ -53,16 +55,33 @@ __device__ __forceinline__ float quick_gelu(float t) {
   return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * t));
 }
 
+// Tile traversal.  blockIdx % 8 labels the XCD (blocks are dealt round-robin over the 8 XCDs); each label gets a
+// contiguous range of logical tile ids (bijective remap), and logical ids walk the tile grid in BANDS of `band`
+// n-tiles: inside a band m is the slow index and n the fast one.  The ~32 tiles an XCD runs concurrently then share
+// `band` weight panels (resident in that XCD's 4 MiB L2 for the whole band) and ~32/band activation panels, which
+// stream through once per band -- instead of cycling through all of W (3.5-4.7 MB) for every m-tile.
+__device__ __forceinline__ void tile_coords(const KArgs& a, int tiles_m, int& tile_m, int& tile_n) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int per_band = tiles_m * a.band;
+  const int b = wg / per_band;
+  const int within = wg - b * per_band;
+  const int rem = a.tiles_n - b * a.band;
+  const int gw = rem < a.band ? rem : a.band;
+  tile_m = within / gw;
+  tile_n = b * a.band + (within - tile_m * gw);
+}
+
 // fp16 outputs: each wave transposes its tile through a private LDS patch (32 rows x 64 cols at a time) so that the
 // global stores are 16 B per lane and 128 contiguous bytes per row, instead of 8-byte pieces of 32-byte row segments.
 // The caller must have passed a workgroup barrier after the last main-loop LDS read.
-template <typename T, int EPI>
+template <typename T, int EPI, int CH>
 __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
-                                                    int wave_n, int lane, int wave, char* smem) {
+                                                    int wave_n, int lane, char* patch) {
   constexpr int TM = T::TM, TN = T::TN;
-  static_assert(T::WTN == 64 && TM % 2 == 0, "staged epilogue assumes 64-column wave tiles");
+  static_assert(T::WTN == 64 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue assumes 64-column wave tiles");
   constexpr int ROWB = T::WTN * 2 + 16;  // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
-  char* patch = smem + wave * (32 * ROWB);
   const int r16 = lane & 15, g4 = lane >> 4;
   f32x4 bias[TN];
 #pragma unroll
@@ -77,12 +96,12 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
   const int rrow = lane >> 3, rcol = lane & 7;
   const int n_st = n0 + wave_n * T::WTN + rcol * 8;
 #pragma unroll
-  for (int jc = 0; jc < TM / 2; ++jc) {
+  for (int jc = 0; jc < TM / CH; ++jc) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < CH; ++jj) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        f32x4 v = acc[i][jc * 2 + jj] + bias[i];
+        f32x4 v = acc[i][jc * CH + jj] + bias[i];
         if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -93,26 +112,36 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
     }
     // same wave, LDS is in order: the reads below see the writes above
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2 * CH; ++t) {
       const int row = t * 8 + rrow;
       const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
-      const int m = m0 + wave_m * T::WTM + jc * 32 + row;
+      const int m = m0 + wave_m * T::WTM + jc * (16 * CH) + row;
       if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
     }
   }
 }
 
 template <typename T, int EPI, bool OUT_F32>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
+                                                int wave_n, int lane);
+
+template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
                                          int lane, int wave, char* smem) {
-  constexpr int TM = T::TM, TN = T::TN;
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
     if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {   // wave-uniform
       __syncthreads();                           // every wave is done with the main-loop LDS image
-      epilogue_f16_staged<T, EPI>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+      epilogue_f16_staged<T, EPI, 2>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * (T::WTN * 2 + 16)));
       return;
     }
   }
+  epilogue_direct<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane);
+}
+
+template <typename T, int EPI, bool OUT_F32>
+__device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
+                                                int wave_n, int lane) {
+  constexpr int TM = T::TM, TN = T::TN;
   const int r16 = lane & 15, g4 = lane >> 4;
   // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m*WTM + j*16 + (lane&15)][n = n0 + wave_n*WTN + i*16 + (lane>>4)*4 + e]
 #pragma unroll
@@ -169,18 +198,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
 
-  // bijective XCD-aware remap: blockIdx % 8 labels the XCD; give each label a contiguous range of tiles
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tile_m = wg / a.tiles_n;
-  const int tile_n = wg - tile_m * a.tiles_n;
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  // De-synchronise the two workgroups that share a CU: without it they run in lockstep (same start, same tile
-  // time) and both sit in their HBM/VALU-bound epilogue while the matrix pipe idles.  Speed only, never correctness.
-  if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   // ---- staging addresses: thread t, instruction i writes LDS 16-B slot p = i*NT + t of the tile;
   //      slot p holds row p>>3, data chunk (p&7) ^ ((row>>1)&7)  (XOR swizzle, applied on the source)
@@ -249,6 +269,17 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
 }
 
+// n-tiles per traversal band.  Measured (profiles/r01_gemm_band_sweep.txt): 4 is best or tied on every tower
+// shape (fc: 298 -> 275 us against the unbanded order); up to 6 n-tiles are kept as one band.
+int pick_band(int tiles_n, int /*bn*/, int /*K*/) {
+  const char* e = getenv("CLIPMI_GEMM_BAND");
+  int g = e ? atoi(e) : (tiles_n <= 6 ? tiles_n : 4);
+  if (g < 1) g = 1;
+  if (g > tiles_n) g = tiles_n;
+  const int nb = (tiles_n + g - 1) / g;   // even out the bands (9 n-tiles, g = 4 -> 3 bands of 3)
+  return (tiles_n + nb - 1) / nb;
+}
+
 template <typename T, int EPI, bool OUT_F32>
 int launch_tile(KArgs k, hipStream_t s) {
   static bool attr_set = false;
@@ -261,6 +292,7 @@ int launch_tile(KArgs k, hipStream_t s) {
   }
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
@@ -296,17 +328,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_ring_kernel(const KArgs a)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
 
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tile_m = wg / a.tiles_n;
-  const int tile_n = wg - tile_m * a.tiles_n;
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  // De-synchronise the two workgroups that share a CU: without it they run in lockstep (same start, same tile
-  // time) and both sit in their HBM/VALU-bound epilogue while the matrix pipe idles.  Speed only, never correctness.
-  if (a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   // staging: instruction i, thread t -> LDS slot p = i*NT + t = row (p>>2), stored chunk (p&3); source chunk = stored ^ swz(row)
   const int srow = tid >> 2;
@@ -382,11 +406,165 @@ int launch_ring(KArgs k, hipStream_t s) {
   }
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
   hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
   return check_launch("gemm_ring_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant of the 2-stage kernel: one workgroup per CU walks its tiles (same XCD-aware order, virtual block
+// id = blockIdx + k * gridDim).  After the last K-step of a tile the first stage of the NEXT tile is DMA'd into the
+// free LDS buffer before the epilogue starts, so the operand latency of a tile's first stage and the drain of the
+// previous tile's stores overlap instead of adding to every tile (K = 768 tiles are only 12 K-steps long).  The fp16
+// epilogue patch lives behind the two stage buffers (16-row chunks keep it at 2.25 KiB per wave).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs a) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
+  constexpr int ROWB = T::WTN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+  const int tiles_m = (a.M + BM - 1) / BM;
+
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  int xoff[T::XI], woff[T::WI];
+#pragma unroll
+  for (int i = 0; i < T::XI; ++i) xoff[i] = ((i * (NT / 8) + srow) * (int)a.lda + schunk * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < T::WI; ++i) woff[i] = ((i * (NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * T::WTM * 128;
+  const int wbase = T::XBYTES + wave_n * T::WTN * 128;
+  const int nk = a.K / BK;   // even? not required: buffer of the last step is (nk-1)&1, the prefetch goes to buffer 0
+                             // only when that is free, i.e. nk even or after the trailing barrier (always true below)
+
+  auto coords = [&](int vb, int& m0, int& n0) {
+    const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_band = tiles_m * a.band;
+    const int b = wg / per_band;
+    const int within = wg - b * per_band;
+    const int rem = a.tiles_n - b * a.band;
+    const int gw = rem < a.band ? rem : a.band;
+    const int tm = within / gw;
+    m0 = tm * BM;
+    n0 = (b * a.band + (within - tm * gw)) * BN;
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
+    char* xs = smem + buf * T::STAGE + lds_wave_off;
+    char* ws = xs + T::XBYTES;
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  int vb = blockIdx.x;
+  int m0, n0;
+  coords(vb, m0, n0);
+  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int first_buf = 0;
+  stage(xrs, wrs, first_buf, 0);
+
+  while (true) {
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = (first_buf + kt) & 1;
+      // stage kt was issued before everything still outstanding except (first iteration only) the previous tile's
+      // epilogue stores; vmcnt(0) also drains those -- they were issued a full prefetch latency ago
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
+      const char* st = smem + buf * T::STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f16x8 xf[TM], wf[TN];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    const int last_buf = (first_buf + nk - 1) & 1;
+    const int cm0 = m0, cn0 = n0;
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < a.nwg;
+    if (has_next) {
+      // the buffer that is NOT the last one read is free (its reads finished before the last barrier)
+      vb = nvb;
+      coords(vb, m0, n0);
+      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+      first_buf = last_buf ^ 1;
+      stage(xrs, wrs, first_buf, 0);
+    }
+    if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
+      if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {
+        epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB));
+      } else {
+        epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
+      }
+    } else {
+      epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
+    }
+    if (!has_next) break;
+  }
+}
+
+template <typename T, int EPI, bool OUT_F32>
+int launch_persist(KArgs k, hipStream_t s) {
+  constexpr int SMEM = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
+  const int grid = k.nwg < n_cu * per_cu ? k.nwg : n_cu * per_cu;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k);
+  return check_launch("gemm_persist_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -410,11 +588,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const KArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
 
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tile_m = wg / a.tiles_n;
-  const int tile_n = wg - tile_m * a.tiles_n;
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
   const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
 
   const int srow = tid >> 2;
@@ -526,6 +701,7 @@ int launch_pipe(KArgs k, hipStream_t s) {
   }
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
@@ -545,15 +721,17 @@ using T256x128o4 = Tile<256, 128, 4, 2, 4>;
 //   - problems too small to give every CU a 256 x 256 tile, and problems whose 256^2 tile count is a small
 //     non-integer multiple of the CU count (N = 768: 591 tiles = 2.3 rounds), run the 128 x 128 tile with two
 //     workgroups per CU (finer quantisation, epilogue of one workgroup under the main loop of the other);
-//   - everything else runs the pipelined 256 x 256 kernel (half the L2->LDS bytes per flop).
+//   - everything else runs the 256 x 256 tile with 16 waves of 64 x 64 (half the L2->LDS bytes per flop, four waves
+//     per SIMD to cover LDS/barrier latency).  Interleaved A/B (tools/gemm_ab.py, profiles/r01_gemm_ab.txt): it
+//     beats the 8-wave, ring-pipelined and persistent variants (2, 4, 8, 9) by 3-6 % on the N >= 2304 shapes.
 int pick_variant(const KArgs& k) {
   const char* e = getenv("CLIPMI_GEMM_VARIANT");
-  if (e && e[0] >= '0' && e[0] <= '8') return e[0] - '0';
+  if (e && e[0] >= '0' && e[0] <= '9') return e[0] - '0';
   const int64_t tiles = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256);
   if (tiles < 256) return 0;
   const int64_t rounds = tiles / 256, rem = tiles % 256;
   if (rounds < 4 && rem > 0 && rem < 160) return 0;   // a mostly empty last round costs more than the smaller tile
-  return 8;
+  return 1;
 }
 
 template <int EPI, bool OUT_F32>
@@ -567,6 +745,7 @@ int launch_one(const KArgs& k, hipStream_t s) {
     case 6: return launch_ring<T128x256o4, 3, EPI, OUT_F32>(k, s);   // 72 KiB -> 2 workgroups / CU
     case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
+    case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
     default: return launch_tile<T128, EPI, OUT_F32>(k, s);
   }
 }
@@ -592,10 +771,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.out = a.out; k.ldo = a.ldo; k.M = a.M; k.N = a.N; k.K = a.K;
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.tiles_n = 0; k.nwg = 0;
-  {
-    const char* e = getenv("CLIPMI_GEMM_STAGGER");
-    k.stagger = e ? atoi(e) : 0;
-  }
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:

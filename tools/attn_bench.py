@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Tuning aid: attention kernel time at the tower shapes (persistent vs per-item kernel)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clip_calibration_amd import ops
+from gemm_bench import timeit
+
+for name, n, l, h, causal in [("vision B=256", 256, 197, 12, False), ("text C=1000", 1000, 77, 8, True), ("maple B=256", 256, 199, 12, False)]:
+    qkv = torch.randn(n * l, 3 * 64 * h, device="cuda").half()
+    row = [f"{name:14s}"]
+    for np_ in ("0", "1"):
+        os.environ["CLIPMI_ATTN_NO_PERSIST"] = np_
+        t = timeit(lambda: ops.attention(qkv, n, l, h, causal))
+        gb = (qkv.numel() + n * l * 64 * h) * 2 / 1e9
+        row.append(f" {'persist' if np_ == '0' else 'per-item'}: {t*1e3:7.1f} us ({gb/t*1e3/1e3:5.2f} TB/s)")
+    print("".join(row), flush=True)

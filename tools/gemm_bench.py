@@ -15,7 +15,7 @@ SHAPES = [("qkv", M, 2304, 768, _lib.EPI_BIAS, torch.float16),
           ("out", M, 768, 768, _lib.EPI_BIAS_RESIDUAL, torch.float32),
           ("fc", M, 3072, 768, _lib.EPI_BIAS_QUICKGELU, torch.float16),
           ("proj", M, 768, 3072, _lib.EPI_BIAS_RESIDUAL, torch.float32)]
-VARIANTS = os.environ.get("VARIANTS", "0,1,2,3,4,5,6,7").split(",")
+VARIANTS = os.environ.get("VARIANTS", "0,1,2,3,4,5,6,7,8").split(",")
 
 
 ITERS = int(os.environ.get("ITERS", "20"))
