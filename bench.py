@@ -95,13 +95,21 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # BENCH_SAME_GPU=1 is a functional self-test of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the
+    # collectives go through gloo (RCCL refuses two ranks on one device).  Never use it for a measurement.
+    same_gpu = os.environ.get("BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from clip_calibration_amd import ops, synthetic as syn
     from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
@@ -186,7 +194,7 @@ def main():
         "tower_tflops": syn.flops_per_image(args.model) * world * B * args.steps / elapsed / 1e12,
         "text_tower_once_s": text_s, "text_tower_first_call_s": text_s_cold,
         "ece_percent": res["ece"], "accuracy_percent": res["accuracy"],
-        "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<BIAS_QUICKGELU,f16> (MLP c_fc)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<Tile<256,256,4,4,4>, BIAS_QUICKGELU, f16> (MLP c_fc)",
                      "shape": {"M": M, "N": N, "K": K}, "flop_per_launch": gemm_flop, "avg_launch_ms": gemm_ms,
                      "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None},

@@ -712,26 +712,48 @@ int launch_pipe(KArgs k, hipStream_t s) {
 using T128 = Tile<128, 128, 2, 2, 2>;      // 4 waves of 64x64, 64 KiB LDS, 2 workgroups / CU
 using T256w16 = Tile<256, 256, 4, 4, 4>;   // 16 waves of 64x64, 128 KiB LDS, 1 workgroup / CU, 4 waves / SIMD
 using T256w8 = Tile<256, 256, 2, 4, 2>;    // 8 waves of 128x64
+using T320w8 = Tile<320, 256, 2, 4, 2>;     // 8 waves of 160x64: 474 tiles at M=50432, N=768 (1.85 rounds instead of 2.31)
 using T256x128 = Tile<256, 128, 4, 2, 2>;  // 8 waves of 64x64, 96 KiB LDS
 using T128x256o4 = Tile<128, 256, 2, 4, 4>;  // 8 waves of 64x64, <=128 VGPRs so two workgroups share a CU
 using T256x128o4 = Tile<256, 128, 4, 2, 4>;
 
-// CLIPMI_GEMM_VARIANT = 0..8 forces a tile configuration (tuning / test aid).  Default (measured on MI355X at
-// M = 50432, profiles/r01_gemm_variants.txt):
-//   - problems too small to give every CU a 256 x 256 tile, and problems whose 256^2 tile count is a small
-//     non-integer multiple of the CU count (N = 768: 591 tiles = 2.3 rounds), run the 128 x 128 tile with two
-//     workgroups per CU (finer quantisation, epilogue of one workgroup under the main loop of the other);
-//   - everything else runs the 256 x 256 tile with 16 waves of 64 x 64 (half the L2->LDS bytes per flop, four waves
-//     per SIMD to cover LDS/barrier latency).  Interleaved A/B (tools/gemm_ab.py, profiles/r01_gemm_ab.txt): it
-//     beats the 8-wave, ring-pipelined and persistent variants (2, 4, 8, 9) by 3-6 % on the N >= 2304 shapes.
+// Tile choice.  CLIPMI_GEMM_VARIANT = 0..9, a forces a configuration (tuning / test aid; every one is parity-tested).
+// Default: minimise a cost model  rounds x tile area x workgroups-per-CU x penalty  over the three configurations that
+// won the interleaved A/B runs on MI355X (tools/gemm_ab.py, profiles/r01_gemm_ab.txt):
+//   1  256 x 256, 16 waves of 64 x 64   half the L2->LDS bytes per flop of the 128^2 tile; best whenever its tile
+//                                        count fills the CUs evenly (qkv 1034 TF, fc 908 TF at M = 50432)
+//   a  320 x 256,  8 waves of 160 x 64  for tile counts that quantise badly at 256 rows: N = 768 at M = 50432 is
+//                                        591 tiles = 2.31 rounds with (1) but 474 = 1.85 rounds here (proj 917 vs 760 TF)
+//   0  128 x 128,  4 waves, 2 WG / CU   small problems (final projections, tiny batches)
+// rounds = ceil(tiles / (CUs x workgroups per CU)); penalties are the measured per-flop slowdowns relative to (1).
+int device_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+
 int pick_variant(const KArgs& k) {
   const char* e = getenv("CLIPMI_GEMM_VARIANT");
   if (e && e[0] >= '0' && e[0] <= '9') return e[0] - '0';
-  const int64_t tiles = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256);
-  if (tiles < 256) return 0;
-  const int64_t rounds = tiles / 256, rem = tiles % 256;
-  if (rounds < 4 && rem > 0 && rem < 160) return 0;   // a mostly empty last round costs more than the smaller tile
-  return 1;
+  if (e && e[0] == 'a') return 10;
+  struct Cand { int id, bm, bn, per_cu; double penalty; };
+  static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
+  const int cus = device_cus();
+  int best = 1;
+  double best_cost = 1e300;
+  for (const Cand& c : cands) {
+    const int64_t tiles = (int64_t)((k.M + c.bm - 1) / c.bm) * ((k.N + c.bn - 1) / c.bn);
+    const int64_t slots = (int64_t)cus * c.per_cu;
+    const int64_t rounds = (tiles + slots - 1) / slots;
+    const double cost = (double)rounds * c.bm * c.bn * c.per_cu * c.penalty;
+    if (cost < best_cost) { best_cost = cost; best = c.id; }
+  }
+  return best;
 }
 
 template <int EPI, bool OUT_F32>
@@ -746,6 +768,7 @@ int launch_one(const KArgs& k, hipStream_t s) {
     case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
+    case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     default: return launch_tile<T128, EPI, OUT_F32>(k, s);
   }
 }
