@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
@@ -34,7 +34,8 @@ class Geometry(C.Structure):
 
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_out", "b_out", "ln2_g", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj")]
+        "ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_out", "b_out", "ln2_g", "ln2_b", "w_fc", "b_fc", "w_proj", "b_proj",
+        "w_qkv_f", "g_qkv", "c_qkv", "w_fc_f", "g_fc", "c_fc")]
 
 
 class VisionWeights(C.Structure):

@@ -3,6 +3,7 @@
 // (reference clip/model.py:394-424, 334-359, 600-613).  Host-side C++ only; kernels live in the other .hip files.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -55,6 +56,7 @@ struct TowerWs {
   half_t* att;    // [M, D]
   half_t* hid;    // [M, 4D] (vision: aliased by the im2col matrix)
   int32_t* idx;   // [2 * n_seq] eot / gather rows (text)
+  float* stats;   // [LN_MAX_PARTS][M][2] row-sum partials of the residual stream (LayerNorm fold)
   size_t bytes;
 };
 
@@ -74,6 +76,7 @@ TowerWs carve(void* base, int64_t M, int D, int n_seq, size_t hid_min_bytes = 0)
   const size_t hid_bytes = (size_t)M * D * 8;
   w.hid = reinterpret_cast<half_t*>(take(hid_bytes > hid_min_bytes ? hid_bytes : hid_min_bytes));
   w.idx = reinterpret_cast<int32_t*>(take((size_t)n_seq * 8));
+  w.stats = reinterpret_cast<float*>(take((size_t)M * 8 * LN_MAX_PARTS));
   w.bytes = off;
   return w;
 }
@@ -84,32 +87,69 @@ int check_block(const clipmi_block_weights& b) {
     CLIPMI_REQUIRE(p != nullptr, CLIPMI_ERR_ARG, "block weights: null pointer");
     CLIPMI_REQUIRE((uintptr_t)p % 16 == 0, CLIPMI_ERR_ARG, "block weights: pointers must be 16-byte aligned");
   }
+  const void* f[] = {b.w_qkv_f, b.g_qkv, b.c_qkv, b.w_fc_f, b.g_fc, b.c_fc};
+  int n_set = 0;
+  for (const void* p : f) {
+    n_set += p != nullptr;
+    CLIPMI_REQUIRE((uintptr_t)p % 16 == 0, CLIPMI_ERR_ARG, "block weights: folded operands must be 16-byte aligned");
+  }
+  CLIPMI_REQUIRE(n_set == 0 || n_set == 6, CLIPMI_ERR_ARG, "block weights: give all six LayerNorm-folded operands or none");
   return CLIPMI_OK;
 }
 
 // One ResidualAttentionBlock (clip/model.py:185-188) over M = n_seq*L rows.
-int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, hipStream_t s) {
+// folded == true: on entry AND on exit w.xn holds fp16(xres) and w.stats the *parts row-sum partials of xres (written
+// by the residual epilogues); ln_1 / ln_2 are applied inside the in-proj / c_fc GEMM epilogues.
+// folded == false: separate LayerNorm kernels.
+int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
+              hipStream_t s) {
   const int M = n_seq * L, H = D / 64;
   int rc;
-  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
   GemmArgs a{};
-  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_qkv; a.ldw = D; a.bias = b.b_qkv; a.out = w.qkv; a.ldo = 3 * D;
+  if (!folded) {
+    if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+    a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
+  } else {
+    a.W = (const half_t*)b.w_qkv_f; a.bias = b.c_qkv; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_qkv; a.ln_dim = D;
+    a.ln_eps = 1e-5f;
+  }
+  a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
   a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
   if ((rc = launch_gemm(a, s))) return rc;
   if ((rc = launch_attention(w.qkv, w.att, n_seq, L, H, causal, s))) return rc;
   a = GemmArgs{};
   a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
   a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; }
   if ((rc = launch_gemm(a, s))) return rc;
-  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
   a = GemmArgs{};
-  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_fc; a.ldw = D; a.bias = b.b_fc; a.out = w.hid; a.ldo = 4 * D;
+  if (!folded) {
+    if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+    a.W = (const half_t*)b.w_fc; a.bias = b.b_fc;
+  } else {
+    a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_fc; a.ln_dim = D;
+    a.ln_eps = 1e-5f;
+  }
+  a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
   a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
   if ((rc = launch_gemm(a, s))) return rc;
   a = GemmArgs{};
   a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
   a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; }
   return launch_gemm(a, s);
+}
+
+// CLIPMI_LN_FOLD=1 applies ln_1 / ln_2 inside the GEMM epilogues (needs the folded operands).  Off by default: on
+// MI355X at B=256 it measures within 1 % of the separate LayerNorm kernels (the 76 us/layer of LayerNorm it removes
+// come back as exposed epilogue time in the two residual GEMMs; profiles/r01_ln_fold.txt), and the unfused path keeps
+// the two-pass variance.
+bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
+  const char* e = getenv("CLIPMI_LN_FOLD");
+  if (!(e && e[0] == '1')) return false;
+  for (const auto& b : blocks)
+    if (!b.w_qkv_f) return false;
+  return !blocks.empty();
 }
 
 int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
@@ -124,12 +164,15 @@ int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
 // text blocks on w.xres (already holds embeddings + pos)
 int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, hipStream_t s) {
   const int L = m->g.context_length, D = m->g.text_width;
-  int rc;
+  const bool folded = fold_enabled(m->tblocks);
+  int rc, parts = 1;
+  if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, 1, C, L, D, 0, L, s))) return rc;   // input rows of block 0
   for (int i = 0; i < m->g.text_layers; ++i) {
     if (hook && i > 0 && i - 1 < hook->n_deep) {
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * hook->n_ctx * D, C, L, D, 1, hook->n_ctx, s))) return rc;
+      if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, C, L, D, 1, hook->n_ctx, s))) return rc;
     }
-    if ((rc = run_block(m->tblocks[i], w, C, L, D, 1, s))) return rc;
+    if ((rc = run_block(m->tblocks[i], w, C, L, D, 1, folded, &parts, s))) return rc;
   }
   return CLIPMI_OK;
 }
@@ -316,13 +359,17 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
   if ((rc = launch_cls_and_ctx_rows(x0, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, batch, L0,
                                     n_ctx, D, s)))
     return rc;
-  if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, w.xres, CLIPMI_F32, D, batch * L, D, 1e-5f, s)))
+  const bool folded = fold_enabled(m->vblocks);
+  int parts = 1;
+  if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, w.xres, CLIPMI_F32, D, batch * L, D, 1e-5f, s,
+                             folded ? w.xn : nullptr, folded ? w.stats : nullptr)))
     return rc;
   for (int i = 0; i < g.vision_layers; ++i) {
     if (hook && i > 0 && i - 1 < hook->n_deep) {
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
+      if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
     }
-    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, s))) return rc;
+    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s))) return rc;
   }
   // ln_post on the class token only, then @ proj (clip/model.py:419-422)
   if ((rc = launch_layernorm(w.xres, CLIPMI_F32, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, w.xn, CLIPMI_F16, D, batch, D,

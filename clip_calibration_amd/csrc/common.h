@@ -48,7 +48,7 @@ int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
 
 // Extra epilogue used only by the vision tower: scatter patch rows into the token matrix and add the
 // positional embedding (clip/model.py:396-402).
-enum { EPI_PATCH_POS = 100 };
+enum { EPI_PATCH_POS = 100, EPI_RESIDUAL_FOLD = 101 /* BIAS_RESIDUAL + fp16 copy + row partials: own kernel instantiation */ };
 
 struct GemmArgs {
   const half_t* A; int64_t lda;
@@ -59,12 +59,24 @@ struct GemmArgs {
   int M, N, K, epilogue;
   // EPI_PATCH_POS: out row = (m / patches) * tokens + (m % patches) + 1, plus pos[(m % patches) + 1][n]
   const float* pos; int patches; int tokens;
+  // LayerNorm folding (see gemm.hip "LayerNorm folded into the GEMMs").  Row statistics live in a partial buffer
+  // stats[p * M + m] = (sum, sum of squares) of row m over the p-th column tile of the producer; consumers add the
+  // ln_parts partials in a fixed order (deterministic, no atomics, nothing to zero).
+  //   consumer (BIAS / BIAS_QUICKGELU): ln_stats != NULL -> out = epi(rstd[m]*acc - rstd[m]*mean[m]*ln_g[n] + bias[n])
+  //   producer (BIAS_RESIDUAL): x16 != NULL -> also store fp16(out) to x16 (ld = ldo), write this tile's row partials to
+  //   stats_out and report the number of partials per row (= its n-tile count) through *parts_out (host pointer)
+  const float* ln_stats; int ln_parts; const float* ln_g; int ln_dim; float ln_eps;
+  half_t* x16; float* stats_out; int* parts_out;
 };
+constexpr int LN_MAX_PARTS = 8;
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
 int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx, const float* gamma,
                      const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
-                     hipStream_t s);
+                     hipStream_t s, half_t* y16 = nullptr, float* stats_out = nullptr);
+// x16[row,:] = fp16(x[row,:]); stats partial 0 of the row = (sum, sum of squares), partials 1..parts-1 = 0; for rows
+// n*L + first + j, j < n_ctx.  M = N*L is the partial stride.
+int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
 // x0[b, 0, :] = cls + pos[0]; x0[b, tokens0 + j, :] = shallow[j] (MaPLe)     (clip/model.py:398-402,459-460)

@@ -75,6 +75,31 @@ __global__ __launch_bounds__(256) void overwrite_kernel(float* __restrict__ x, c
   for (int d = threadIdx.x; d < D; d += 256) dst[d] = src[d];
 }
 
+// x16[row,:] = fp16(x[row,:]); stats partial 0 = (sum, sum of squares), other partials 0: producer side of the LayerNorm fold for
+// rows that no GEMM epilogue wrote (text-tower input, MaPLe token overwrite).  One wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, half_t* __restrict__ x16,
+                                                        float* __restrict__ stats, int parts, int64_t M, int L, int D, int first,
+                                                        int n_ctx, int total) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= total) return;
+  const int64_t row = (int64_t)(r / n_ctx) * L + first + (r % n_ctx);
+  const float* xr = x + row * D;
+  float s = 0.f, q = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+    *reinterpret_cast<f16x4*>(x16 + row * D + c) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane < parts) *reinterpret_cast<float2*>(stats + 2 * ((int64_t)lane * M + row)) = lane == 0 ? make_float2(s, q) : make_float2(0.f, 0.f);
+}
+
 template <typename TI>
 __global__ __launch_bounds__(256) void add_pos_kernel(const TI* __restrict__ src, const float* __restrict__ pos,
                                                       float* __restrict__ xres, int L, int D4, int64_t total4) {
@@ -218,6 +243,16 @@ int launch_overwrite_tokens(float* x, const float* prompt, int N, int L, int D, 
   if (N == 0) return CLIPMI_OK;
   hipLaunchKernelGGL(overwrite_kernel, dim3(N * n_ctx), dim3(256), 0, s, x, prompt, L, D, first, n_ctx);
   return check_launch("overwrite_kernel");
+}
+
+int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s) {
+  CLIPMI_REQUIRE(x && x16 && stats, CLIPMI_ERR_ARG, "row_stats: null pointer");
+  CLIPMI_REQUIRE(parts >= 1 && parts <= LN_MAX_PARTS, CLIPMI_ERR_ARG, "row_stats: parts=%d", parts);
+  CLIPMI_REQUIRE(D % 4 == 0 && first >= 0 && n_ctx > 0 && first + n_ctx <= L, CLIPMI_ERR_SHAPE, "row_stats: bad shape");
+  const int total = N * n_ctx;
+  if (total == 0) return CLIPMI_OK;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((total + 3) / 4), dim3(256), 0, s, x, x16, stats, parts, (int64_t)N * L, L, D, first, n_ctx, total);
+  return check_launch("row_stats_kernel");
 }
 
 int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int D, hipStream_t s) {

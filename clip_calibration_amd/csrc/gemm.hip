@@ -34,7 +34,34 @@ struct KArgs {
   const float* pos; int patches; int tokens;
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
+  const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
+  half_t* x16; float* stats_out;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs (removes the two LayerNorm kernels of every residual block and their 232 MB pass).
+//   LN(x) @ W^T + b  =  rstd * (x @ (gamma*W)^T)  -  rstd*mean * g  +  c,   g[n] = sum_k (gamma*W)[n,k],
+//                                                                           c[n] = sum_k beta[k] W[n,k] + b[n]
+// The producer of x (a BIAS_RESIDUAL epilogue, or the ln_pre LayerNorm kernel) also writes fp16(x) -- the operand of
+// the consumer GEMM -- and per-row partial sums of x and x^2, one (sum, sumsq) pair per column tile of the producer
+// (reduced over the workgroup's waves through LDS, then a plain store: no atomics, nothing to zero, bit-reproducible).
+// The consumer adds the partials in order and forms the variance E[x^2] - mean^2 in double.  g is summed from the
+// fp16-rounded folded weights the MFMA actually multiplies, so the mean term cancels as it does inside a LayerNorm.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_row_params(const KArgs& a, int m, float& rstd, float& mu_rstd) {
+  const int mm = m < a.M ? m : a.M - 1;
+  double s = 0.0, ss = 0.0;
+  for (int p = 0; p < a.ln_parts; ++p) {
+    const float2 st = *reinterpret_cast<const float2*>(a.ln_stats + 2 * ((int64_t)p * a.M + mm));
+    s += (double)st.x;
+    ss += (double)st.y;
+  }
+  const double mean = s * (double)a.ln_inv_d;
+  double var = ss * (double)a.ln_inv_d - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  rstd = rsqrtf((float)var + a.ln_eps);
+  mu_rstd = (float)mean * rstd;
+}
 
 // Tile configuration: BM x BN workgroup tile (m = activation rows, n = weight rows), WGM x WGN waves.
 template <int BM_, int BN_, int WGM_, int WGN_, int OCC_>
@@ -83,13 +110,18 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
   static_assert(T::WTN == 64 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue assumes 64-column wave tiles");
   constexpr int ROWB = T::WTN * 2 + 16;  // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
   const int r16 = lane & 15, g4 = lane >> 4;
-  f32x4 bias[TN];
+  f32x4 bias[TN], lng[TN];
+  const bool fold = a.ln_stats != nullptr;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (EPI != CLIPMI_EPI_NONE) {
       const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
-      if (n < a.N) bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
+      if (n < a.N) {
+        bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (fold) lng[i] = *reinterpret_cast<const f32x4*>(a.ln_g + n);
+      }
     }
   }
   half_t* out = static_cast<half_t*>(a.out);
@@ -99,9 +131,11 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
   for (int jc = 0; jc < TM / CH; ++jc) {
 #pragma unroll
     for (int jj = 0; jj < CH; ++jj) {
+      float rs = 1.f, mrs = 0.f;
+      if (fold) ln_row_params(a, m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16, rs, mrs);
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        f32x4 v = acc[i][jc * CH + jj] + bias[i];
+        f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
         if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -121,6 +155,79 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
   }
 }
 
+// Producer side of the LayerNorm fold: BIAS_RESIDUAL epilogue that, besides the fp32 read-modify-write of the residual
+// stream, stores fp16(out) to x16 through the wave-private LDS transpose and writes this tile's row partials.
+// Worked in chunks of 32 rows with a scheduling fence between chunks, so that the residual loads of later chunks are
+// not hoisted over the whole epilogue (the 160-accumulator tile has no registers to spare).
+template <typename T>
+__device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int tile_n,
+                                                       int wave_m, int wave_n, int lane, int wave, char* smem) {
+  constexpr int TM = T::TM, TN = T::TN;
+  constexpr int ROWB = T::WTN * 2 + 16;
+  constexpr int PATCH = 32 * ROWB;
+  static_assert(T::WTN == 64 && TM % 2 == 0, "fold epilogue assumes 64-column wave tiles");
+  const int r16 = lane & 15, g4 = lane >> 4;
+  char* patch = smem + wave * PATCH;
+  float2* red = reinterpret_cast<float2*>(smem + T::NW * PATCH);   // [WGN][BM]
+  __syncthreads();   // every wave is done with the main-loop LDS image
+  float* out = static_cast<float*>(a.out);
+  const int rrow = lane >> 3, rcol = lane & 7;
+  const int n_st = n0 + wave_n * T::WTN + rcol * 8;
+  f32x4 bias[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+    bias[i] = n < a.N ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int jc = 0; jc < TM / 2; ++jc) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int ml = wave_m * T::WTM + (jc * 2 + jj) * 16 + r16;
+      const int m = m0 + ml;
+      float rsum = 0.f, rsq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < a.M && n < a.N) {
+          v = acc[i][jc * 2 + jj] + bias[i] + *reinterpret_cast<const f32x4*>(a.residual + (int64_t)m * a.ldo + n);
+          *reinterpret_cast<f32x4*>(out + (int64_t)m * a.ldo + n) = v;
+          rsum += (v[0] + v[1]) + (v[2] + v[3]);
+          rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
+            f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      }
+      rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
+      rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+      if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {   // same wave, LDS in order: reads see the writes above
+      const int row = t * 8 + rrow;
+      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+      const int m = m0 + wave_m * T::WTM + jc * 32 + row;
+      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T::BM; t += T::NT) {
+    const int m = m0 + t;
+    if (m < a.M) {
+      float sx = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < T::WGN; ++w) {
+        const float2 pr = red[w * T::BM + t];
+        sx += pr.x;
+        sq += pr.y;
+      }
+      *reinterpret_cast<float2*>(a.stats_out + 2 * ((int64_t)tile_n * a.M + m)) = make_float2(sx, sq);
+    }
+  }
+}
+
 template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
                                                 int wave_n, int lane);
@@ -128,6 +235,10 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
                                          int lane, int wave, char* smem) {
+  if constexpr (EPI == EPI_RESIDUAL_FOLD) {
+    epilogue_residual_fold<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
+    return;
+  }
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
     if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {   // wave-uniform
       __syncthreads();                           // every wave is done with the main-loop LDS image
@@ -156,12 +267,21 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
       orow = (int64_t)b * a.tokens + t;
       posrow = a.pos + (int64_t)t * a.N;
     }
+    float rs = 1.f, mrs = 0.f;
+    if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+      if (a.ln_stats) ln_row_params(a, m, rs, mrs);
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
-      if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL) {
+      if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.ln_stats) b -= mrs * *reinterpret_cast<const f32x4*>(a.ln_g + n);
+        v = v * rs + b;
+      }
+      if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
         v += b;
       }
@@ -757,8 +877,17 @@ int pick_variant(const KArgs& k) {
 }
 
 template <int EPI, bool OUT_F32>
-int launch_one(const KArgs& k, hipStream_t s) {
-  switch (pick_variant(k)) {
+int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
+  int variant = pick_variant(k);
+  if (k.x16) {   // producer fold: needs the non-persistent epilogue and at most LN_MAX_PARTS column tiles
+    if (variant == 9) variant = 2;
+    const int bn = (variant == 0) ? 128 : (variant == 3 || variant == 7) ? 128 : 256;
+    if ((k.N + bn - 1) / bn > LN_MAX_PARTS) variant = 1;
+    CLIPMI_REQUIRE((k.N + 255) / 256 <= LN_MAX_PARTS, CLIPMI_ERR_SHAPE, "gemm: N=%d has too many column tiles for the LayerNorm fold", k.N);
+    const int bn2 = (variant == 0 || variant == 3 || variant == 7) ? 128 : 256;
+    *parts_out = (k.N + bn2 - 1) / bn2;
+  }
+  switch (variant) {
     case 1: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
     case 2: return launch_tile<T256w8, EPI, OUT_F32>(k, s);
     case 3: return launch_tile<T256x128, EPI, OUT_F32>(k, s);
@@ -793,25 +922,34 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.A = a.A; k.lda = a.lda; k.W = a.W; k.ldw = a.ldw; k.bias = a.bias; k.residual = a.residual;
   k.out = a.out; k.ldo = a.ldo; k.M = a.M; k.N = a.N; k.K = a.K;
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
+  k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
+  k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
+  CLIPMI_REQUIRE(!a.ln_stats || (a.ln_g && a.ln_dim > 0 && a.ln_parts >= 1 && a.ln_parts <= LN_MAX_PARTS &&
+                                 (a.epilogue == CLIPMI_EPI_BIAS || a.epilogue == CLIPMI_EPI_BIAS_QUICKGELU)),
+                 CLIPMI_ERR_ARG, "gemm: LayerNorm fold needs ln_g, ln_dim, 1..%d partials and a BIAS / BIAS_QUICKGELU epilogue", LN_MAX_PARTS);
+  CLIPMI_REQUIRE((!a.x16 && !a.stats_out) || (a.x16 && a.stats_out && a.parts_out && a.epilogue == CLIPMI_EPI_BIAS_RESIDUAL &&
+                                              a.N % 8 == 0 && a.ldo % 8 == 0),
+                 CLIPMI_ERR_ARG, "gemm: x16/stats_out/parts_out come together, only with BIAS_RESIDUAL and N %% 8 == 0");
   k.tiles_n = 0; k.nwg = 0;
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:
-      return f32 ? launch_one<CLIPMI_EPI_NONE, true>(k, s) : launch_one<CLIPMI_EPI_NONE, false>(k, s);
+      return f32 ? launch_one<CLIPMI_EPI_NONE, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_NONE, false>(k, s, a.parts_out);
     case CLIPMI_EPI_BIAS:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
-      return f32 ? launch_one<CLIPMI_EPI_BIAS, true>(k, s) : launch_one<CLIPMI_EPI_BIAS, false>(k, s);
+      return f32 ? launch_one<CLIPMI_EPI_BIAS, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS, false>(k, s, a.parts_out);
     case CLIPMI_EPI_BIAS_QUICKGELU:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
-      return f32 ? launch_one<CLIPMI_EPI_BIAS_QUICKGELU, true>(k, s) : launch_one<CLIPMI_EPI_BIAS_QUICKGELU, false>(k, s);
+      return f32 ? launch_one<CLIPMI_EPI_BIAS_QUICKGELU, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS_QUICKGELU, false>(k, s, a.parts_out);
     case CLIPMI_EPI_BIAS_RESIDUAL:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
       CLIPMI_REQUIRE(a.residual && (uintptr_t)a.residual % 16 == 0, CLIPMI_ERR_ARG, "gemm: residual missing/unaligned");
       CLIPMI_REQUIRE(f32, CLIPMI_ERR_ARG, "gemm: the residual stream is fp32");
-      return launch_one<CLIPMI_EPI_BIAS_RESIDUAL, true>(k, s);
+      if (a.x16) return launch_one<EPI_RESIDUAL_FOLD, true>(k, s, a.parts_out);
+      return launch_one<CLIPMI_EPI_BIAS_RESIDUAL, true>(k, s, a.parts_out);
     case EPI_PATCH_POS:
       CLIPMI_REQUIRE(a.pos && a.patches > 0 && a.tokens > a.patches && f32, CLIPMI_ERR_ARG, "gemm: bad patch epilogue");
-      return launch_one<EPI_PATCH_POS, true>(k, s);
+      return launch_one<EPI_PATCH_POS, true>(k, s, a.parts_out);
     default:
       set_error("gemm: unknown epilogue %d", a.epilogue);
       return CLIPMI_ERR_ARG;

@@ -31,7 +31,8 @@ template <typename TI, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, int64_t in_stride,
                                                         const int32_t* __restrict__ gather, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TO* __restrict__ y,
-                                                        int64_t out_stride, int rows, int D, float eps) {
+                                                        int64_t out_stride, int rows, int D, float eps,
+                                                        half_t* __restrict__ y16, float* __restrict__ stats_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
   TO* yr = y + (int64_t)row * out_stride;
+  float os = 0.f, oq = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
@@ -75,21 +77,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       Vec4<TO>::store(yr + c * 4, o);
+      if (y16) {   // producer side of the LayerNorm fold (gemm.hip): fp16 copy + row sums of the OUTPUT
+        Vec4<half_t>::store(y16 + (int64_t)row * out_stride + c * 4, o);
+        os += (o[0] + o[1]) + (o[2] + o[3]);
+        oq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+      }
+    }
+  }
+  if (stats_out) {
+    os = wave_sum(os);
+    oq = wave_sum(oq);
+    if (lane == 0) {
+      *reinterpret_cast<float2*>(stats_out + 2 * (int64_t)row) = make_float2(os, oq);   // partial 0 (the only one)
     }
   }
 }
 
 template <typename TI, typename TO>
 int dispatch(const void* x, int64_t in_stride, const int32_t* gather, const float* gamma, const float* beta, void* y,
-             int64_t out_stride, int rows, int D, float eps, hipStream_t s) {
+             int64_t out_stride, int rows, int D, float eps, hipStream_t s, half_t* y16, float* stats_out) {
   const dim3 grid((rows + 3) / 4), block(256);
   const int nvec = D / 4;
   if (nvec <= 64 * 4) {
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 4>), grid, block, 0, s, (const TI*)x, in_stride, gather, gamma, beta,
-                       (TO*)y, out_stride, rows, D, eps);
+                       (TO*)y, out_stride, rows, D, eps, y16, stats_out);
   } else {
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 16>), grid, block, 0, s, (const TI*)x, in_stride, gather, gamma, beta,
-                       (TO*)y, out_stride, rows, D, eps);
+                       (TO*)y, out_stride, rows, D, eps, y16, stats_out);
   }
   return check_launch("layernorm_kernel");
 }
@@ -98,8 +112,9 @@ int dispatch(const void* x, int64_t in_stride, const int32_t* gather, const floa
 
 int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx, const float* gamma,
                      const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
-                     hipStream_t s) {
+                     hipStream_t s, half_t* y16, float* stats_out) {
   CLIPMI_REQUIRE(x && gamma && beta && y, CLIPMI_ERR_ARG, "layernorm: null pointer");
+  CLIPMI_REQUIRE((!y16 && !stats_out) || (y16 && stats_out), CLIPMI_ERR_ARG, "layernorm: y16 and stats_out come together");
   if (rows == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, CLIPMI_ERR_SHAPE,
                  "layernorm: rows=%d D=%d unsupported (D %% 4 == 0, D <= 4096)", rows, D);
@@ -109,10 +124,10 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
                  CLIPMI_ERR_ARG, "layernorm: unaligned pointer");
   const bool xi32 = x_dtype == CLIPMI_F32, yo32 = y_dtype == CLIPMI_F32;
   CLIPMI_REQUIRE((xi32 || x_dtype == CLIPMI_F16) && (yo32 || y_dtype == CLIPMI_F16), CLIPMI_ERR_ARG, "layernorm: bad dtype");
-  if (xi32 && yo32) return dispatch<float, float>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s);
-  if (xi32 && !yo32) return dispatch<float, half_t>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s);
-  if (!xi32 && yo32) return dispatch<half_t, float>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s);
-  return dispatch<half_t, half_t>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s);
+  if (xi32 && yo32) return dispatch<float, float>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s, y16, stats_out);
+  if (xi32 && !yo32) return dispatch<float, half_t>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s, y16, stats_out);
+  if (!xi32 && yo32) return dispatch<half_t, float>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s, y16, stats_out);
+  return dispatch<half_t, half_t>(x, in_stride, gather_idx, gamma, beta, y, out_stride, rows, D, eps, s, y16, stats_out);
 }
 
 }  // namespace clipmi

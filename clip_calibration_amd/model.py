@@ -217,13 +217,25 @@ class CLIP(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        def fold(lin_w, lin_b, ln):
+            """LayerNorm folded into the following Linear (csrc/gemm.hip "LayerNorm folded into the GEMMs"):
+            w_f = fp16(gamma * W), g = row sums of that fp16 w_f (what the MFMA multiplies), c = W beta + b."""
+            w32 = lin_w.detach().float()
+            wf = (w32 * ln.weight.detach().float()[None, :]).to(torch.float16).contiguous()
+            gsum = wf.float().sum(dim=1).contiguous()
+            c = (w32 @ ln.bias.detach().float() + lin_b.detach().float()).contiguous()
+            keep.extend([wf, gsum, c])
+            return wf.data_ptr(), gsum.data_ptr(), c.data_ptr()
+
         def blocks(mods) -> "C.Array":
             arr = (_lib.BlockWeights * len(mods))()
             for i, b in enumerate(mods):
                 arr[i] = _lib.BlockWeights(
                     f32(b.ln_1.weight), f32(b.ln_1.bias), f16(b.attn.in_proj_weight), f32(b.attn.in_proj_bias),
                     f16(b.attn.out_proj.weight), f32(b.attn.out_proj.bias), f32(b.ln_2.weight), f32(b.ln_2.bias),
-                    f16(b.mlp.c_fc.weight), f32(b.mlp.c_fc.bias), f16(b.mlp.c_proj.weight), f32(b.mlp.c_proj.bias))
+                    f16(b.mlp.c_fc.weight), f32(b.mlp.c_fc.bias), f16(b.mlp.c_proj.weight), f32(b.mlp.c_proj.bias),
+                    *fold(b.attn.in_proj_weight, b.attn.in_proj_bias, b.ln_1),
+                    *fold(b.mlp.c_fc.weight, b.mlp.c_fc.bias, b.ln_2))
             return arr
 
         v = self.visual

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 1
+#define CLIPMI_ABI_VERSION 2
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -136,6 +136,11 @@ typedef struct clipmi_block_weights {
   const float* ln2_g; const float* ln2_b;
   const void* w_fc;   const float* b_fc;    /* mlp.c_fc [4D,D] */
   const void* w_proj; const float* b_proj;  /* mlp.c_proj [D,4D] */
+  /* Optional LayerNorm-folded operands (all six or none; NULL = run ln_1 / ln_2 as separate kernels):
+   *   w_*_f = fp16(gamma * W) row-wise over the input dim, g_*[n] = sum_k float(w_*_f[n,k]),
+   *   c_*[n] = sum_k beta[k] * W[n,k] + b[n];  LN(x) W^T + b = rstd*(x w_f^T) - rstd*mean*g + c. */
+  const void* w_qkv_f; const float* g_qkv; const float* c_qkv;   /* ln_1 folded into attn.in_proj */
+  const void* w_fc_f;  const float* g_fc;  const float* c_fc;    /* ln_2 folded into mlp.c_fc */
 } clipmi_block_weights;
 
 typedef struct clipmi_vision_weights {

@@ -232,6 +232,29 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle():
     assert coop_new.text_features() is not got_new
 
 
+@pytest.mark.parametrize("gname", ["tiny", "ViT-B/16"])
+def test_layernorm_fold_path(monkeypatch, gname):
+    """CLIPMI_LN_FOLD=1: ln_1 / ln_2 applied inside the GEMM epilogues (gamma folded into the weights, mean / rstd from
+    per-tile row partials).  Same tolerance as the default path, and bit-reproducible run to run."""
+    monkeypatch.setenv("CLIPMI_LN_FOLD", "1")
+    sd, model = _build(gname)
+    images = syn.synthetic_images(3, gname, seed=3)
+    ids = syn.synthetic_token_ids(6, gname, seed=3)
+    with torch.no_grad():
+        a = model.image_features_f32(images.cuda())
+        b = model.image_features_f32(images.cuda())
+        t = model.text_features_f32(ids.cuda())
+        ref_i = orc.encode_image(sd, images).numpy()
+        ref_t = orc.encode_text(sd, ids).numpy()
+    assert torch.equal(a, b)
+    _feat_close(a.cpu().numpy(), ref_i, "folded image tower")
+    _feat_close(t.cpu().numpy(), ref_t, "folded text tower")
+    monkeypatch.setenv("CLIPMI_LN_FOLD", "0")
+    with torch.no_grad():
+        c = model.image_features_f32(images.cuda())
+    assert np.abs(_cos(a.cpu().numpy(), c.cpu().numpy()) - _cos(c.cpu().numpy(), c.cpu().numpy())).max() < 5e-4
+
+
 def test_stress_residual_magnitudes():
     """Scaled-up residual branches (real CLIP has large outlier channels): still finite and within tolerance."""
     from clip_calibration_amd.model import build_model
