@@ -36,7 +36,7 @@ __device__ __forceinline__ f16x4 tr_read(const char* p) {
 // the fp16 pack.  Masking code exists only in tiles that can contain a dead key (wave-uniform test); fully dead
 // causal tiles are skipped.  Row sums come out of the matrix pipe: a third "V^T" tile of all ones accumulates
 // sum_k P[k][q] in lacc alongside O, from the same fp16-rounded P that multiplies V.
-template <int NKT, int GROUP, bool TR>
+template <int NKT, int GROUP, bool TR, int DENSE = 0>
 __device__ __forceinline__ void attend_block(const char* const (&kread)[4], const char* const (&vread)[2], const f16x8 (&qf)[4],
                                              int kb0, int L, int causal, int q0, int q, int hh, float& m_run,
                                              f32x16 (&oacc)[2], f32x16& lacc) {
@@ -53,7 +53,11 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
       live[t] = false;
       if (kt < NKT) {
         const int k_lo = kb0 + kt * 32;
-        live[t] = (k_lo < L) && !(causal && k_lo > q0 + 31);
+        // DENSE (vision towers: no causal mask, L > (NKT-1)*32): every tile is live and only the last can be partial,
+        // so the whole group is one basic block and hipcc can run the LDS reads ahead of the MFMAs
+        // DENSE == 2 (text tower, 3 tiles): every tile is computed and masked per lane -- a few wasted MFMAs buy
+        // straight-line code.
+        live[t] = DENSE ? true : ((k_lo < L) && !(causal && k_lo > q0 + 31));
         if (live[t]) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
@@ -62,12 +66,12 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
             const f16x8 kf = *reinterpret_cast<const f16x8*>(kread[ks] + kt * 4096);
             s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
           }
-          const bool partial = (k_lo + 32 > L) || (causal && k_lo + 31 > q0);   // wave-uniform
+          const bool partial = DENSE == 1 ? (kt == NKT - 1) : (DENSE == 2 ? true : ((k_lo + 32 > L) || (causal && k_lo + 31 > q0)));   // wave-uniform
           if (partial) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int key = k_lo + (e & 3) + 8 * (e >> 2) + 4 * hh;
-              const bool dead = (key >= L) || (causal && key > q);
+              const bool dead = DENSE == 1 ? (key >= L) : ((key >= L) || (causal && key > q));
               s[t][e] = dead ? NEG_BIG : s[t][e];
             }
           }
@@ -237,9 +241,9 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
 // the HBM/L2 latency of the operands never sits on the critical path.  Per item: vmcnt(0) (loads issued a whole item
 // ago) -> barrier -> issue loads for the next item -> compute -> store.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NKT, int GROUP>
+template <int NKT, int GROUP, int DENSE>
 __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                                   int L, int H, int causal, int n_items) {
+                                                                   int L, int H, int causal, int n_items, int stagger) {
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V
@@ -302,9 +306,16 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
     const int next = item + gridDim.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // this item's K/V visible to all waves; everybody is done with the other buffer
+    // qf was loaded one item ago and is complete (vmcnt(0) above).  Make that visible to hipcc: without this fence it
+    // waits vmcnt(0) at the first MFMA that reads qf -- AFTER the prefetch below has been issued -- and the prefetch
+    // of the next item's K/V/Q ends up on the critical path.
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     if (next < n_items) {
       stage(next, buf ^ 1);
       load_q(next, qn);
+    }
+    if (stagger > 0 && wave >= 4) {   // waves w and w+4 share a SIMD: run them half a phase apart (MFMA beside VALU)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(4);
     }
     if (active) {
       const char* b = smem + buf * BUF;
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
       f32x16 lacc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-      attend_block<NKT, GROUP, true>(kread, vread, qf, 0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      attend_block<NKT, GROUP, true, DENSE>(kread, vread, qf, 0, L, causal, q0, q, hh, m_run, oacc, lacc);
       if (q < L) {
         const int n = item / H, h = item - n * H;
         store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
@@ -330,12 +341,12 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
   }
 }
 
-template <int NKT, int GROUP>
+template <int NKT, int GROUP, int DENSE>
 int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
   static bool attr_set = false;
   static int n_cu = 0;
-  auto fn = attention_persist_kernel<NKT, GROUP>;
+  auto fn = attention_persist_kernel<NKT, GROUP, DENSE>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       (void)hipGetLastError();
@@ -350,7 +361,8 @@ int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int caus
   const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
   const int n_items = N * H;
   const int grid = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items);
+  const char* st = getenv("CLIPMI_ATTN_STAGGER");
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items, st ? atoi(st) : 0);
   return check_launch("attention_persist_kernel");
 }
 
@@ -390,8 +402,14 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   const bool tr = use_tr();
   const char* np = getenv("CLIPMI_ATTN_NO_PERSIST");
   if (tr && !(np && np[0] == '1')) {
-    if (L <= 96) return launch_persist<3, 3>(qkv, out, N, L, H, causal, s);
-    if (L <= 224) return launch_persist<7, 4>(qkv, out, N, L, H, causal, s);
+    if (L <= 96) {
+      if (causal && L > 64) return launch_persist<3, 3, 2>(qkv, out, N, L, H, causal, s);
+      return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);
+    }
+    if (L <= 224) {
+      if (!causal && L > 192) return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
+      return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
+    }
   }
   if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
   return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);
