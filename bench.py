@@ -171,6 +171,16 @@ def main():
     gemm_ms = model.profile_mlp_gemm_ms(B, iters=24)              # hipEvents on the launch stream, per launch
     gemm_flop = 2.0 * M * N * K
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+    # HBM-side bytes per launch of that kernel come from the PMC passes committed under profiles/ (rocprofv3 cannot
+    # run inside this process); only reported when the profile is for exactly this shape.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_mlp_gemm_traffic.json")) as f:
+            prof = json.load(f)
+        if prof["shape"] == {"M": M, "N": N, "K": K}:
+            traffic = prof["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "images/sec ViT-B/16 224px zero-shot + ECE",
@@ -197,7 +207,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<Tile<256,256,4,4,4>, BIAS_QUICKGELU, f16> (MLP c_fc)",
                      "shape": {"M": M, "N": N, "K": K}, "flop_per_launch": gemm_flop, "avg_launch_ms": gemm_ms,
                      "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None},
+                     "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01_mlp_gemm_traffic.json; "
+                                     "algorithmic bytes = 2*(M*K + N*K + M*N)"},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
