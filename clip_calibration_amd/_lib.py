@@ -74,6 +74,7 @@ _SIGNATURES = {
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipmi_calibrate_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "clipmi_knn_dists": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_ece_accumulate": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     "clipmi_create": (_i, [C.POINTER(Geometry), C.POINTER(_vp)]),
     "clipmi_destroy": (_i, [_vp]),

@@ -262,6 +262,10 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
 
+int clipmi_knn_dists(const float* queries, const float* refs, float* out, int Nq, int Nr, int E, int K, clipmi_stream_t stream) {
+  return launch_knn(queries, refs, out, Nq, Nr, E, K, (hipStream_t)stream);
+}
+
 int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins, int n_bins,
                           clipmi_stream_t stream) {
   return launch_ece_accumulate(conf, pred, labels, n, bins, n_bins, (hipStream_t)stream);

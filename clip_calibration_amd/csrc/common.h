@@ -98,6 +98,8 @@ int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
 int launch_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins,
                           int n_bins, hipStream_t s);
 
+int launch_knn(const float* q, const float* refs, float* out, int Nq, int Nr, int E, int K, hipStream_t s);
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 

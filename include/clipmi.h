@@ -109,6 +109,12 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
 int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n,
                           double* bins, int n_bins, clipmi_stream_t stream);
 
+/* get_knn_dists / get_val_image_knn_dists (trainers/calibration/proximity.py:19-70) -- SURVEY f-2: for every query row
+ * the K smallest L2 distances ||refs[j] - queries[i]||_2, ascending, out fp32 [Nq, K].  queries [Nq,E], refs [Nr,E]
+ * fp32; E % 64 == 0; 1 <= K <= min(16, Nr).  (The "val image" variant asks for K+1 against itself and drops column 0.) */
+int clipmi_knn_dists(const float* queries, const float* refs, float* out, int Nq, int Nr, int E, int K,
+                     clipmi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Model level.  One handle per CLIP model per GPU.
  * ---------------------------------------------------------------------------------------------------- */

@@ -264,6 +264,22 @@ def ece(conf: np.ndarray, pred: np.ndarray, gt: np.ndarray, n_bins: int = 10) ->
     return float(np.sum(weights * np.abs(avg - acc)))
 
 
+def knn_dists(val_base_class_features: np.ndarray, image_features_cur: np.ndarray, k: int) -> np.ndarray:
+    """get_knn_dists (trainers/calibration/proximity.py:19-46): per query, the k smallest L2 distances to the reference
+    rows, ascending (fp32, like the torch tensors the reference builds)."""
+    refs = np.asarray(val_base_class_features, dtype=np.float32)
+    q = np.asarray(image_features_cur, dtype=np.float32)
+    out = np.empty((q.shape[0], k), dtype=np.float32)
+    for i in range(q.shape[0]):
+        out[i] = np.sort(np.linalg.norm(refs - q[i], axis=1))[:k]
+    return out
+
+
+def val_image_knn_dists(image_features_cur: np.ndarray, k: int) -> np.ndarray:
+    """get_val_image_knn_dists (proximity.py:49-70): k+1 nearest within the set itself, the first (self) dropped."""
+    return knn_dists(image_features_cur, image_features_cur, k + 1)[:, 1:]
+
+
 def tokenize_ids(token_lists: List[List[int]], sot: int, eot: int, context_length: int = 77) -> np.ndarray:
     """clip.tokenize's packing (clip/clip.py:207-224): [SOT] + bpe + [EOT], zero padded to 77, error if too long."""
     out = np.zeros((len(token_lists), context_length), dtype=np.int64)

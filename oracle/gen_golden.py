@@ -209,6 +209,27 @@ def main():
     np.savez_compressed(os.path.join(OUT, "dac_cases.npz"), **dac)
     print("wrote dac_cases.npz")
 
+    # ---------------- kNN proximity (trainers/calibration/proximity.py) ----------------
+    # both functions hard-code .to('cuda'); shimmed to the identity as above
+    ref_prox = _load("ref_prox", "trainers/calibration/proximity.py")
+    torch_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else torch_to(self, *a, **k)
+    knn = {}
+    try:
+        for name, (nq, nr, dim, k) in {"k5": (37, 150, 128, 5), "k10": (20, 64, 64, 10), "tiny": (3, 7, 64, 5)}.items():
+            refs = rng.normal(size=(nr, dim)).astype(np.float32)
+            refs /= np.linalg.norm(refs, axis=1, keepdims=True)
+            q = rng.normal(size=(nq, dim)).astype(np.float32)
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            q[0] = refs[3]                                   # an exact duplicate: distance 0
+            knn.update({f"{name}:refs": refs, f"{name}:queries": q, f"{name}:k": np.int64(k),
+                        f"{name}:knn": ref_prox.get_knn_dists(refs, q, k),
+                        f"{name}:val_knn": ref_prox.get_val_image_knn_dists(refs, min(k, nr - 2))})
+    finally:
+        torch.Tensor.to = torch_to
+    np.savez_compressed(os.path.join(OUT, "knn_cases.npz"), **knn)
+    print("wrote knn_cases.npz")
+
 
 if __name__ == "__main__":
     main()

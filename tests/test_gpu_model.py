@@ -232,6 +232,24 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle():
     assert coop_new.text_features() is not got_new
 
 
+@pytest.mark.parametrize("gname,batch", [("ViT-L/14", 2), ("ViT-L/14@336px", 1)])
+def test_vit_large_towers_vs_oracle(gname, batch):
+    """BASELINE config 5 geometry (ViT-L/14 at 224 and 336 px: 24 layers, width 1024, patch 14 -> K padded 588 -> 640,
+    L = 257 / 577 tokens -> multi-block attention, E = 768; text tower width 768) against the CPU oracle."""
+    sd, model = _build(gname)
+    images = syn.synthetic_images(batch, gname, seed=11)
+    ids = syn.synthetic_token_ids(5, gname, seed=11)
+    with torch.no_grad():
+        img = model.image_features_f32(images.cuda())
+        txt = model.text_features_f32(ids.cuda())
+        ref_i = orc.encode_image(sd, images).numpy()
+        ref_t = orc.encode_text(sd, ids).numpy()
+    _feat_close(img.cpu().numpy(), ref_i, f"{gname} image tower")
+    _feat_close(txt.cpu().numpy(), ref_t, f"{gname} text tower")
+    cos = _cos(img.cpu().numpy(), txt.cpu().numpy())
+    assert np.abs(cos - _cos(ref_i, ref_t)).max() < COS_TOL
+
+
 @pytest.mark.parametrize("gname", ["tiny", "ViT-B/16"])
 def test_layernorm_fold_path(monkeypatch, gname):
     """CLIPMI_LN_FOLD=1: ln_1 / ln_2 applied inside the GEMM epilogues (gamma folded into the weights, mean / rstd from

@@ -214,3 +214,21 @@ def test_ece_device_accumulation(ops):
         assert res["ece"] / 100.0 == pytest.approx(want, abs=1e-6), n
         assert res["total"] == len(conf)
         assert ECE(conf32, pred, gt, bins) == pytest.approx(want, abs=1e-6)
+
+
+def test_knn_proximity(ops):
+    """SURVEY f-2: kNN distances vs fixtures produced by the reference's own proximity.py, then a larger oracle case."""
+    from clip_calibration_amd import proximity as prox
+    g = load_golden("knn_cases.npz")
+    for n in sorted({k.split(":")[0] for k in g}):
+        k = int(g[f"{n}:k"])
+        got = prox.get_knn_dists(g[f"{n}:refs"], g[f"{n}:queries"], k)
+        assert got.shape == g[f"{n}:knn"].shape and got.dtype == np.float32
+        np.testing.assert_allclose(got, g[f"{n}:knn"], rtol=3e-6, atol=3e-7)
+        kv = g[f"{n}:val_knn"].shape[1]
+        np.testing.assert_allclose(prox.get_val_image_knn_dists(g[f"{n}:refs"], kv), g[f"{n}:val_knn"], rtol=3e-6, atol=3e-7)
+    rng = np.random.default_rng(5)
+    refs = rng.normal(size=(1000, 512)).astype(np.float32)
+    q = rng.normal(size=(203, 512)).astype(np.float32)
+    np.testing.assert_allclose(prox.get_knn_dists(refs, q, 10), orc.knn_dists(refs, q, 10), rtol=3e-6)
+    np.testing.assert_allclose(prox.proximity_from_knn(orc.knn_dists(refs, q, 5)), np.exp(-orc.knn_dists(refs, q, 5).mean(1)))

@@ -146,3 +146,14 @@ def test_tokenize_packing():
     assert ids.argmax(-1)[0] == 7
     with pytest.raises(RuntimeError):
         orc.tokenize_ids([[5] * 80], 1, 2)
+
+
+def test_knn_cases():
+    g = load_golden("knn_cases.npz")
+    for n in sorted({k.split(":")[0] for k in g}):
+        k = int(g[f"{n}:k"])
+        got = orc.knn_dists(g[f"{n}:refs"], g[f"{n}:queries"], k)
+        np.testing.assert_allclose(got, g[f"{n}:knn"], rtol=2e-6, atol=2e-7)
+        assert got[0, 0] < 1e-6                                   # the planted duplicate
+        kv = g[f"{n}:val_knn"].shape[1]
+        np.testing.assert_allclose(orc.val_image_knn_dists(g[f"{n}:refs"], kv), g[f"{n}:val_knn"], rtol=2e-6, atol=2e-7)
