@@ -230,6 +230,50 @@ def main():
     np.savez_compressed(os.path.join(OUT, "knn_cases.npz"), **knn)
     print("wrote knn_cases.npz")
 
+    # ---------------- tokenizer (clip/simple_tokenizer.py; packing of clip/clip.py:207-224) ----------------
+    # ftfy is not installed: stubbed to the identity (exact for ASCII).  Every merge-table lookup that HIT during the
+    # run is recorded, so the fixture carries a sparse {pair: rank} table instead of OpenAI's 1.3 MB data file.
+    import json, sys, types
+    sys.modules.setdefault("ftfy", types.SimpleNamespace(fix_text=lambda t: t))
+    ref_tok_mod = _load("ref_tok", "clip/simple_tokenizer.py")
+    tok = ref_tok_mod.SimpleTokenizer(os.path.join(REF, "clip", "bpe_simple_vocab_16e6.txt.gz"))
+
+    class Recording(dict):
+        def __init__(self, d):
+            super().__init__(d)
+            self.hits = {}
+        def get(self, k, default=None):
+            v = super().get(k, default)
+            if v is not default and k in self:
+                self.hits[k] = v
+            return v
+        def __contains__(self, k):
+            return super().__contains__(k)
+    tok.bpe_ranks = Recording(tok.bpe_ranks)
+    names = ["accordion", "airplane", "anchor", "ant", "barrel", "bass", "beaver", "binocular", "bonsai", "brain",
+             "brontosaurus", "buddha", "butterfly", "camera", "cannon", "car_side", "ceiling_fan", "cellphone", "chair",
+             "chandelier", "cougar_body", "crab", "crayfish", "crocodile", "cup", "dalmatian", "dollar_bill", "dolphin",
+             "dragonfly", "electric_guitar", "elephant", "emu", "euphonium", "ewer", "ferry", "flamingo", "garfield",
+             "gerenuk", "gramophone", "grand_piano", "hawksbill", "headphone", "hedgehog", "helicopter", "ibis",
+             "inline_skate", "joshua_tree", "kangaroo", "ketch", "lamp", "laptop", "llama", "lobster", "lotus", "mandolin",
+             "mayfly", "menorah", "metronome", "minaret", "nautilus", "octopus", "okapi", "pagoda", "panda", "pigeon",
+             "pizza", "platypus", "pyramid", "revolver", "rhino", "rooster", "saxophone", "schooner", "scissors",
+             "scorpion", "sea_horse", "snoopy", "soccer_ball", "stapler", "starfish", "stegosaurus", "stop_sign",
+             "strawberry", "sunflower", "tick", "trilobite", "umbrella", "watch", "water_lilly", "wheelchair", "wild_cat",
+             "windsor_chair", "wrench", "yin_yang", "abyssinian", "american pit bull terrier", "boeing 737-800",
+             "crème brûlée", "annual crop land", "2012 tesla model s sedan", "bird's nest", "it's 3 o'clock &amp; fine"]
+    templates = ["a photo of a {}.", "a photo of a {}, a type of pet.", "{} texture.", "a centered satellite photo of {}.",
+                 "a photo of a person doing {}.", "X X X X {}.", "X X X X X X X X X X X X X X X X {}."]
+    prompts = [t.format(n.replace("_", " ")) for i, n in enumerate(names) for t in (templates[i % len(templates)], templates[0])]
+    sot, eot = tok.encoder["<|startoftext|>"], tok.encoder["<|endoftext|>"]
+    ids = [[sot] + tok.encode(p) + [eot] for p in prompts]
+    fixture = {"prompts": prompts, "ids": ids, "sot": sot, "eot": eot,
+               "merges": [[a, b, int(r)] for (a, b), r in sorted(tok.bpe_ranks.hits.items(), key=lambda kv: kv[1])],
+               "decoded": [tok.decode(i[1:-1]) for i in ids[:10]]}
+    with open(os.path.join(OUT, "tokenizer_cases.json"), "w") as f:
+        json.dump(fixture, f)
+    print("wrote tokenizer_cases.json:", len(prompts), "prompts,", len(fixture["merges"]), "merge ranks")
+
 
 if __name__ == "__main__":
     main()

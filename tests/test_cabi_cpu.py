@@ -128,3 +128,31 @@ def test_dac_fit_host():
         cal = DistanseAwareCalibration()
         cal.fit(g[f"{n}:base_zs"], g[f"{n}:cur_zs"], g[f"{n}:base_tuned"], g[f"{n}:cur_tuned"], int(g[f"{n}:k"]))
         np.testing.assert_allclose(cal.class_confidence, g[f"{n}:class_confidence"], rtol=1e-13)
+
+
+def test_tokenizer_matches_reference_fixture():
+    """SURVEY f-3: own BPE implementation vs ids produced by the reference SimpleTokenizer (sparse merge table)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from clip_calibration_amd.tokenizer import ClipTokenizer, coop_prompts, zeroshot_prompts
+    fx = json.load(open(os.path.join(GOLDEN, "tokenizer_cases.json")))
+    tok = ClipTokenizer(merges={(a, b): r for a, b, r in fx["merges"]})
+    assert (tok.sot, tok.eot) == (fx["sot"], fx["eot"]) == (49406, 49407)
+    for p, want in zip(fx["prompts"], fx["ids"]):
+        assert [tok.sot] + tok.encode(p) + [tok.eot] == want, p
+    packed = tok.tokenize(fx["prompts"][:20])
+    assert packed.shape == (20, 77) and packed.dtype == torch.int64
+    for row, want in zip(packed, fx["ids"][:20]):
+        assert row[: len(want)].tolist() == want and int(row[len(want):].sum()) == 0
+        assert int(row.argmax()) == len(want) - 1                     # EOT = max id (clip/model.py:611)
+    for i, text in enumerate(fx["decoded"]):
+        assert tok.decode(fx["ids"][i][1:-1]) == text
+    assert tok.encode("a photo of a accordion.") == [320, 1125, 539, 320, 48760, 269]   # SURVEY §8(c) known answer
+    with pytest.raises(RuntimeError):
+        tok.tokenize("accordion " * 80)
+    assert tok.tokenize("accordion " * 80, truncate=True)[0, -1] == tok.eot
+    assert zeroshot_prompts(["car_side"], "Caltech101") == ["a photo of a car side."]
+    assert coop_prompts(["car_side"], 4) == ["X X X X car side."]
+    with pytest.raises(FileNotFoundError):
+        ClipTokenizer(bpe_path="/nonexistent/bpe.txt.gz")
