@@ -36,6 +36,7 @@ struct KArgs {
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   half_t* x16; float* stats_out;
+  long long* stamps;   // diagnostic only (tools/gemm_stamps.py): per-workgroup s_memrealtime stamps, NULL in every real run
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,10 +364,16 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K / BK;
+  const bool stamp = a.stamps != nullptr && tid == 0;
+  if (stamp) {
+    a.stamps[blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[blockIdx.x * 8 + 5] = (long long)__smid();
+  }
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
+    if (stamp && kt == 0) a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* st = smem + (kt & 1) * T::STAGE;
 #pragma unroll
@@ -386,7 +393,13 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     }
   }
 
+  if (stamp) a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
   epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+  if (a.stamps != nullptr) {
+    if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp) a.stamps[blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // n-tiles per traversal band.  Measured (profiles/r01_gemm_band_sweep.txt): 4 is best or tied on every tower
@@ -545,6 +558,8 @@ template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs a) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
   constexpr int ROWB = T::WTN * 2 + 16;
+  constexpr bool PATCH_ALIASED = T::SMEM + T::NW * 16 * ROWB > 160 * 1024;
+  static_assert(T::NW * 16 * ROWB <= T::STAGE, "epilogue patches must fit one stage buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -647,7 +662,15 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     }
     if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
       if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {
-        epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB));
+        if constexpr (PATCH_ALIASED) {
+          // 16-wave tile: no LDS left behind the stage buffers -> the patches live in the stage buffer of the last
+          // K-step (the prefetch above went to the other one).  Everyone must be done reading it first; the barrier
+          // at the top of the next tile's first K-step keeps stage(.., 1) out of it until every epilogue has finished.
+          __syncthreads();
+          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + last_buf * T::STAGE + wave * (16 * ROWB));
+        } else {
+          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB));
+        }
       } else {
         epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
       }
@@ -660,7 +683,8 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
 
 template <typename T, int EPI, bool OUT_F32>
 int launch_persist(KArgs k, hipStream_t s) {
-  constexpr int SMEM = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
+  constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
+  constexpr int SMEM = SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP;
   static bool attr_set = false;
   static int n_cu = 0;
   auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
@@ -861,6 +885,7 @@ int pick_variant(const KArgs& k) {
   const char* e = getenv("CLIPMI_GEMM_VARIANT");
   if (e && e[0] >= '0' && e[0] <= '9') return e[0] - '0';
   if (e && e[0] == 'a') return 10;
+  if (e && e[0] == 'b') return 11;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
@@ -873,6 +898,11 @@ int pick_variant(const KArgs& k) {
     const double cost = (double)rounds * c.bm * c.bn * c.per_cu * c.penalty;
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
+  // CLIPMI_GEMM_PERSIST=1: use the persistent form of (1) (variant b: next tile's first stage prefetched before the
+  // epilogue, no workgroup relaunch gap) for multi-round problems.  Isolated A/B: +4.5 % on qkv, neutral on fc; inside the
+  // tower it measures 1 % slower (20.33 vs 20.55 k img/s, three alternating runs), so it stays opt-in.
+  const char* ps = getenv("CLIPMI_GEMM_PERSIST");
+  if (best == 1 && ps && ps[0] == '1' && (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)cus) best = 11;
   return best;
 }
 
@@ -881,6 +911,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
   int variant = pick_variant(k);
   if (k.x16) {   // producer fold: needs the non-persistent epilogue and at most LN_MAX_PARTS column tiles
     if (variant == 9) variant = 2;
+    if (variant == 11) variant = 1;
     const int bn = (variant == 0) ? 128 : (variant == 3 || variant == 7) ? 128 : 256;
     if ((k.N + bn - 1) / bn > LN_MAX_PARTS) variant = 1;
     CLIPMI_REQUIRE((k.N + 255) / 256 <= LN_MAX_PARTS, CLIPMI_ERR_SHAPE, "gemm: N=%d has too many column tiles for the LayerNorm fold", k.N);
@@ -898,6 +929,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
     case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
+    case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s);
     default: return launch_tile<T128, EPI, OUT_F32>(k, s);
   }
 }
@@ -924,6 +956,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
   k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
+  {
+    const char* e = getenv("CLIPMI_GEMM_STAMPS_PTR");   // tuning aid: device buffer of 8 int64 per workgroup
+    k.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr;
+  }
   CLIPMI_REQUIRE(!a.ln_stats || (a.ln_g && a.ln_dim > 0 && a.ln_parts >= 1 && a.ln_parts <= LN_MAX_PARTS &&
                                  (a.epilogue == CLIPMI_EPI_BIAS || a.epilogue == CLIPMI_EPI_BIAS_QUICKGELU)),
                  CLIPMI_ERR_ARG, "gemm: LayerNorm fold needs ln_g, ln_dim, 1..%d partials and a BIAS / BIAS_QUICKGELU epilogue", LN_MAX_PARTS);
