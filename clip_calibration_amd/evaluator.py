@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
-from .metrics import ece_from_bins
+from .metrics import ece_from_bins, mce_from_bins
 
 
 class DeviceCalibrationEvaluator:
@@ -35,5 +35,6 @@ class DeviceCalibrationEvaluator:
         res["error_rate"] = 100.0 - res["accuracy"]
         res["confidence"] = b[1].sum() / total
         res["ece"] = 100.0 * ece_from_bins(b, self.n_bins)
+        res["mce"] = 100.0 * mce_from_bins(b, self.n_bins)
         res["total"] = int(total)
         return res

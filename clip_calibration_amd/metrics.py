@@ -46,3 +46,21 @@ def ece_from_bins(bins: np.ndarray, n_bins: int = 10) -> float:
 
 def ECE(conf, pred, gt, conf_bin_num: int = 10) -> float:
     return ece_from_bins(bin_statistics(conf, pred, gt, conf_bin_num), conf_bin_num)
+
+
+def mce_from_bins(bins: np.ndarray, n_bins: int = 10) -> float:
+    """The reference's "MCE" (tools/metrics.py:181-208): bins from digitize(conf, linspace(0,1,n+1)[1:-1]) -- so conf == 1.0
+    belongs to the last bin and DOES enter its means -- and the per-bin gap weighted by the bin's share:
+    max_b |mean acc_b - mean conf_b| * count_b / N  =  max_b |sum_correct_b - sum_conf_b| / N."""
+    b = np.asarray(bins, dtype=np.float64).reshape(3, n_bins + 1).copy()
+    b[:, n_bins - 1] += b[:, n_bins]
+    b = b[:, :n_bins]
+    total = b[0].sum()
+    if total == 0:
+        return float("nan")
+    nz = b[0] > 0
+    return float(np.max(np.abs(b[2][nz] - b[1][nz])) / total)
+
+
+def MCE(conf, pred, gt, conf_bin_num: int = 10) -> float:
+    return mce_from_bins(bin_statistics(conf, pred, gt, conf_bin_num), conf_bin_num)

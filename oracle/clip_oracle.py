@@ -264,6 +264,19 @@ def ece(conf: np.ndarray, pred: np.ndarray, gt: np.ndarray, n_bins: int = 10) ->
     return float(np.sum(weights * np.abs(avg - acc)))
 
 
+def mce(conf: np.ndarray, pred: np.ndarray, gt: np.ndarray, n_bins: int = 10) -> float:
+    """tools/metrics.py:181-208 (the reference's weighted "maximal" calibration error): bins =
+    digitize(conf, linspace(0,1,n+1)[1:-1]); max over non-empty bins of |mean correct - mean conf| * count / N."""
+    conf = np.asarray(conf, dtype=np.float64)
+    correct = (np.asarray(pred) == np.asarray(gt)).astype(np.float64)
+    which = np.digitize(conf, np.linspace(0, 1, n_bins + 1)[1:-1])
+    best = 0.0
+    for b in np.unique(which):
+        sel = which == b
+        best = max(best, abs(correct[sel].mean() - conf[sel].mean()) * sel.sum() / len(conf))
+    return float(best)
+
+
 def knn_dists(val_base_class_features: np.ndarray, image_features_cur: np.ndarray, k: int) -> np.ndarray:
     """get_knn_dists (trainers/calibration/proximity.py:19-46): per query, the k smallest L2 distances to the reference
     rows, ascending (fp32, like the torch tensors the reference builds)."""

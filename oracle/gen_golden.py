@@ -164,6 +164,7 @@ def main():
         cases[f"{name}:gt"] = gt
         cases[f"{name}:bins"] = np.int64(bins)
         cases[f"{name}:ece"] = np.float64(ref_metrics.ECE(conf, pred, gt, bins))
+        cases[f"{name}:mce"] = np.float64(ref_metrics.MCE(conf, pred, gt, bins))
     n = 2000
     conf = rng.uniform(0.05, 1.0, n)
     pred = rng.integers(0, 50, n)

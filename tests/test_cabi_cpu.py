@@ -102,6 +102,7 @@ def test_host_ece_matches_reference_goldens():
         # float32 confidences: the reference's np.mean accumulates in float32, this module in float64
         tol = 1e-12 if conf.dtype == np.float64 else 2e-7
         assert metrics.ECE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:ece"]), abs=tol), n
+        assert metrics.MCE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:mce"]), abs=tol), n
         which = metrics.digitize_bins(conf, bins)
         assert np.array_equal(which, np.digitize(conf, np.linspace(0, 1, bins + 1)) - 1)
 

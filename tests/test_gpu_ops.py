@@ -213,6 +213,7 @@ def test_ece_device_accumulation(ops):
         res = ev.evaluate()
         assert res["ece"] / 100.0 == pytest.approx(want, abs=1e-6), n
         assert res["total"] == len(conf)
+        assert res["mce"] / 100.0 == pytest.approx(orc.mce(conf32, pred, gt, bins), abs=1e-6), n
         assert ECE(conf32, pred, gt, bins) == pytest.approx(want, abs=1e-6)
 
 

@@ -117,6 +117,9 @@ def test_ece_cases():
     for n in names:
         got = orc.ece(g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], int(g[f"{n}:bins"]))
         assert got == pytest.approx(float(g[f"{n}:ece"]), abs=1e-15), n
+        # float32 confidences: pandas (the reference) averages them in float32, the oracle in float64
+        mtol = 1e-12 if g[f"{n}:conf"].dtype == np.float64 else 2e-7
+        assert orc.mce(g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], int(g[f"{n}:bins"])) == pytest.approx(float(g[f"{n}:mce"]), abs=mtol), n
 
 
 def test_dac_cases():
