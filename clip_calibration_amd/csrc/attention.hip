@@ -66,7 +66,8 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
             const f16x8 kf = *reinterpret_cast<const f16x8*>(kread[ks] + kt * 4096);
             s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
           }
-          const bool partial = DENSE == 1 ? (kt == NKT - 1) : (DENSE == 2 ? true : ((k_lo + 32 > L) || (causal && k_lo + 31 > q0)));   // wave-uniform
+          // DENSE == 3: a key block that lies entirely inside the sequence (multi-block sequences): nothing to mask
+          const bool partial = DENSE == 3 ? false : DENSE == 1 ? (kt == NKT - 1) : (DENSE == 2 ? true : ((k_lo + 32 > L) || (causal && k_lo + 31 > q0)));   // wave-uniform
           if (partial) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
     __syncthreads();
 
     if (active) {
-      attend_block<NKT, GROUP, TR>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      if (!causal && kb0 + KEYS <= L)   // block-uniform: full block -> straight-line code
+        attend_block<NKT, GROUP, TR, 3>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      else
+        attend_block<NKT, GROUP, TR, 0>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
     }
   }
 

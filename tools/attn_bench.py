@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clip_calibration_amd import ops
 from gemm_bench import timeit
 
-for name, n, l, h, causal in [("vision B=256", 256, 197, 12, False), ("text C=1000", 1000, 77, 8, True)]:
+for name, n, l, h, causal in [("vision B=256", 256, 197, 12, False), ("text C=1000", 1000, 77, 8, True), ("ViT-L@336 B=64", 64, 577, 16, False), ("ViT-L B=64", 64, 257, 16, False)]:
     qkv = torch.randn(n * l, 3 * 64 * h, device="cuda").half()
     row = [f"{name:14s}"]
     for np_ in ("0", "1"):
