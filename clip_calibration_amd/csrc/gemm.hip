@@ -616,12 +616,17 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
   int first_buf = 0;
   stage(xrs, wrs, first_buf, 0);
 
+  const bool stamp = a.stamps != nullptr && tid == 0;
   while (true) {
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stamp) {
+      a.stamps[vb * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = (first_buf + kt) & 1;
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       // epilogue stores; vmcnt(0) also drains those -- they were issued a full prefetch latency ago
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (stamp && kt == 0) a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
       const char* st = smem + buf * T::STAGE;
 #pragma unroll
@@ -649,6 +655,8 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     }
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cn0 = n0;
+    const int cvb = vb;
+    if (stamp) a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < a.nwg;
     if (has_next) {
@@ -677,6 +685,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     } else {
       epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
     }
+    if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
     if (!has_next) break;
   }
 }

@@ -273,6 +273,45 @@ def test_layernorm_fold_path(monkeypatch, gname):
     assert np.abs(_cos(a.cpu().numpy(), c.cpu().numpy()) - _cos(c.cpu().numpy(), c.cpu().numpy())).max() < 5e-4
 
 
+def test_kgcoop_mirror_and_reference_style_zeroshot():
+    """KgCoOp eval forward (kgcoop.py:246-259: CoOp with ctx taken from the embedding of "a photo of a", n_ctx = 4) and the
+    reference's own ZeroshotCLIP.model_inference statements (zsclip.py:97-102) executed on the attribute surface."""
+    from clip_calibration_amd.trainers import KgCoOpCLIP
+    sd, model = _build("tiny")
+    C = 6
+    ids_ctx = syn.synthetic_token_ids(C, "tiny", seed=4, n_ctx_placeholders=4)
+    ids_zs = syn.synthetic_token_ids(C, "tiny", seed=4)
+    init = syn.synthetic_token_ids(1, "tiny", seed=4)            # [SOT, a, photo, of, a, ...]: ctx = embeddings 1..4
+    kg = KgCoOpCLIP(model, ids_ctx, zeroshot_tokenized_prompts=ids_zs, ctx_init_ids=init[:, :6])
+    images = syn.synthetic_images(3, "tiny", seed=4)
+    logits, imf, txf = kg(images.cuda())
+    ctx = sd["token_embedding.weight"][init[0, 1:5]].half().float()
+    with torch.no_grad():
+        tf_ref = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_ctx, ctx), ids_ctx))
+        lg_ref, _, _ = orc.clip_logits(orc.encode_image(sd, images), tf_ref, sd["logit_scale"].exp())
+        zs_ref = orc.l2_normalize(orc.encode_text(sd, ids_zs))
+    assert np.abs(logits.cpu().numpy() - lg_ref.numpy()).max() < 100 * COS_TOL
+    assert np.abs(kg.ori_embedding.cpu().numpy() @ zs_ref.numpy().T - (zs_ref @ zs_ref.t()).numpy()).max() < COS_TOL
+    # zsclip.py:97-102 verbatim, fp16 tensors as the reference would hold them
+    clip_model = model
+    text_features = clip_model.encode_text(ids_zs.cuda())
+    text_features = text_features / text_features.norm(dim=-1, keepdim=True)
+    image = images.cuda()
+    image_features = clip_model.encode_image(image)
+    image_features = image_features / image_features.norm(dim=-1, keepdim=True)
+    logit_scale = clip_model.logit_scale.exp()
+    lg = logit_scale * image_features @ text_features.t()
+    with torch.no_grad():
+        want, _, _ = orc.clip_logits(orc.encode_image(sd, images), orc.encode_text(sd, ids_zs), sd["logit_scale"].exp())
+    assert lg.dtype == torch.float16
+    assert np.abs(lg.float().detach().cpu().numpy() - want.numpy()).max() < 0.25   # fp16 end to end at scale 100: the reference's own noise floor
+    # ln_final on a non-contiguous view and a 2-D input
+    x = torch.randn(4, 77, 128, device="cuda").half().permute(1, 0, 2)
+    y = clip_model.ln_final(x)
+    ref = orc.layer_norm(x.float().cpu(), sd["ln_final.weight"], sd["ln_final.bias"])
+    assert y.shape == x.shape and np.abs(y.float().cpu().numpy() - ref.numpy()).max() < 5e-3
+
+
 def test_stress_residual_magnitudes():
     """Scaled-up residual branches (real CLIP has large outlier channels): still finite and within tolerance."""
     from clip_calibration_amd.model import build_model
