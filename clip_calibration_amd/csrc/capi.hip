@@ -261,6 +261,10 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
+int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
+                        clipmi_stream_t stream) {
+  return launch_softmax_rows(logits, dac_conf, probs, conf, pred, B, C, (hipStream_t)stream);
+}
 
 int clipmi_knn_dists(const float* queries, const float* refs, float* out, int Nq, int Nr, int E, int K, clipmi_stream_t stream) {
   return launch_knn(queries, refs, out, Nq, Nr, E, K, (hipStream_t)stream);

@@ -95,6 +95,8 @@ int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int 
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,
                   float* conf, int32_t* pred, int B, int C, int E, hipStream_t s);
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
+int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
+                        hipStream_t s);
 int launch_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins,
                           int n_bins, hipStream_t s);
 

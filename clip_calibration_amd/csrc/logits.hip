@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
 }
 
 // One wave per image row.
-__global__ __launch_bounds__(256) void row_calibrate_kernel(float* __restrict__ logits, const float* __restrict__ dac,
-                                                            float* __restrict__ conf, int32_t* __restrict__ pred, int B, int C) {
+// probs == nullptr: DAC scales the row in place (predict of distanse_aware_calibration.py); probs != nullptr: the row is
+// left alone and softmax(row * f) is written to probs (which may be the same buffer).  No __restrict__ on these two.
+__global__ __launch_bounds__(256) void row_calibrate_kernel(float* logits, const float* __restrict__ dac,
+                                                            float* __restrict__ conf, int32_t* __restrict__ pred, int B, int C,
+                                                            float* probs) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -81,11 +84,16 @@ __global__ __launch_bounds__(256) void row_calibrate_kernel(float* __restrict__ 
   float se = 0.f;
   for (int c = lane; c < C; c += 64) {
     const float v = lr[c] * f;
-    if (dac) lr[c] = v;
+    if (dac && !probs) lr[c] = v;
     se += __expf(v - mx);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  if (probs) {
+    float* pr = probs + (int64_t)row * C;
+    const float inv = 1.0f / se;
+    for (int c = lane; c < C; c += 64) pr[c] = __expf(lr[c] * f - mx) * inv;   // same lane reads then writes element c
+  }
   if (lane == 0) {
     if (conf) conf[row] = 1.0f / se;
     if (pred) pred[row] = bi;
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(256) void ece_accumulate_kernel(const float* __rest
 
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits, float* conf,
                   int32_t* pred, int B, int C, int E, hipStream_t s) {
-  CLIPMI_REQUIRE(img_n && txt_n && logits, CLIPMI_ERR_ARG, "logits: null pointer (img_n, txt_n and logits are required)");
   if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(img_n && txt_n && logits, CLIPMI_ERR_ARG, "logits: null pointer (img_n, txt_n and logits are required)");
   CLIPMI_REQUIRE(B > 0 && C > 0 && E > 0 && E % 16 == 0, CLIPMI_ERR_SHAPE, "logits: B=%d C=%d E=%d unsupported (E %% 16 == 0)", B, C, E);
   CLIPMI_REQUIRE((uintptr_t)img_n % 16 == 0 && (uintptr_t)txt_n % 16 == 0, CLIPMI_ERR_ARG, "logits: features must be 16-byte aligned");
   hipLaunchKernelGGL(cosine_logits_kernel, dim3((B + 15) / 16, (C + 255) / 256), dim3(256), 0, s, img_n, txt_n, scale, logits, B, C, E);
@@ -134,10 +142,19 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
 }
 
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s) {
-  CLIPMI_REQUIRE(logits, CLIPMI_ERR_ARG, "calibrate_rows: null logits");
   if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(logits, CLIPMI_ERR_ARG, "calibrate_rows: null logits");
   CLIPMI_REQUIRE(B > 0 && C > 0, CLIPMI_ERR_SHAPE, "calibrate_rows: B=%d C=%d", B, C);
-  hipLaunchKernelGGL(row_calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, dac_conf, conf, pred, B, C);
+  hipLaunchKernelGGL(row_calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, dac_conf, conf, pred, B, C, (float*)nullptr);
+  return check_launch("row_calibrate_kernel");
+}
+
+int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
+                        hipStream_t s) {
+  if (B == 0) return CLIPMI_OK;   // an empty batch has no storage to point at
+  CLIPMI_REQUIRE(logits && probs, CLIPMI_ERR_ARG, "softmax_rows: null pointer (logits and probs are required)");
+  CLIPMI_REQUIRE(B > 0 && C > 0, CLIPMI_ERR_SHAPE, "softmax_rows: B=%d C=%d", B, C);
+  hipLaunchKernelGGL(row_calibrate_kernel, dim3((B + 3) / 4), dim3(256), 0, s, const_cast<float*>(logits), dac_conf, conf, pred, B, C, probs);
   return check_launch("row_calibrate_kernel");
 }
 

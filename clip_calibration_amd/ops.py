@@ -135,6 +135,24 @@ def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_con
     return logits, conf, pred
 
 
+def softmax_rows(logits: torch.Tensor, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):
+    """probs = softmax(logits * dac_conf[argmax]) row-wise (vl_calibrator.py:83-109, DAC / plain branches); logits untouched."""
+    logits = _dev(logits, "logits", (torch.float32,))
+    B, Cn = logits.shape
+    dac_conf, pd = _opt(dac_conf, "dac_conf", (torch.float32,))
+    if dac_conf is not None and dac_conf.numel() != Cn:
+        raise ValueError("softmax_rows: dac_conf must have one entry per class")
+    probs = torch.empty_like(logits)
+    conf = pred = None
+    pc = pp = None
+    if want_conf_pred:
+        conf = torch.empty(B, dtype=torch.float32, device=logits.device)
+        pred = torch.empty(B, dtype=torch.int32, device=logits.device)
+        pc, pp = conf.data_ptr(), pred.data_ptr()
+    check(lib.clipmi_softmax_rows(logits.data_ptr(), pd, probs.data_ptr(), pc, pp, B, Cn, _stream()), "clipmi_softmax_rows")
+    return (probs, conf, pred) if want_conf_pred else probs
+
+
 def ece_accumulate(conf: torch.Tensor, pred: torch.Tensor, labels: torch.Tensor, bins: torch.Tensor, n_bins: int) -> None:
     conf = _dev(conf, "conf", (torch.float32,))
     pred = _dev(pred, "pred", (torch.int32,))

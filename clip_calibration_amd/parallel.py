@@ -57,3 +57,32 @@ def merge_ece_bins(bins: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)
     return bins
+
+
+def all_gather_varlen(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate per-rank tensors whose dim-0 lengths differ (rank-major): lengths are exchanged first, shards padded to
+    the longest, one all-gather, padding stripped."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(x.item()) for x in lens]
+    width = max(lens)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    gathered = all_gather_embeddings(pad, group)
+    return torch.cat([gathered[r * width: r * width + lens[r]] for r in range(world)], dim=0)
+
+
+def gather_samples(evaluator, proximity=None, group=None):
+    """End-of-evaluation merge for a sharded test split: sums the bin accumulators and replaces the evaluator's kept
+    (conf, pred, gt) vectors by the all-rank concatenation, so that ``evaluate`` returns identical numbers on every rank.
+    Returns the gathered proximity vector (or None)."""
+    merge_ece_bins(evaluator.bins, group)
+    if evaluator.keep_samples and evaluator._conf:
+        evaluator._conf = [all_gather_varlen(torch.cat(evaluator._conf), group)]
+        evaluator._pred = [all_gather_varlen(torch.cat(evaluator._pred), group)]
+        evaluator._gt = [all_gather_varlen(torch.cat(evaluator._gt), group)]
+    return None if proximity is None else all_gather_varlen(proximity, group)

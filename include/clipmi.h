@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 2
+#define CLIPMI_ABI_VERSION 3
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -101,6 +101,13 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
  * multiplied in place by dac_conf[pred]; conf[i] = max_c softmax(row).  conf / pred may be NULL. */
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C,
                           clipmi_stream_t stream);
+
+/* VLCalibration.predict on its DAC / plain branches (trainers/calibration/vl_calibrator.py:83-109): probs[i,:] =
+ * softmax(logits[i,:] * (dac_conf ? dac_conf[argmax_i] : 1)), the full probability matrix the reference hands to
+ * VLClassification.evaluate (vl_evaluator.py:59).  logits fp32 [B,C] are NOT modified; probs fp32 [B,C] (required, may
+ * alias logits); conf / pred as above, may be NULL. */
+int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred,
+                        int B, int C, clipmi_stream_t stream);
 
 /* Device-side accumulation of the ECE statistics (tools/metrics.py:90-130) -- SURVEY f-1.  bins: float64
  * [3*(n_bins+1)] = per-bin (count, sum_conf, sum_correct), bin n_bins collects conf == 1.0 (the digitize

@@ -277,6 +277,62 @@ def mce(conf: np.ndarray, pred: np.ndarray, gt: np.ndarray, n_bins: int = 10) ->
     return float(best)
 
 
+def quantile_bins(x: np.ndarray, n_bins: int) -> np.ndarray:
+    """sklearn KBinsDiscretizer(n_bins, encode='ordinal', strategy='quantile').fit_transform as the reference calls it
+    (tools/metrics.py:152, 228; sklearn is a third-party dependency, unpinned in requirements.txt, 1.7.2 in this image):
+    edges = np.percentile(x, linspace(0, 100, n+1)) with linear interpolation; an edge within 1e-8 of its predecessor is
+    removed; the ordinal code is searchsorted(inner edges, x, side='right'); a constant column maps to 0."""
+    x = np.asarray(x)
+    x = x if x.dtype in (np.float32, np.float64) else x.astype(np.float64)
+    if x.min() == x.max():
+        return np.zeros(len(x), dtype=np.int64)
+    edges = [float(e) for e in np.percentile(x, np.linspace(0, 100, n_bins + 1))]
+    kept = [edges[0]]
+    for prev, e in zip(edges[:-1], edges[1:]):
+        if e - prev > 1e-8:
+            kept.append(e)
+    inner = np.array(kept[1:-1], dtype=np.float64)
+    return np.array([int(np.sum(inner <= v)) for v in x], dtype=np.int64)
+
+
+def _group_gap(keys: List, conf: np.ndarray, correct: np.ndarray) -> float:
+    """sum_g |mean(correct_g) - mean(conf_g)| * |g| / N over the distinct keys (the pandas groupby of metrics.py:159-162)."""
+    total = 0.0
+    for key in set(keys):
+        sel = np.array([k == key for k in keys])
+        total += abs(correct[sel].mean() - conf[sel].mean()) * sel.sum() / len(conf)
+    return float(total)
+
+
+def ace(conf: np.ndarray, pred: np.ndarray, gt: np.ndarray, n_bins: int = 10) -> float:
+    """AdaptiveECE, tools/metrics.py:212-236: equal-mass bins of the confidence."""
+    conf = np.asarray(conf)
+    correct = (np.asarray(pred) == np.asarray(gt)).astype(np.float64)
+    return _group_gap(list(quantile_bins(conf, n_bins)), conf.astype(np.float64), correct)
+
+
+def piece(conf: np.ndarray, proximity: np.ndarray, pred: np.ndarray, gt: np.ndarray, dist_bins: int = 10, conf_bins: int = 10) -> float:
+    """PIECE, tools/metrics.py:132-178: groups = (quantile bin of the proximity, digitize(conf, linspace(0,1,n+1)[1:-1]))."""
+    conf = np.asarray(conf)
+    correct = (np.asarray(pred) == np.asarray(gt)).astype(np.float64)
+    kb = quantile_bins(np.asarray(proximity), dist_bins)
+    cb = np.digitize(conf, np.linspace(0, 1, conf_bins + 1)[1:-1])
+    return _group_gap(list(zip(kb.tolist(), cb.tolist())), conf.astype(np.float64), correct)
+
+
+def macro_f1(pred: np.ndarray, gt: np.ndarray) -> float:
+    """sklearn f1_score(labels, preds, average='macro', labels=np.unique(labels)) (vl_evaluator.py:77-82): the plain mean
+    over classes present in gt of 2tp / (2tp + fp + fn), 0 where that denominator is 0."""
+    pred, gt = np.asarray(pred), np.asarray(gt)
+    scores = []
+    for c in np.unique(gt):
+        tp = np.sum((pred == c) & (gt == c))
+        fp = np.sum((pred == c) & (gt != c))
+        fn = np.sum((pred != c) & (gt == c))
+        scores.append(2 * tp / (2 * tp + fp + fn) if (2 * tp + fp + fn) > 0 else 0.0)
+    return float(np.mean(scores))
+
+
 def knn_dists(val_base_class_features: np.ndarray, image_features_cur: np.ndarray, k: int) -> np.ndarray:
     """get_knn_dists (trainers/calibration/proximity.py:19-46): per query, the k smallest L2 distances to the reference
     rows, ascending (fp32, like the torch tensors the reference builds)."""

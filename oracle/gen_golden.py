@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import importlib.util
 import os
+import warnings
 import sys
 
 import numpy as np
@@ -86,6 +87,7 @@ def ref_forward(ref_model, geom_name, seed, n_img, n_cls, capture=False):
 
 
 def main():
+    from sklearn.metrics import f1_score
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref_model = _load("ref_model", "clip/model.py")
@@ -165,6 +167,13 @@ def main():
         cases[f"{name}:bins"] = np.int64(bins)
         cases[f"{name}:ece"] = np.float64(ref_metrics.ECE(conf, pred, gt, bins))
         cases[f"{name}:mce"] = np.float64(ref_metrics.MCE(conf, pred, gt, bins))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")            # sklearn: quantile_method FutureWarning, constant-feature warning
+            cases[f"{name}:ace"] = np.float64(ref_metrics.AdaptiveECE(conf, pred, gt, bins))
+            prox = np.exp(-np.abs(np.random.default_rng(len(conf)).normal(0.8, 0.2, len(conf))))
+            cases[f"{name}:prox"] = prox
+            cases[f"{name}:piece"] = np.float64(ref_metrics.PIECE(conf, prox, pred, gt, 10, bins))
+            cases[f"{name}:f1"] = np.float64(f1_score(gt, pred, average="macro", labels=np.unique(gt)))
     n = 2000
     conf = rng.uniform(0.05, 1.0, n)
     pred = rng.integers(0, 50, n)

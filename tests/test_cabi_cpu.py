@@ -103,6 +103,9 @@ def test_host_ece_matches_reference_goldens():
         tol = 1e-12 if conf.dtype == np.float64 else 2e-7
         assert metrics.ECE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:ece"]), abs=tol), n
         assert metrics.MCE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:mce"]), abs=tol), n
+        assert metrics.AdaptiveECE(conf, pred, gt, bins) == pytest.approx(float(g[f"{n}:ace"]), abs=tol), n
+        assert metrics.PIECE(conf, g[f"{n}:prox"], pred, gt, 10, bins) == pytest.approx(float(g[f"{n}:piece"]), abs=tol), n
+        assert metrics.macro_f1(pred, gt) == pytest.approx(float(g[f"{n}:f1"]), abs=1e-12), n
         which = metrics.digitize_bins(conf, bins)
         assert np.array_equal(which, np.digitize(conf, np.linspace(0, 1, bins + 1)) - 1)
 
@@ -157,3 +160,55 @@ def test_tokenizer_matches_reference_fixture():
     assert coop_prompts(["car_side"], 4) == ["X X X X car side."]
     with pytest.raises(FileNotFoundError):
         ClipTokenizer(bpe_path="/nonexistent/bpe.txt.gz")
+
+
+def test_checkpoint_and_base_feature_formats(tmp_path):
+    """f-3: Dassl prompt-learner checkpoint layout (coop.py:311-343) and the base_features.pt dict (base_learner.py:184-239)."""
+    import torch.nn as nn
+    from clip_calibration_amd import checkpoint as ck
+
+    class PL(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ctx = nn.Parameter(torch.zeros(4, 8))
+            self.register_buffer("token_prefix", torch.zeros(3, 1, 8))
+            self.register_buffer("token_suffix", torch.zeros(3, 5, 8))
+    src = PL()
+    with torch.no_grad():
+        src.ctx.copy_(torch.randn(4, 8))
+        src.token_prefix.fill_(7.0)                       # a DIFFERENT class list's fixed tokens: must not be loaded
+    path = ck.save_checkpoint(src.state_dict(), str(tmp_path), "prompt_learner", 50, val_result=12.5)
+    assert path.endswith("prompt_learner/model.pth.tar-50") and (tmp_path / "prompt_learner" / "checkpoint").read_text().strip() == "model.pth.tar-50"
+    dst = PL()
+    assert ck.load_model(dst, str(tmp_path), "prompt_learner", epoch=50) == 50
+    assert torch.equal(dst.ctx, src.ctx) and float(dst.token_prefix.abs().sum()) == 0.0
+    with pytest.raises(FileNotFoundError):
+        ck.load_model(dst, str(tmp_path), "prompt_learner")          # no model-best.pth.tar written
+    p = ck.base_features_path(str(tmp_path / "temp"), "Caltech101", "CoOp", 16, "ViT-B/16", 1)
+    assert p.endswith("Caltech101/CoOp/shots16/ViT-B/16/base/seed1/base_features.pt")
+    rng = np.random.default_rng(0)
+    d = dict(val_logits=rng.normal(size=(6, 3)).astype(np.float32), val_image_features=rng.normal(size=(6, 8)).astype(np.float32),
+             val_text_features=rng.normal(size=(3, 8)).astype(np.float32), val_labels=rng.integers(0, 3, 6),
+             val_image_knn_dists=rng.uniform(size=(6, 2)).astype(np.float32))
+    ck.save_base_features(p, **d)
+    back = ck.load_base_features(p)
+    assert set(back) == set(ck.BASE_FEATURE_KEYS) and all(np.array_equal(back[k], d[k]) for k in d)
+    torch.save({"val_logits": d["val_logits"]}, p)
+    with pytest.raises(KeyError):
+        ck.load_base_features(p)
+
+
+def test_quantile_bins_match_sklearn():
+    """metrics.quantile_bin_index restates sklearn's KBinsDiscretizer(quantile, ordinal) -- checked live where sklearn exists."""
+    sk = pytest.importorskip("sklearn.preprocessing")
+    import warnings
+    rng = np.random.default_rng(3)
+    cases = [rng.uniform(size=500), rng.uniform(size=37).astype(np.float32), np.round(rng.uniform(size=400), 1),   # heavy ties
+             np.concatenate([np.ones(90), rng.uniform(size=10)]), np.full(12, 0.5), np.array([0.2, 0.9])]
+    for x in cases:
+        for nb in (3, 10, 15):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = sk.KBinsDiscretizer(n_bins=nb, encode="ordinal", strategy="quantile").fit_transform(x[:, None])[:, 0]
+            assert np.array_equal(metrics.quantile_bin_index(x, nb), want.astype(np.int64))
+            assert np.array_equal(orc.quantile_bins(x, nb), want.astype(np.int64))

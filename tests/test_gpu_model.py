@@ -312,6 +312,88 @@ def test_kgcoop_mirror_and_reference_style_zeroshot():
     assert y.shape == x.shape and np.abs(y.float().cpu().numpy() - ref.numpy()).max() < 5e-3
 
 
+def test_runner_base_to_new_calibration_flow(tmp_path):
+    """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
+    -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of
+    base_learner.py:59-152 / vl_calibrator.py:83-109 / vl_evaluator.py:59-102."""
+    from clip_calibration_amd import checkpoint as ck, metrics, runner
+    from clip_calibration_amd.calibrator import VLCalibration
+    from clip_calibration_amd.trainers import CoOpCLIP, ZeroshotCLIP
+    sd, model = _build("tiny")
+    C, n_ctx, K = 12, 4, 3
+    ids_zs_b, ids_zs_n = syn.synthetic_token_ids(C, "tiny", seed=20), syn.synthetic_token_ids(C, "tiny", seed=21)
+    ids_cp_b = syn.synthetic_token_ids(C, "tiny", seed=20, n_ctx_placeholders=n_ctx)
+    ids_cp_n = syn.synthetic_token_ids(C, "tiny", seed=21, n_ctx_placeholders=n_ctx)
+    coop_b = CoOpCLIP(model, ids_cp_b, n_ctx=n_ctx, seed=2)
+    coop_n = CoOpCLIP(model, ids_cp_n, n_ctx=n_ctx, seed=2)
+    # f-3: the tuned context travels through a Dassl-style checkpoint
+    ck.save_checkpoint(coop_b.prompt_learner.state_dict(), str(tmp_path), "prompt_learner", 50)
+    with torch.no_grad():
+        coop_n.prompt_learner.ctx.zero_()
+    assert ck.load_model(coop_n.prompt_learner, str(tmp_path), "prompt_learner", epoch=50) == 50
+    assert torch.equal(coop_n.prompt_learner.ctx, coop_b.prompt_learner.ctx)
+    ctx = coop_n.prompt_learner.ctx.detach().float().cpu()
+    zs_b, zs_n = ZeroshotCLIP(model, ids_zs_b), ZeroshotCLIP(model, ids_zs_n)
+
+    val_images = syn.synthetic_images(20, "tiny", seed=30)
+    test_images = syn.synthetic_images(37, "tiny", seed=31)
+    with torch.no_grad():
+        r_val_f, r_test_f = orc.encode_image(sd, val_images), orc.encode_image(sd, test_images)
+        r_tb = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_cp_b, ctx), ids_cp_b))
+        r_tn = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_cp_n, ctx), ids_cp_n))
+        r_zb, r_zn = orc.l2_normalize(orc.encode_text(sd, ids_zs_b)), orc.l2_normalize(orc.encode_text(sd, ids_zs_n))
+        scale = sd["logit_scale"].exp()
+        r_val_logits, r_val_n, _ = orc.clip_logits(r_val_f, r_tb, scale)
+        r_test_logits, r_test_n, _ = orc.clip_logits(r_test_f, r_tn, scale)
+    val_labels = syn.synthetic_labels(r_val_logits.argmax(1), C, seed=2)
+    loader = lambda im, lb, bs: [(im[i:i + bs], lb[i:i + bs]) for i in range(0, len(im), bs)]
+
+    # save_base_val_features for the tuned and the zero-shot model, through the file format
+    paths = {}
+    for name, infer in (("CoOp", coop_b), ("ZeroshotCLIP", zs_b.model_inference)):
+        d = runner.collect_base_val_features(infer, loader(val_images, val_labels, 8), image_k=K)
+        paths[name] = ck.base_features_path(str(tmp_path / "temp"), "Caltech101", name, 16, "tiny", 1)
+        ck.save_base_features(paths[name], **d)
+    tuned, zsd = ck.load_base_features(paths["CoOp"]), ck.load_base_features(paths["ZeroshotCLIP"])
+    assert np.abs(tuned["val_logits"] - r_val_logits.numpy()).max() < 100 * COS_TOL
+    assert np.array_equal(tuned["val_labels"], val_labels.numpy())
+    np.testing.assert_allclose(tuned["val_image_knn_dists"], orc.val_image_knn_dists(r_val_n.numpy(), K), atol=2e-3)
+    tfd = runner.text_feature_dict(zsd, zs_n.text_features, tuned, coop_n.text_features())
+    cal = VLCalibration(tuned, tfd, dac_flag=True, k_dac=5)
+    cal.fit()
+    r_cc = orc.dac_fit(r_zb.numpy(), r_zn.numpy(), r_tb.numpy(), r_tn.numpy(), 5)
+    np.testing.assert_allclose(cal.dac_calibrator.class_confidence, r_cc, rtol=5e-3)
+    with pytest.raises(NotImplementedError):
+        VLCalibration(tuned, tfd, base_calibration_mode="bin_based")
+
+    # VLCalibration.predict: numpy logits -> probabilities (DAC + softmax), reference contract
+    r_scaled = orc.dac_predict(r_test_logits.numpy(), r_cc)
+    r_probs = orc.softmax_probs(r_scaled.astype(np.float64))
+    probs = cal.predict(r_test_logits.numpy(), np.ones(len(test_images)))
+    assert probs.shape == r_probs.shape and np.abs(probs - r_probs).max() < 2e-3
+    np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+    with pytest.raises(AssertionError):
+        cal.predict(r_test_logits.numpy(), np.ones(3))
+
+    # test(): fused loop; labels drawn so that accuracy is neither 0 nor 1
+    r_conf, r_pred = orc.conf_pred(r_probs)
+    test_labels = syn.synthetic_labels(torch.from_numpy(r_pred), C, seed=3)
+    res = runner.test(coop_n, loader(test_images, test_labels, 16), val_dict=tuned, calibrator=cal, image_k=K)
+    r_prox = np.exp(-orc.knn_dists(r_val_n.numpy(), r_test_n.numpy(), K).mean(1))
+    gt = test_labels.numpy()
+    assert res["total"] == 37
+    assert res["accuracy"] == pytest.approx(100.0 * np.mean(r_pred == gt), abs=1e-9)
+    assert res["macro_f1"] == pytest.approx(100.0 * orc.macro_f1(r_pred, gt), abs=1e-9)
+    assert res["confidence"] == pytest.approx(float(r_conf.mean()), abs=1e-3)
+    # binned metrics: a sample within 1e-3 of a bin edge may change bins -> allow one sample's weight on top of |dconf|
+    slack = 100.0 * (1e-3 + 2.0 / 37)
+    assert abs(res["ece"] - 100.0 * orc.ece(r_conf, r_pred, gt, 10)) < slack
+    assert abs(res["mce"] - 100.0 * orc.mce(r_conf, r_pred, gt, 10)) < slack
+    assert abs(res["ace"] - 100.0 * orc.ace(r_conf, r_pred, gt, 10)) < slack
+    assert abs(res["piece"] - 100.0 * orc.piece(r_conf, r_prox, r_pred, gt, 10, 10)) < 2 * slack
+    assert list(res)[:8] == ["accuracy", "error_rate", "macro_f1", "confidence", "ece", "mce", "ace", "piece"]   # vl_evaluator.py:92-99
+
+
 def test_stress_residual_magnitudes():
     """Scaled-up residual branches (real CLIP has large outlier channels): still finite and within tolerance."""
     from clip_calibration_amd.model import build_model

@@ -120,6 +120,10 @@ def test_ece_cases():
         # float32 confidences: pandas (the reference) averages them in float32, the oracle in float64
         mtol = 1e-12 if g[f"{n}:conf"].dtype == np.float64 else 2e-7
         assert orc.mce(g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], int(g[f"{n}:bins"])) == pytest.approx(float(g[f"{n}:mce"]), abs=mtol), n
+        bins = int(g[f"{n}:bins"])
+        assert orc.ace(g[f"{n}:conf"], g[f"{n}:pred"], g[f"{n}:gt"], bins) == pytest.approx(float(g[f"{n}:ace"]), abs=mtol), n
+        assert orc.piece(g[f"{n}:conf"], g[f"{n}:prox"], g[f"{n}:pred"], g[f"{n}:gt"], 10, bins) == pytest.approx(float(g[f"{n}:piece"]), abs=mtol), n
+        assert orc.macro_f1(g[f"{n}:pred"], g[f"{n}:gt"]) == pytest.approx(float(g[f"{n}:f1"]), abs=1e-12), n
 
 
 def test_dac_cases():

@@ -72,3 +72,46 @@ def test_single_process_is_identity():
     t = torch.arange(6.0).reshape(3, 2)
     assert parallel.all_gather_embeddings(t) is t
     assert parallel.all_gather_ragged(t, 3) is t
+
+
+class _HostEvaluator:
+    """CPU stand-in with the fields gather_samples touches (the real one accumulates through the HIP kernel)."""
+    keep_samples = True
+
+    def __init__(self, conf, pred, gt, n_bins=10):
+        self.bins = torch.from_numpy(metrics.bin_statistics(conf, pred, gt, n_bins)).reshape(-1)
+        half = len(conf) // 2                           # two "batches", as process() would have appended them
+        self._conf = [torch.from_numpy(conf[:half]), torch.from_numpy(conf[half:])]
+        self._pred = [torch.from_numpy(pred[:half]), torch.from_numpy(pred[half:])]
+        self._gt = [torch.from_numpy(gt[:half]), torch.from_numpy(gt[half:])]
+
+
+def _sample_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        n = 301                                          # uneven shards: 151 / 150
+        conf = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        pred = rng.integers(0, 9, n)
+        gt = np.where(rng.uniform(size=n) < conf, pred, rng.integers(0, 9, n))
+        prox = rng.uniform(0.2, 0.9, n).astype(np.float32)
+        lo, hi = parallel.shard_bounds(n, rank, world)
+        ev = _HostEvaluator(conf[lo:hi], pred[lo:hi], gt[lo:hi])
+        got_prox = parallel.gather_samples(ev, torch.from_numpy(prox[lo:hi]))
+        assert np.array_equal(got_prox.numpy(), prox)
+        assert np.array_equal(torch.cat(ev._conf).numpy(), conf) and np.array_equal(torch.cat(ev._gt).numpy(), gt)
+        assert abs(metrics.ece_from_bins(ev.bins.numpy(), 10) - orc.ece(conf.astype(np.float64), pred, gt, 10)) < 1e-12
+        c, p, g = torch.cat(ev._conf).numpy(), torch.cat(ev._pred).numpy(), torch.cat(ev._gt).numpy()
+        res = np.array([metrics.AdaptiveECE(c, p, g, 10), metrics.PIECE(c, got_prox.numpy(), p, g, 10, 10), metrics.macro_f1(p, g)])
+        want = np.array([orc.ace(conf, pred, gt, 10), orc.piece(conf, prox, pred, gt, 10, 10), orc.macro_f1(pred, gt)])
+        assert np.abs(res - want).max() < 1e-6
+        np.save(os.path.join(out_dir, f"res{rank}.npy"), res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_level_metrics_world2(tmp_path):
+    mp.spawn(_sample_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "res0.npy"), np.load(tmp_path / "res1.npy"))
