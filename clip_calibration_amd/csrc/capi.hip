@@ -261,6 +261,18 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
+int clipmi_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,
+                      float* ctx_shifted, int B, int E, int H, int D, int n_ctx, clipmi_stream_t stream) {
+  return launch_cocoop_ctx(img_n, w1, b1, w2, b2, ctx, ctx_shifted, B, E, H, D, n_ctx, (hipStream_t)stream);
+}
+int clipmi_cocoop_prompts(const void* base, int base_dtype, const float* ctx_shifted, void* prompts, int n_images, int C, int L,
+                          int D, int n_ctx, clipmi_stream_t stream) {
+  return launch_cocoop_prompts(base, base_dtype, ctx_shifted, (half_t*)prompts, n_images, C, L, D, n_ctx, (hipStream_t)stream);
+}
+int clipmi_logits_per_image(const float* img_n, const float* txt, float scale, const float* dac_conf, float* logits, float* conf,
+                            int32_t* pred, float* txt_n_last, int B, int C, int E, clipmi_stream_t stream) {
+  return launch_logits_per_image(img_n, txt, scale, dac_conf, logits, conf, pred, txt_n_last, B, C, E, (hipStream_t)stream);
+}
 int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         clipmi_stream_t stream) {
   return launch_softmax_rows(logits, dac_conf, probs, conf, pred, B, C, (hipStream_t)stream);

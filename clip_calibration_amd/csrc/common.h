@@ -97,6 +97,12 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
 int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         hipStream_t s);
+int launch_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,
+                      float* ctx_shifted, int B, int E, int H, int D, int n_ctx, hipStream_t s);
+int launch_cocoop_prompts(const void* base, int base_dtype, const float* ctx_shifted, half_t* prompts, int nb, int C, int L, int D,
+                          int n_ctx, hipStream_t s);
+int launch_logits_per_image(const float* img_n, const float* txt, float scale, const float* dac_conf, float* logits, float* conf,
+                            int32_t* pred, float* txt_n_last, int B, int C, int E, hipStream_t s);
 int launch_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins,
                           int n_bins, hipStream_t s);
 

@@ -109,7 +109,8 @@ class TextTransformer(nn.Module):
             y = owner._text_blocks(xt, list(deep), n_ctx)
             used = min(len(deep), self.layers - 1)
             return [y, deep, counter + used]
-        return owner._text_blocks(x, None, 0)
+        deep, n_ctx = owner.ivlp_text_prompts()
+        return owner._text_blocks(x, deep, n_ctx)
 
 
 class VisionTransformer(nn.Module):
@@ -154,9 +155,42 @@ class CLIP(nn.Module):
         self.ln_final = LayerNorm(geom.transformer_width)
         self.text_projection = nn.Parameter(torch.empty(geom.transformer_width, geom.embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * float(np.log(1 / 0.07)))
+        self._init_ivlp_prompts()
         self._handle: Optional[int] = None
         self._bound = None          # keeps the packed tensors + ctypes arrays alive
         self._ws: Dict[str, torch.Tensor] = {}
+
+    # ---- IVLP / VPT design (clip/model.py:191-256, 334-346, 361-381) -------------------------------------------
+    def _init_ivlp_prompts(self) -> None:
+        """Per-layer prompt tokens owned by the model itself, under the reference's parameter names: ``visual.VPT``
+        (appended after the positional embedding), ``visual.transformer.resblocks.{i}.VPT_shallow`` and
+        ``transformer.resblocks.{i}.VPT_shallow`` for 1 <= i < depth (block 0 never carries one, model.py:209-226)."""
+        dd, g = self.design_details, self.geometry
+        if dd.get("trainer") not in ("IVLP", "VPT"):
+            return
+        v_depth, v_ctx = int(dd.get("vision_depth", 0)), int(dd.get("vision_ctx", 0))
+        t_depth, t_ctx = int(dd.get("language_depth", 0)), int(dd.get("language_ctx", 0))
+
+        def tokens(n, width):
+            return nn.Parameter(torch.empty(n, width).normal_(std=0.02))
+        if v_depth > 0:
+            self.visual.VPT = tokens(v_ctx, g.vision_width)
+            for i in range(1, min(v_depth, g.vision_layers)):
+                self.visual.transformer.resblocks[i].VPT_shallow = tokens(v_ctx, g.vision_width)
+        for i in range(1, min(t_depth, g.transformer_layers)):
+            self.transformer.resblocks[i].VPT_shallow = tokens(t_ctx, g.transformer_width)
+
+    def ivlp_vision_prompts(self):
+        """(shallow, deep list) for the image tower, (None, None) for every other design."""
+        vpt = getattr(self.visual, "VPT", None)
+        if vpt is None:
+            return None, None
+        return vpt, [b.VPT_shallow for b in self.visual.transformer.resblocks[1:] if hasattr(b, "VPT_shallow")]
+
+    def ivlp_text_prompts(self):
+        """(deep list, n_ctx) for the text tower, (None, 0) when the design has none."""
+        deep = [b.VPT_shallow for b in self.transformer.resblocks[1:] if hasattr(b, "VPT_shallow")]
+        return (deep, deep[0].shape[0]) if deep else (None, 0)
 
     # ---- nn.Module protocol -----------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -290,6 +324,8 @@ class CLIP(nn.Module):
         B = image.shape[0]
         out = torch.empty(B, g.embed_dim, dtype=torch.float32, device=image.device)
         hook_ref, keep, n_ctx = None, None, 0
+        if shared_ctx is None:                      # IVLP / VPT models carry their own prompt tokens
+            shared_ctx, deep_prompts = self.ivlp_vision_prompts()
         if shared_ctx is not None:
             n_ctx = shared_ctx.shape[0]
             hook, keep = self._hook(n_ctx, shared_ctx, deep_prompts, g.vision_layers - 1)
@@ -334,6 +370,9 @@ class CLIP(nn.Module):
         eot = tokenized_prompts.to(prompts.device).argmax(dim=-1).to(torch.int32).contiguous()  # index plumbing
         out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=prompts.device)
         hook_ref, keep = None, None
+        if not deep_prompts:
+            deep_prompts, n_ctx_own = self.ivlp_text_prompts()
+            n_ctx = n_ctx_own if deep_prompts else n_ctx
         if deep_prompts:
             hook, keep = self._hook(n_ctx, None, deep_prompts, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
@@ -348,6 +387,8 @@ class CLIP(nn.Module):
         text = ops._dev(text, "text", (torch.int64,))
         if text.dim() != 2 or text.shape[1] != g.context_length:
             raise ValueError(f"encode_text: expected ids [C,{g.context_length}], got {tuple(text.shape)}")
+        if self.ivlp_text_prompts()[0]:      # IVLP text blocks splice their own tokens: embeddings in, hook on
+            return self.text_encoder_f32(self.token_embedding(text), text)
         Cn = text.shape[0]
         out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=text.device)
         ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))

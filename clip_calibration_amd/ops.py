@@ -162,3 +162,60 @@ def ece_accumulate(conf: torch.Tensor, pred: torch.Tensor, labels: torch.Tensor,
         raise ValueError("ece_accumulate: bins must hold 3*(n_bins+1) float64")
     check(lib.clipmi_ece_accumulate(conf.data_ptr(), pred.data_ptr(), labels.data_ptr(), conf.numel(), bins.data_ptr(),
                                     n_bins, _stream()), "clipmi_ece_accumulate")
+
+
+# ---- CoCoOp glue (cocoop.py:154-199) -------------------------------------------------------------------------------
+def cocoop_ctx(img_n: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+               ctx: torch.Tensor) -> torch.Tensor:
+    """ctx + meta_net(img_n) per image -> fp32 [B, n_ctx, D]."""
+    f32 = (torch.float32,)
+    img_n, w1, b1, w2, b2, ctx = (_dev(t, n, f32) for t, n in ((img_n, "img_n"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"), (ctx, "ctx")))
+    B, E = img_n.shape
+    H, D, n_ctx = w1.shape[0], w2.shape[0], ctx.shape[0]
+    if w1.shape != (H, E) or b1.shape != (H,) or w2.shape != (D, H) or b2.shape != (D,) or ctx.shape != (n_ctx, D):
+        raise ValueError("cocoop_ctx: meta-net shapes do not chain")
+    out = torch.empty(B, n_ctx, D, dtype=torch.float32, device=img_n.device)
+    check(lib.clipmi_cocoop_ctx(img_n.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), ctx.data_ptr(),
+                                out.data_ptr(), B, E, H, D, n_ctx, _stream()), "clipmi_cocoop_ctx")
+    return out
+
+
+def cocoop_prompts(base: torch.Tensor, ctx_shifted: torch.Tensor) -> torch.Tensor:
+    """[C,L,D] base embeddings x [nb,n_ctx,D] shifted contexts -> fp16 prompts [nb*C, L, D]."""
+    base = _dev(base, "base", (torch.float16, torch.float32))
+    ctx_shifted = _dev(ctx_shifted, "ctx_shifted", (torch.float32,))
+    Cn, L, D = base.shape
+    nb, n_ctx, d2 = ctx_shifted.shape
+    if d2 != D:
+        raise ValueError("cocoop_prompts: widths differ")
+    out = torch.empty(nb * Cn, L, D, dtype=torch.float16, device=base.device)
+    check(lib.clipmi_cocoop_prompts(base.data_ptr(), _DT[base.dtype], ctx_shifted.data_ptr(), out.data_ptr(), nb, Cn, L, D, n_ctx,
+                                    _stream()), "clipmi_cocoop_prompts")
+    return out
+
+
+def logits_per_image(img_n: torch.Tensor, txt: torch.Tensor, scale: float, dac_conf: Optional[torch.Tensor] = None,
+                     want_conf_pred: bool = True, want_last_text: bool = True):
+    """logits[b,c] = scale * <img_n[b], normalise(txt[b,c])>; txt [B,C,E] un-normalised."""
+    img_n = _dev(img_n, "img_n", (torch.float32,))
+    txt = _dev(txt, "txt", (torch.float32,))
+    B, E = img_n.shape
+    if txt.dim() != 3 or txt.shape[0] != B or txt.shape[2] != E:
+        raise ValueError(f"logits_per_image: txt must be [B={B}, C, E={E}], got {tuple(txt.shape)}")
+    Cn = txt.shape[1]
+    dac_conf, pd = _opt(dac_conf, "dac_conf", (torch.float32,))
+    if dac_conf is not None and dac_conf.numel() != Cn:
+        raise ValueError("logits_per_image: dac_conf must have one entry per class")
+    logits = torch.empty(B, Cn, dtype=torch.float32, device=img_n.device)
+    conf = pred = last = None
+    pc = pp = pl = None
+    if want_conf_pred:
+        conf = torch.empty(B, dtype=torch.float32, device=img_n.device)
+        pred = torch.empty(B, dtype=torch.int32, device=img_n.device)
+        pc, pp = conf.data_ptr(), pred.data_ptr()
+    if want_last_text:
+        last = torch.empty(Cn, E, dtype=torch.float32, device=img_n.device)
+        pl = last.data_ptr()
+    check(lib.clipmi_logits_per_image(img_n.data_ptr(), txt.data_ptr(), float(scale), pd, logits.data_ptr(), pc, pp, pl, B, Cn, E,
+                                      _stream()), "clipmi_logits_per_image")
+    return logits, conf, pred, last

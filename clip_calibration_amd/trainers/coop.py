@@ -91,10 +91,13 @@ class CustomCLIP(nn.Module):
     def _text_inputs(self):
         return self.prompt_learner(), None, 0
 
+    def _cache_params(self):
+        """Everything the cached text features depend on (besides the frozen tower weights)."""
+        return list(self.prompt_learner.parameters())
+
     @torch.no_grad()
     def text_features(self) -> torch.Tensor:
-        params = [p for p in self.prompt_learner.parameters()]
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in self._cache_params())
         if self.cache_text_features and key == self._cache_key and self._cache is not None:
             return self._cache
         prompts, deep, n_ctx = self._text_inputs()

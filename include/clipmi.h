@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 3
+#define CLIPMI_ABI_VERSION 4
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -108,6 +108,25 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
  * alias logits); conf / pred as above, may be NULL. */
 int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred,
                         int B, int C, clipmi_stream_t stream);
+
+/* CoCoOp (trainers/classification/cocoop.py:154-199) -- SURVEY f-4: instance-conditioned prompts.  All fp32 unless noted.
+ *  clipmi_cocoop_ctx       PromptLearner.forward's meta-net and shift (:154-161): ctx_shifted[b,t,:] = ctx[t,:] +
+ *                          W2 relu(W1 img_n[b] + b1) + b2.  img_n [B,E] (L2-normalised image features), w1 [H,E], b1 [H],
+ *                          w2 [D,H], b2 [D], ctx [n_ctx,D] -> ctx_shifted [B,n_ctx,D].
+ *  clipmi_cocoop_prompts   construct_prompts for `n_images` images x C classes (:163-171): prompts[(b,c),l,:] =
+ *                          ctx_shifted[b,l-1,:] for 1 <= l <= n_ctx, else base[c,l,:] (base = token embedding of the
+ *                          "X X .. X name." prompts, [C,L,D] fp16|fp32).  prompts fp16 [n_images*C, L, D], the input of
+ *                          clipmi_text_encoder.  D % 8 == 0.
+ *  clipmi_logits_per_image the loop body of CustomCLIP.forward (:193-199): logits[b,c] = scale * <img_n[b],
+ *                          txt[b,c,:] / ||txt[b,c,:]||>, txt [B,C,E] UN-normalised text-encoder outputs; then the same
+ *                          DAC / softmax top-1 row pass as clipmi_logits.  txt_n_last [C,E] (may be NULL) receives the
+ *                          normalised text features of the last image -- what the reference's 3-tuple carries. */
+int clipmi_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* ctx, float* ctx_shifted, int B, int E, int H, int D, int n_ctx, clipmi_stream_t stream);
+int clipmi_cocoop_prompts(const void* base, int base_dtype, const float* ctx_shifted, void* prompts, int n_images,
+                          int C, int L, int D, int n_ctx, clipmi_stream_t stream);
+int clipmi_logits_per_image(const float* img_n, const float* txt, float scale, const float* dac_conf, float* logits,
+                            float* conf, int32_t* pred, float* txt_n_last, int B, int C, int E, clipmi_stream_t stream);
 
 /* Device-side accumulation of the ECE statistics (tools/metrics.py:90-130) -- SURVEY f-1.  bins: float64
  * [3*(n_bins+1)] = per-bin (count, sum_conf, sum_correct), bin n_bins collects conf == 1.0 (the digitize

@@ -164,6 +164,34 @@ def encode_text(sd: SD, ids: Tensor, dtype: torch.dtype = torch.float32) -> Tens
     return text_encoder(sd, emb, ids, dtype)
 
 
+def ivlp_prompts(sd: SD):
+    """Prompt tokens an IVLP / VPT model carries in its own state_dict (clip/model.py:191-226, 361-381): returns
+    (vision shallow [n,W] or None, vision deep list for blocks 1.., text deep list for blocks 1.., text n_ctx).  Block i's
+    ``VPT_shallow`` replaces the previous block's prompt tokens before block i runs -- the same splice as MaPLe's deep
+    prompts (clip/model.py:231-252 vs :301-328), so the tower functions above take them unchanged."""
+    def per_block(prefix):
+        out, i = [], 1
+        while f"{prefix}resblocks.{i}.VPT_shallow" in sd:
+            out.append(sd[f"{prefix}resblocks.{i}.VPT_shallow"])
+            i += 1
+        return out
+    deep_t = per_block("transformer.")
+    return sd.get("visual.VPT"), per_block("visual.transformer."), deep_t, (deep_t[0].shape[0] if deep_t else 0)
+
+
+def encode_image_ivlp(sd: SD, image: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
+    """VisionTransformer.forward of an IVLP / VPT model (clip/model.py:394-424 with VPT_shallow = True)."""
+    shallow, deep_v, _, _ = ivlp_prompts(sd)
+    return encode_image(sd, image, dtype, shallow, deep_v if shallow is not None else None)
+
+
+def encode_text_ivlp(sd: SD, ids: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
+    """CLIP.encode_text of an IVLP model: the text blocks overwrite tokens 1..n_ctx from block 1 on (clip/model.py:240-252)."""
+    _, _, deep_t, n_ctx = ivlp_prompts(sd)
+    emb = sd["token_embedding.weight"][ids].to(dtype)
+    return text_encoder(sd, emb, ids, dtype, deep_t or None, n_ctx)
+
+
 def coop_prompts(sd: SD, ids: Tensor, ctx: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
     """PromptLearner.forward, class_token_position == 'end' (coop.py:128-144; maple.py:170-176):
     [SOS embedding | ctx (shared or per-class) | embeddings of the tokens after the n_ctx placeholders]."""
@@ -173,6 +201,24 @@ def coop_prompts(sd: SD, ids: Tensor, ctx: Tensor, dtype: torch.dtype = torch.fl
     if c.dim() == 2:
         c = c.unsqueeze(0).expand(ids.shape[0], -1, -1)
     return torch.cat([emb[:, :1], c, emb[:, 1 + n_ctx:]], dim=1)
+
+
+def cocoop_forward(sd: SD, pl: SD, image: Tensor, ids: Tensor, dtype: torch.dtype = torch.float32):
+    """CoCoOp CustomCLIP.forward in eval mode (trainers/classification/cocoop.py:154-199).  ``pl`` holds ``ctx`` [n_ctx,D] and
+    ``meta_net.linear{1,2}.{weight,bias}``; ids are those of "X X .. X name." prompts.  Per image: ctx + meta_net(f) is
+    spliced into the C prompts, the text tower runs on them, the features are normalised and dotted with that image.
+    Returns (logits [B,C], image_features_n [B,E], per-image un-normalised text features [B,C,E])."""
+    f = l2_normalize(encode_image(sd, image, dtype))
+    hid = torch.relu(f @ pl["meta_net.linear1.weight"].to(dtype).t() + pl["meta_net.linear1.bias"].to(dtype))
+    bias = hid @ pl["meta_net.linear2.weight"].to(dtype).t() + pl["meta_net.linear2.bias"].to(dtype)
+    scale = sd["logit_scale"].exp()
+    logits, feats = [], []
+    for b in range(f.shape[0]):
+        prompts = coop_prompts(sd, ids, pl["ctx"].to(dtype) + bias[b], dtype)
+        tf = text_encoder(sd, prompts, ids, dtype)
+        feats.append(tf)
+        logits.append(scale * f[b] @ l2_normalize(tf).t())
+    return torch.stack(logits), f, torch.stack(feats)
 
 
 def maple_prompt_learner(sd: SD, ids: Tensor, pl: SD, dtype: torch.dtype = torch.float32):

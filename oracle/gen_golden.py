@@ -117,6 +117,39 @@ def main():
             tf = x[torch.arange(5), ids_c.argmax(-1)] @ m32.text_projection
         out.update(coop_ids=ids_c.numpy(), coop_ctx=ctx.numpy(), coop_prompts=_np(prompts), coop_text_features=_np(tf))
 
+        # CoCoOp glue (trainers/classification/cocoop.py:154-199) with the reference model's own sub-modules: meta-net
+        # shift of the context per image, C prompts per image through the text tower, per-image normalise + dot.
+        if gname == "tiny":
+            g = torch.Generator().manual_seed(79)
+            E, D = geom.embed_dim, geom.transformer_width
+            mn = {"ctx": (0.02 * torch.randn(n_ctx, D, generator=g)).half().float(),
+                  "meta_net.linear1.weight": (torch.randn(E // 16, E, generator=g) * E ** -0.5).half().float(),
+                  "meta_net.linear1.bias": (0.1 * torch.randn(E // 16, generator=g)).half().float(),
+                  "meta_net.linear2.weight": (torch.randn(D, E // 16, generator=g) * (E // 16) ** -0.5 * 0.1).half().float(),
+                  "meta_net.linear2.bias": (0.02 * torch.randn(D, generator=g)).half().float()}
+            images = torch.from_numpy(out["images"])
+            with torch.no_grad():
+                imf = m32.encode_image(images)
+                imf = imf / imf.norm(dim=-1, keepdim=True)
+                hid = torch.relu(torch.nn.functional.linear(imf, mn["meta_net.linear1.weight"], mn["meta_net.linear1.bias"]))
+                bias = torch.nn.functional.linear(hid, mn["meta_net.linear2.weight"], mn["meta_net.linear2.bias"])
+                ctx_shifted = mn["ctx"].unsqueeze(0) + bias.unsqueeze(1)
+                emb = m32.token_embedding(ids_c)
+                lg, tfs = [], []
+                for ctx_i, imf_i in zip(ctx_shifted, imf):
+                    pts = torch.cat([emb[:, :1], ctx_i.unsqueeze(0).expand(5, -1, -1), emb[:, 1 + n_ctx:]], dim=1)
+                    x = pts + m32.positional_embedding
+                    x = m32.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+                    x = m32.ln_final(x)
+                    tf = x[torch.arange(5), ids_c.argmax(-1)] @ m32.text_projection
+                    tfs.append(tf)
+                    tf = tf / tf.norm(dim=-1, keepdim=True)
+                    lg.append(m32.logit_scale.exp() * imf_i @ tf.t())
+            out.update(cocoop_logits=_np(torch.stack(lg)), cocoop_text_features=_np(torch.stack(tfs)),
+                       cocoop_ctx_shifted=_np(ctx_shifted))
+            for k, v in mn.items():
+                out["cocoop_pl:" + k] = v.numpy()
+
         # MaPLe: reference VisionTransformer_MaPLe / ResidualAttentionBlock_MaPLe (clip/model.py:259-331,427-478)
         if gname == "tiny":
             mm = ref_model.build_model(dict(sd), dict(MAPLE)).float()
@@ -148,6 +181,26 @@ def main():
                        maple_shared_ctx=_np(shared))
             for k, v in pl.items():
                 out["maple_pl:" + k] = v.numpy()
+
+        # IVLP / VPT blocks (clip/model.py:191-256, 361-424): per-layer prompt tokens that live INSIDE the model
+        # (visual.VPT, *.resblocks.{i}.VPT_shallow).  The synthetic state_dict has none of them, so the reference's
+        # non-strict fallback leaves them at their seeded random init; the fixture stores them next to the outputs.
+        if gname == "tiny3":
+            import contextlib, io
+            for tag, dd in (("ivlp", {"trainer": "IVLP", "vision_depth": 3, "language_depth": 3, "vision_ctx": 2, "language_ctx": 2}),
+                            ("vpt", {"trainer": "VPT", "vision_depth": 2, "language_depth": 0, "vision_ctx": 4, "language_ctx": 0})):
+                torch.manual_seed(1234)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mi = ref_model.build_model(dict(sd), dict(dd)).float()
+                ids_i = syn.synthetic_token_ids(5, gname, seed=3, n_ctx_placeholders=dd["language_ctx"])
+                images = torch.from_numpy(out["images"])
+                with torch.no_grad():
+                    out[f"{tag}_image_features"] = _np(mi.encode_image(images))
+                    out[f"{tag}_text_features"] = _np(mi.encode_text(ids_i))
+                out[f"{tag}_ids"] = ids_i.numpy()
+                for k, v in mi.state_dict().items():
+                    if "VPT" in k:
+                        out[f"{tag}_sd:{k}"] = v.float().numpy()
         np.savez_compressed(os.path.join(OUT, fname), **out)
         print("wrote", fname, {k: np.shape(v) for k, v in out.items() if not k.startswith("sd:")})
 

@@ -312,6 +312,133 @@ def test_kgcoop_mirror_and_reference_style_zeroshot():
     assert y.shape == x.shape and np.abs(y.float().cpu().numpy() - ref.numpy()).max() < 5e-3
 
 
+@pytest.mark.parametrize("tag,dd", [
+    ("ivlp", {"trainer": "IVLP", "vision_depth": 3, "language_depth": 3, "vision_ctx": 2, "language_ctx": 2}),
+    ("vpt", {"trainer": "VPT", "vision_depth": 2, "language_depth": 0, "vision_ctx": 4, "language_ctx": 0})])
+def test_golden_ivlp_vpt_designs(tag, dd):
+    """f-4: build_model(..., design_details IVLP / VPT) creates the reference's per-layer prompt parameters
+    (clip/model.py:191-256, 361-381), loads them by name, and both towers splice them -- against outputs of the
+    reference's own IVLP model (tests/golden/tiny3_clip.npz)."""
+    g = load_golden("tiny3_clip.npz")
+    sd = syn.synthetic_state_dict("tiny3", seed=0)
+    plain_keys = set(sd)
+    from clip_calibration_amd.model import build_model
+    model = build_model(dict(sd), dict(dd))                       # prompts missing from the dict: non-strict fallback
+    own = {k for k in model.state_dict() if "VPT" in k}
+    want = {k.split(":", 1)[1] for k in g if k.startswith(tag + "_sd:")}
+    assert own == want and not (own & plain_keys)
+    assert all(model.state_dict()[k].dtype == torch.float32 for k in own)       # convert_weights leaves them fp32
+    model.load_state_dict({k: torch.from_numpy(g[f"{tag}_sd:{k}"]) for k in own}, strict=False)
+    model = model.cuda()
+    images, ids = torch.from_numpy(g["images"]).cuda(), torch.from_numpy(g[tag + "_ids"]).cuda()
+    with torch.no_grad():
+        img = model.encode_image(images).float().cpu().numpy()
+        txt = model.encode_text(ids).float().cpu().numpy()
+        img32 = model.image_features_f32(images).cpu().numpy()
+    ri, rt = g[tag + "_image_features"], g[tag + "_text_features"]
+    cos = lambda a, b: (a / np.linalg.norm(a, axis=1, keepdims=True)) @ (b / np.linalg.norm(b, axis=1, keepdims=True)).T
+    assert np.abs(cos(img32, ri) - cos(ri, ri)).max() < COS_TOL
+    assert np.abs(cos(txt, rt) - cos(rt, rt)).max() < 2 * COS_TOL             # through the fp16 return dtype
+    assert np.abs(cos(img, ri) - cos(ri, ri)).max() < 2 * COS_TOL
+    assert np.abs(img32 - g["image_features"]).max() > 1e-3                     # and not the plain tower's answer
+    # the reference's TextEncoder statements (vpt.py:56-67) on the attribute surface
+    x = model.token_embedding(ids).type(model.dtype) + model.positional_embedding.type(model.dtype)
+    x = model.transformer(x.permute(1, 0, 2)).permute(1, 0, 2)
+    x = model.ln_final(x).type(model.dtype)
+    tf = (x[torch.arange(x.shape[0]), ids.argmax(dim=-1)] @ model.text_projection).float().detach().cpu().numpy()
+    assert np.abs(cos(tf, rt) - cos(rt, rt)).max() < 5 * COS_TOL
+
+
+def test_golden_cocoop_and_chunking():
+    """f-4: CoCoOp eval forward (cocoop.py:154-199) -- meta-net shift, B*C prompts through the text tower, per-image
+    normalise + dot -- against the fixture produced with the reference model's sub-modules, and across chunk sizes."""
+    from clip_calibration_amd.trainers import CoCoOpCLIP
+    g = load_golden("tiny_clip.npz")
+    sd, model = _build("tiny")
+    ids = torch.from_numpy(g["coop_ids"])
+    images = torch.from_numpy(g["images"]).cuda()
+    ref_txt = g["cocoop_text_features"]                                    # [B,C,E] un-normalised
+    outs = []
+    for per_call in (4096, 5, 7):                                          # all images at once / one image / ragged chunks
+        co = CoCoOpCLIP(model, ids, n_ctx=4, prompts_per_call=per_call)
+        co.prompt_learner.load_state_dict({k.split(":", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("cocoop_pl:")},
+                                          strict=False)
+        logits, imf, txf, conf, pred = co(images, want_conf_pred=True)
+        outs.append(logits.cpu().numpy())
+        assert np.abs(logits.cpu().numpy() - g["cocoop_logits"]).max() < 100 * COS_TOL
+        ctx_shifted = co.prompt_learner(imf).cpu().numpy()
+        assert np.abs(ctx_shifted - g["cocoop_ctx_shifted"]).max() < 1e-4
+        last = ref_txt[-1] / np.linalg.norm(ref_txt[-1], axis=1, keepdims=True)
+        assert np.abs(txf.cpu().numpy() @ last.T - last @ last.T).max() < COS_TOL      # the LAST image's text features
+        probs = orc.softmax_probs(g["cocoop_logits"].astype(np.float64))
+        rc, rp = orc.conf_pred(probs)
+        assert np.array_equal(pred.cpu().numpy(), rp) and np.abs(conf.cpu().numpy() - rc).max() < 5e-3
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])       # chunking is bitwise neutral
+
+
+def test_cocoop_vs_oracle_with_dac_larger_batch():
+    from clip_calibration_amd.trainers import CoCoOpCLIP
+    sd, model = _build("tiny")
+    B, C = 9, 13
+    ids = syn.synthetic_token_ids(C, "tiny", seed=40, n_ctx_placeholders=4)
+    images = syn.synthetic_images(B, "tiny", seed=40)
+    co = CoCoOpCLIP(model, ids, n_ctx=4, prompts_per_call=40, seed=5)
+    with torch.no_grad():                                                  # a meta-net that actually moves the context
+        for p in co.prompt_learner.meta_net.parameters():
+            p.copy_((torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.2).to(p))
+    pl = {k: v.detach().float().cpu() for k, v in co.prompt_learner.state_dict().items()}
+    dac = torch.linspace(0.6, 1.4, C)
+    logits, imf, txf, conf, pred = co(images.cuda(), dac_conf=dac.cuda(), want_conf_pred=True)
+    with torch.no_grad():
+        r_logits, r_f, _ = orc.cocoop_forward(sd, pl, images, ids)
+    r_scaled = orc.dac_predict(r_logits.numpy(), dac.numpy())
+    assert np.abs(logits.cpu().numpy() - r_scaled).max() < 100 * COS_TOL * 1.5
+    rc, rp = orc.conf_pred(orc.softmax_probs(r_scaled.astype(np.float64)))
+    assert np.array_equal(pred.cpu().numpy(), rp)
+    assert np.abs(imf.cpu().numpy() @ r_f.numpy().T - (r_f @ r_f.t()).numpy()).max() < COS_TOL
+
+
+def test_promptsrc_and_vpt_mirrors():
+    """PromptSRC eval forward = CoOp splice through an IVLP-design CLIP (promptsrc.py:186-214); VPT = fixed hand-written
+    text embeddings + a VPT-design image tower (vpt.py:94-116).  Oracle with the model's own prompt tokens."""
+    from clip_calibration_amd.model import build_model
+    from clip_calibration_amd.trainers import PromptSRCCLIP, VPTCLIP, CoOpCLIP
+    sd = syn.synthetic_state_dict("tiny3", seed=0)
+    images = syn.synthetic_images(4, "tiny3", seed=50)
+    C = 6
+    # --- PromptSRC
+    dd = {"trainer": "IVLP", "vision_depth": 3, "language_depth": 2, "vision_ctx": 3, "language_ctx": 4}
+    torch.manual_seed(7)
+    model = build_model(dict(sd), dict(dd)).cuda()
+    ids = syn.synthetic_token_ids(C, "tiny3", seed=50, n_ctx_placeholders=4)
+    ps = PromptSRCCLIP(model, ids, n_ctx=4, seed=9)
+    full = dict(sd); full.update({k: v.detach().float().cpu() for k, v in model.state_dict().items() if "VPT" in k})
+    ctx = ps.prompt_learner.ctx.detach().float().cpu()
+    logits, imf, txf = ps(images.cuda())
+    _, _, deep_t, n_ctx_t = orc.ivlp_prompts(full)
+    with torch.no_grad():
+        r_t = orc.l2_normalize(orc.text_encoder(full, orc.coop_prompts(full, ids, ctx), ids, torch.float32, deep_t, n_ctx_t))
+        r_l, r_i, _ = orc.clip_logits(orc.encode_image_ivlp(full, images), r_t, sd["logit_scale"].exp())
+    assert np.abs(logits.cpu().numpy() - r_l.numpy()).max() < 100 * COS_TOL
+    cached = ps.text_features()
+    with torch.no_grad():
+        model.transformer.resblocks[1].VPT_shallow.add_(0.05)            # a text-side model token changes -> cache must miss
+    assert ps.text_features() is not cached
+    with pytest.raises(ValueError):
+        PromptSRCCLIP(_build("tiny3")[1], ids)                            # plain design: refused
+    # --- VPT
+    dd = {"trainer": "VPT", "vision_depth": 2, "language_depth": 0, "vision_ctx": 4, "language_ctx": 0}
+    model = build_model(dict(sd), dict(dd)).cuda()
+    ids_zs = syn.synthetic_token_ids(C, "tiny3", seed=51)
+    vp = VPTCLIP(model, ids_zs)
+    full = dict(sd); full.update({k: v.detach().float().cpu() for k, v in model.state_dict().items() if "VPT" in k})
+    logits, imf, txf = vp(images.cuda())
+    with torch.no_grad():
+        r_l, _, _ = orc.clip_logits(orc.encode_image_ivlp(full, images), orc.encode_text(full, ids_zs), sd["logit_scale"].exp())
+    assert np.abs(logits.cpu().numpy() - r_l.numpy()).max() < 100 * COS_TOL
+    assert vp.fixed_embeddings is txf
+
+
 def test_runner_base_to_new_calibration_flow(tmp_path):
     """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
     -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of

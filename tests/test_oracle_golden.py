@@ -92,6 +92,34 @@ def test_maple(tiny):
     np.testing.assert_allclose(imf.numpy(), tiny["maple_image_features"], rtol=1e-4, atol=1e-4)
 
 
+def test_cocoop(tiny):
+    g, sd = tiny, syn.synthetic_state_dict("tiny", seed=0)
+    pl = {k.split(":", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("cocoop_pl:")}
+    with torch.no_grad():
+        logits, _, feats = orc.cocoop_forward(sd, pl, torch.from_numpy(g["images"]), torch.from_numpy(g["coop_ids"]))
+    np.testing.assert_allclose(feats.numpy(), g["cocoop_text_features"], atol=2e-5)
+    np.testing.assert_allclose(logits.numpy() / 100.0, g["cocoop_logits"] / 100.0, atol=2e-5)
+    # the shift is per image: the three images see different text features
+    assert np.abs(g["cocoop_text_features"][0] - g["cocoop_text_features"][1]).max() > 1e-3
+
+
+@pytest.mark.parametrize("tag", ["ivlp", "vpt"])
+def test_ivlp_vpt_blocks(tag):
+    """f-4: per-layer prompt tokens of the IVLP / VPT design (clip/model.py:191-256) on the 3-layer geometry."""
+    g = load_golden("tiny3_clip.npz")
+    sd = syn.synthetic_state_dict("tiny3", seed=0)
+    sd.update({k.split(":", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith(tag + "_sd:")})
+    shallow, deep_v, deep_t, n_ctx = orc.ivlp_prompts(sd)
+    assert (len(deep_v), len(deep_t), n_ctx) == ((2, 2, 2) if tag == "ivlp" else (1, 0, 0))
+    with torch.no_grad():
+        img = orc.encode_image_ivlp(sd, torch.from_numpy(g["images"]))
+        txt = orc.encode_text_ivlp(sd, torch.from_numpy(g[tag + "_ids"]))
+    np.testing.assert_allclose(img.numpy(), g[tag + "_image_features"], atol=2e-5)
+    np.testing.assert_allclose(txt.numpy(), g[tag + "_text_features"], atol=2e-5)
+    # the prompts matter: the plain towers give something else on the image side
+    assert np.abs(img.numpy() - g["image_features"]).max() > 1e-3
+
+
 def test_vitb16_full_geometry():
     g = load_golden("vitb16_seed0.npz")
     sd = syn.synthetic_state_dict("ViT-B/16", seed=0)
