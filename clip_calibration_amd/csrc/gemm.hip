@@ -108,8 +108,9 @@ template <typename T, int EPI, int CH>
 __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
                                                     int wave_n, int lane, char* patch) {
   constexpr int TM = T::TM, TN = T::TN;
-  static_assert(T::WTN == 64 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue assumes 64-column wave tiles");
-  constexpr int ROWB = T::WTN * 2 + 16;  // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
+  static_assert(T::WTN % 64 == 0 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue works on 64-column slices of the wave tile");
+  constexpr int NH = T::WTN / 64;        // 64-column slices per wave tile (1 for the 64-wide wave tiles, 2 for 128)
+  constexpr int ROWB = 64 * 2 + 16;      // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
   const int r16 = lane & 15, g4 = lane >> 4;
   f32x4 bias[TN], lng[TN];
   const bool fold = a.ln_stats != nullptr;   // wave-uniform
@@ -127,31 +128,35 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
   }
   half_t* out = static_cast<half_t*>(a.out);
   const int rrow = lane >> 3, rcol = lane & 7;
-  const int n_st = n0 + wave_n * T::WTN + rcol * 8;
 #pragma unroll
   for (int jc = 0; jc < TM / CH; ++jc) {
 #pragma unroll
-    for (int jj = 0; jj < CH; ++jj) {
-      float rs = 1.f, mrs = 0.f;
-      if (fold) ln_row_params(a, m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16, rs, mrs);
+    for (int h = 0; h < NH; ++h) {
+      const int n_st = n0 + wave_n * T::WTN + h * 64 + rcol * 8;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
-        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+      for (int jj = 0; jj < CH; ++jj) {
+        float rs = 1.f, mrs = 0.f;
+        if (fold) ln_row_params(a, m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16, rs, mrs);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = h * 4 + ii;
+          f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
+          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (ii * 16 + g4 * 4) * 2) =
+              f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         }
-        *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
-            f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       }
-    }
-    // same wave, LDS is in order: the reads below see the writes above
+      // same wave, LDS is in order: the reads below see the writes above (and the next slice's writes follow these reads)
 #pragma unroll
-    for (int t = 0; t < 2 * CH; ++t) {
-      const int row = t * 8 + rrow;
-      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
-      const int m = m0 + wave_m * T::WTM + jc * (16 * CH) + row;
-      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
+      for (int t = 0; t < 2 * CH; ++t) {
+        const int row = t * 8 + rrow;
+        const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+        const int m = m0 + wave_m * T::WTM + jc * (16 * CH) + row;
+        if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
+      }
     }
   }
 }
@@ -243,7 +248,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
     if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {   // wave-uniform
       __syncthreads();                           // every wave is done with the main-loop LDS image
-      epilogue_f16_staged<T, EPI, 2>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * (T::WTN * 2 + 16)));
+      epilogue_f16_staged<T, EPI, 2>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * 144));
       return;
     }
   }
@@ -862,6 +867,150 @@ int launch_pipe(KArgs k, hipStream_t s) {
   return check_launch("gemm_pipe_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide-wave variant: 256 x 256 tile, FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers each).  The
+// 16-wave kernel reads every operand element from LDS four times (4 x 4 wave grid); at 128 B/clk/CU that LDS traffic
+// takes as long as the MFMAs themselves, so its main loop tops out near 60 % of the matrix peak.  A 2 x 2 wave grid
+// halves the LDS bytes per flop.  With a single wave per SIMD nothing else hides latency, so the wave pipelines
+// itself: BK = 32 stages in a 4-slot LDS ring, DMA issued three stages ahead (counted vmcnt), and the MFMA fragments
+// of stage kt+1 are read from LDS into a second register set while the 64 MFMAs of stage kt execute.
+// Per iteration kt:  wait(stage kt+1 landed) ; barrier ; DMA stage kt+3 -> slot of stage kt-1 (its fragment reads
+// completed before any wave left iteration kt-1) ; ds_read fragments kt+1 ; MFMAs on fragments kt.
+// MEASURED (tools/gemm_ksweep.py, profiles/r01_gemm_wide.txt): 7-12 % SLOWER than the 16-wave kernel, in slope (main loop)
+// and intercept (a lone wave per SIMD stores its 128 x 128 outputs with nothing to overlap) alike -- the 16-wave loop is
+// bound by the latency of the one-stage-ahead L2->LDS DMA, not by LDS bandwidth.  Variants that move the fragment reads
+// into the MFMA stream make hipcc shuffle accumulators between AGPRs and VGPRs (400+ v_accvgpr moves per iteration).
+// Kept as CLIPMI_GEMM_VARIANT=c (parity-tested), never chosen by the cost model.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(T::NT, 1) void gemm_wide_kernel(const KArgs a) {
+  using R = Ring<T, 4>;
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int srow = tid >> 2;
+  const int schunk = (tid & 3) ^ ring_swz(srow);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int xoff[R::XI], woff[R::WI];
+#pragma unroll
+  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
+#pragma unroll
+  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+  auto stage = [&](int kt) {
+    char* xs = smem + (kt & 3) * R::STAGE + lds_wave_off;
+    char* ws = xs + R::XB;
+    const int k0 = kt * R::BKR * 2;
+#pragma unroll
+    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
+  const int xbase = wave_m * T::WTM * 64 + foff;
+  const int wbase = R::XB + wave_n * T::WTN * 64 + foff;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+
+  // Fragment reads of stage kt+1 are issued in two halves INSIDE the MFMA stream of stage kt (after the first 8 and after
+  // the first 32 MFMAs).  The LDS counter is 4 bits on gfx9, so "16 reads in flight while waiting for the 16 before them"
+  // cannot be expressed; instead every wait the compiler needs is an lgkmcnt(0) that falls in front of the first MFMA
+  // of a step, when the newest outstanding read was issued 32 MFMAs (~500 cycles) earlier.
+  auto read_x = [&](int kt, f16x8 (&xf)[TM]) {
+    const char* st = smem + (kt & 3) * R::STAGE;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 1024);
+  };
+  auto read_w = [&](int kt, f16x8 (&wf)[TN]) {
+    const char* st = smem + (kt & 3) * R::STAGE;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 1024);
+  };
+  auto mfma_rows = [&](int i0, int i1, const f16x8 (&xf)[TM], const f16x8 (&wf)[TN]) {
+#pragma unroll
+    for (int i = i0; i < i1; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+  // one pipeline step: fragments of stage kt are in (xc, wc); (xn, wn) receive stage kt+1.  FULL = steady state
+  // (stages kt+1 .. kt+3 all exist), otherwise the same sequence with its guards.
+  auto step = [&](auto full, int kt, int nk, const f16x8 (&xc)[TM], const f16x8 (&wc)[TN], f16x8 (&xn)[TM], f16x8 (&wn)[TN]) {
+    constexpr bool FULL = decltype(full)::value;
+    const bool next = FULL || kt + 1 < nk;
+    if (next) {
+      if (FULL || kt + 2 < nk) wait_vmcnt<R::G>();   // stage kt+2 may stay in flight
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                  // stage kt+1 visible; every wave is past the MFMAs of stage kt-1
+      if (FULL || kt + 3 < nk) stage(kt + 3);
+    }
+    if (next) {
+      read_x(kt + 1, xn);
+      read_w(kt + 1, wn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_rows(0, TN, xc, wc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = a.K / R::BKR;   // even: K is a multiple of 64
+  stage(0);
+  stage(1);
+  if (2 < nk) stage(2);
+  if (2 < nk) wait_vmcnt<2 * R::G>();
+  else wait_vmcnt<R::G>();
+  __builtin_amdgcn_s_barrier();
+  read_x(0, xf0);
+  read_w(0, wf0);
+  int kt = 0;
+  for (; kt + 4 < nk; kt += 2) {   // steady state: no branches inside
+    step(std::true_type{}, kt, nk, xf0, wf0, xf1, wf1);
+    step(std::true_type{}, kt + 1, nk, xf1, wf1, xf0, wf0);
+  }
+  for (; kt < nk; kt += 2) {       // at most four general steps
+    step(std::false_type{}, kt, nk, xf0, wf0, xf1, wf1);
+    step(std::false_type{}, kt + 1, nk, xf1, wf1, xf0, wf0);
+  }
+  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+}
+
+template <typename T, int EPI, bool OUT_F32>
+int launch_wide(KArgs k, hipStream_t s) {
+  using R = Ring<T, 4>;
+  static bool attr_set = false;
+  auto fn = gemm_wide_kernel<T, EPI, OUT_F32>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
+  return check_launch("gemm_wide_kernel");
+}
+
 using T128 = Tile<128, 128, 2, 2, 2>;      // 4 waves of 64x64, 64 KiB LDS, 2 workgroups / CU
 using T256w16 = Tile<256, 256, 4, 4, 4>;   // 16 waves of 64x64, 128 KiB LDS, 1 workgroup / CU, 4 waves / SIMD
 using T256w8 = Tile<256, 256, 2, 4, 2>;    // 8 waves of 128x64
@@ -869,6 +1018,7 @@ using T320w8 = Tile<320, 256, 2, 4, 2>;     // 8 waves of 160x64: 474 tiles at M
 using T256x128 = Tile<256, 128, 4, 2, 2>;  // 8 waves of 64x64, 96 KiB LDS
 using T128x256o4 = Tile<128, 256, 2, 4, 4>;  // 8 waves of 64x64, <=128 VGPRs so two workgroups share a CU
 using T256x128o4 = Tile<256, 128, 4, 2, 4>;
+using T256w4 = Tile<256, 256, 2, 2, 1>;    // 4 waves of 128x128 (gemm_wide_kernel)
 
 // Tile choice.  CLIPMI_GEMM_VARIANT = 0..9, a forces a configuration (tuning / test aid; every one is parity-tested).
 // Default: minimise a cost model  rounds x tile area x workgroups-per-CU x penalty  over the three configurations that
@@ -895,6 +1045,7 @@ int pick_variant(const KArgs& k) {
   if (e && e[0] >= '0' && e[0] <= '9') return e[0] - '0';
   if (e && e[0] == 'a') return 10;
   if (e && e[0] == 'b') return 11;
+  if (e && e[0] == 'c') return 12;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
@@ -920,7 +1071,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
   int variant = pick_variant(k);
   if (k.x16) {   // producer fold: needs the non-persistent epilogue and at most LN_MAX_PARTS column tiles
     if (variant == 9) variant = 2;
-    if (variant == 11) variant = 1;
+    if (variant == 11 || variant == 12) variant = 1;
     const int bn = (variant == 0) ? 128 : (variant == 3 || variant == 7) ? 128 : 256;
     if ((k.N + bn - 1) / bn > LN_MAX_PARTS) variant = 1;
     CLIPMI_REQUIRE((k.N + 255) / 256 <= LN_MAX_PARTS, CLIPMI_ERR_SHAPE, "gemm: N=%d has too many column tiles for the LayerNorm fold", k.N);
@@ -939,6 +1090,9 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
     case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s);
+    case 12:
+      if constexpr (EPI == EPI_RESIDUAL_FOLD) return launch_tile<T256w16, EPI, OUT_F32>(k, s);   // fold epilogue: 64-column wave tiles only
+      else return launch_wide<T256w4, EPI, OUT_F32>(k, s);
     default: return launch_tile<T128, EPI, OUT_F32>(k, s);
   }
 }

@@ -15,6 +15,12 @@ SHAPES = [("qkv", M, 2304, 768, _lib.EPI_BIAS, torch.float16),
           ("out", M, 768, 768, _lib.EPI_BIAS_RESIDUAL, torch.float32),
           ("fc", M, 3072, 768, _lib.EPI_BIAS_QUICKGELU, torch.float16),
           ("proj", M, 768, 3072, _lib.EPI_BIAS_RESIDUAL, torch.float32)]
+if os.environ.get("TOWER", "vision") == "text":      # ViT-B/16's text tower: C prompts x 77 tokens, width 512
+    M = int(os.environ.get("C", "4000")) * 77
+    SHAPES = [("qkv", M, 1536, 512, _lib.EPI_BIAS, torch.float16),
+              ("out", M, 512, 512, _lib.EPI_BIAS_RESIDUAL, torch.float32),
+              ("fc", M, 2048, 512, _lib.EPI_BIAS_QUICKGELU, torch.float16),
+              ("proj", M, 512, 2048, _lib.EPI_BIAS_RESIDUAL, torch.float32)]
 VARIANTS = os.environ.get("VARIANTS", "0,1,2,3,4,5,6,7,8").split(",")
 
 
