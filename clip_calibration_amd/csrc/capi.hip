@@ -261,6 +261,9 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
+int clipmi_group_mean(const float* in, float* out, int G, int P, int E, clipmi_stream_t stream) {
+  return launch_group_mean(in, out, G, P, E, (hipStream_t)stream);
+}
 int clipmi_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,
                       float* ctx_shifted, int B, int E, int H, int D, int n_ctx, clipmi_stream_t stream) {
   return launch_cocoop_ctx(img_n, w1, b1, w2, b2, ctx, ctx_shifted, B, E, H, D, n_ctx, (hipStream_t)stream);

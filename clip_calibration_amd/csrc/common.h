@@ -91,6 +91,7 @@ int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos
                         int L, int D, int vocab, hipStream_t s);
 int launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);  // rows[c] = c*L + eot[c]
 int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
+int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStream_t s);
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s);
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,
                   float* conf, int32_t* pred, int B, int C, int E, hipStream_t s);

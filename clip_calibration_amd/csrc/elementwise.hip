@@ -199,7 +199,26 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, 
   for (int e = lane; e < E; e += 64) out[(int64_t)row * E + e] = (float)x[e] * inv;
 }
 
+// out[g,:] = mean_p in[(g*P + p),:]  -- ProDA's prompt-ensemble mean of the normalised text features (proda.py:328-332)
+__global__ __launch_bounds__(256) void group_mean_kernel(const float* __restrict__ in, float* __restrict__ out, int G, int P, int E) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)G * E) return;
+  const int g = (int)(i / E), e = (int)(i % E);
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += in[((int64_t)g * P + p) * E + e];
+  out[i] = s / (float)P;
+}
+
 }  // namespace
+
+int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStream_t s) {
+  if (G == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(in && out, CLIPMI_ERR_ARG, "group_mean: null pointer");
+  CLIPMI_REQUIRE(G > 0 && P > 0 && E > 0, CLIPMI_ERR_SHAPE, "group_mean: G=%d P=%d E=%d", G, P, E);
+  const int64_t total = (int64_t)G * E;
+  hipLaunchKernelGGL(group_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, G, P, E);
+  return check_launch("group_mean_kernel");
+}
 
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s) {
   CLIPMI_REQUIRE(image && col, CLIPMI_ERR_ARG, "patchify: null pointer");

@@ -219,3 +219,14 @@ def logits_per_image(img_n: torch.Tensor, txt: torch.Tensor, scale: float, dac_c
     check(lib.clipmi_logits_per_image(img_n.data_ptr(), txt.data_ptr(), float(scale), pd, logits.data_ptr(), pc, pp, pl, B, Cn, E,
                                       _stream()), "clipmi_logits_per_image")
     return logits, conf, pred, last
+
+
+def group_mean(x: torch.Tensor, group: int) -> torch.Tensor:
+    """[G*group, E] -> [G, E] mean over consecutive groups of rows (ProDA's prompt-ensemble mean, proda.py:328-332)."""
+    x = _dev(x, "x", (torch.float32,))
+    rows, E = x.shape
+    if group <= 0 or rows % group:
+        raise ValueError(f"group_mean: {rows} rows do not split into groups of {group}")
+    out = torch.empty(rows // group, E, dtype=torch.float32, device=x.device)
+    check(lib.clipmi_group_mean(x.data_ptr(), out.data_ptr(), rows // group, group, E, _stream()), "clipmi_group_mean")
+    return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 4
+#define CLIPMI_ABI_VERSION 5
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -108,6 +108,10 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
  * alias logits); conf / pred as above, may be NULL. */
 int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred,
                         int B, int C, clipmi_stream_t stream);
+
+/* ProDA's classifier (trainers/classification/proda.py:316-333): out[g,:] = mean over the P prompts of class g of the
+ * (already L2-normalised) text features in [(g*P + p), :].  fp32; the mean is NOT re-normalised, as in the reference. */
+int clipmi_group_mean(const float* in, float* out, int G, int P, int E, clipmi_stream_t stream);
 
 /* CoCoOp (trainers/classification/cocoop.py:154-199) -- SURVEY f-4: instance-conditioned prompts.  All fp32 unless noted.
  *  clipmi_cocoop_ctx       PromptLearner.forward's meta-net and shift (:154-161): ctx_shifted[b,t,:] = ctx[t,:] +

@@ -221,6 +221,37 @@ def cocoop_forward(sd: SD, pl: SD, image: Tensor, ids: Tensor, dtype: torch.dtyp
     return torch.stack(logits), f, torch.stack(feats)
 
 
+def proda_classifier(sd: SD, ids: Tensor, ctx: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
+    """ProDA's set_classifier (trainers/classification/proda.py:146-222, 316-333).  ctx [P, n_ctx, D]; prompt p of every class
+    places the class-name tokens in FRONT of the context for p < P//4, in the MIDDLE (after n_ctx//2 context tokens) for
+    P//4 <= p < P//2, and after the whole context otherwise (proda.py:110-114); ids are "X*n_ctx name ." prompts.  Every
+    prompt goes through the text tower, is L2-normalised, and the class classifier is the plain mean over its P prompts.
+    (The reference orders a class's prompts end|middle|front before averaging; the mean does not depend on it.)
+    Pinning: proda.py imports dassl and cannot run here, so no reference-generated fixture covers the prompt ASSEMBLY;
+    the text tower underneath is pinned by tests/golden/tiny*_clip.npz."""
+    P, n_ctx, _ = ctx.shape
+    emb = sd["token_embedding.weight"][ids].to(dtype)
+    eot = ids.argmax(dim=-1)
+    half = n_ctx // 2
+    out = []
+    for c in range(ids.shape[0]):
+        nl = int(eot[c]) - n_ctx - 2
+        sos, name, rest = emb[c, :1], emb[c, 1 + n_ctx: 1 + n_ctx + nl], emb[c, 1 + n_ctx + nl:]
+        feats = []
+        for p in range(P):
+            cp = ctx[p].to(dtype)
+            if P > 1 and p < P // 4:
+                seq = torch.cat([sos, name, cp, rest])
+            elif P > 1 and p < 2 * (P // 4):
+                seq = torch.cat([sos, cp[:half], name, cp[half:], rest])
+            else:
+                seq = torch.cat([sos, cp, name, rest])
+            feats.append(seq)
+        tf = text_encoder(sd, torch.stack(feats), ids[c:c + 1].expand(P, -1), dtype)
+        out.append(l2_normalize(tf).mean(dim=0))
+    return torch.stack(out)
+
+
 def maple_prompt_learner(sd: SD, ids: Tensor, pl: SD, dtype: torch.dtype = torch.float32):
     """MultiModalPromptLearner.forward (maple.py:170-187): returns (prompts, shared_ctx = proj(ctx),
     deep text prompts, deep visual prompts = per-depth Linear(512->768) of the text prompts)."""

@@ -439,6 +439,43 @@ def test_promptsrc_and_vpt_mirrors():
     assert vp.fixed_embeddings is txf
 
 
+def test_proda_and_prograd_mirrors():
+    """ProDA: prompt-collection classifier with front / middle / end class positions (proda.py:146-222, 316-333);
+    ProGrad: CoOp's forward (prograd.py:272-289) plus the zero-shot teacher."""
+    from clip_calibration_amd.trainers import ProDACLIP, ProGradCLIP, CoOpCLIP
+    from clip_calibration_amd.trainers.prograd import CLIP as ProGradTeacher
+    sd, model = _build("tiny")
+    C, n_ctx, P = 7, 4, 8
+    ids = syn.synthetic_token_ids(C, "tiny", seed=60, n_ctx_placeholders=n_ctx)
+    images = syn.synthetic_images(5, "tiny", seed=60)
+    pd = ProDACLIP(model, ids, n_ctx=n_ctx, n_prompt=P, seed=4, prompts_per_call=20)      # ragged tower calls: 20 + 20 + 16
+    with torch.no_grad():
+        pd.prompt_learner.ctx.mul_(25.0)            # make the context matter (0.02-sigma init barely moves the features)
+    assert pd.prompt_learner.pos.tolist() == [0, 0, 1, 1, 2, 2, 2, 2]
+    ctx = pd.prompt_learner.ctx.detach().float().cpu()
+    logits, imf, txf = pd(images.cuda())
+    with torch.no_grad():
+        r_cls = orc.proda_classifier(sd, ids, ctx)
+        r_l, r_i, _ = orc.clip_logits(orc.encode_image(sd, images), r_cls, sd["logit_scale"].exp())
+        # clip_logits normalises its text argument; ProDA's mean is NOT normalised: redo the last step by hand
+        r_l = sd["logit_scale"].exp() * r_i @ r_cls.t()
+    assert np.abs(txf.cpu().numpy() - r_cls.numpy()).max() < COS_TOL
+    assert np.abs(logits.cpu().numpy() - r_l.numpy()).max() < 100 * COS_TOL
+    assert float(txf.norm(dim=1).max()) < 1.0           # a mean of unit vectors
+    # position matters: with every prompt at the end the classifier differs
+    with torch.no_grad():
+        end_only = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids, ctx[0]), ids))
+    assert np.abs(end_only.numpy() - r_cls.numpy()).max() > 1e-2
+    # ProGrad
+    assert ProGradCLIP is CoOpCLIP
+    teacher = ProGradTeacher(model, syn.synthetic_token_ids(C, "tiny", seed=61))
+    lg, _, tf = teacher(images.cuda())
+    with torch.no_grad():
+        want, _, _ = orc.clip_logits(orc.encode_image(sd, images), orc.encode_text(sd, syn.synthetic_token_ids(C, "tiny", seed=61)),
+                                     sd["logit_scale"].exp())
+    assert np.abs(lg.cpu().numpy() - want.numpy()).max() < 100 * COS_TOL
+
+
 def test_runner_base_to_new_calibration_flow(tmp_path):
     """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
     -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of
