@@ -398,8 +398,8 @@ static bool use_tr() {
 }
 
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
-  CLIPMI_REQUIRE(qkv && out, CLIPMI_ERR_ARG, "attention: null pointer");
   if (N == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(qkv && out, CLIPMI_ERR_ARG, "attention: null pointer");
   CLIPMI_REQUIRE(N > 0 && L > 0 && H > 0, CLIPMI_ERR_SHAPE, "attention: bad shape N=%d L=%d H=%d", N, L, H);
   CLIPMI_REQUIRE((int64_t)N * H < (1ll << 31), CLIPMI_ERR_SHAPE, "attention: grid too large");
   CLIPMI_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, CLIPMI_ERR_ARG, "attention: unaligned pointer");

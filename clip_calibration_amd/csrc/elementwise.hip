@@ -221,8 +221,8 @@ int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStrea
 }
 
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s) {
-  CLIPMI_REQUIRE(image && col, CLIPMI_ERR_ARG, "patchify: null pointer");
   if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(image && col, CLIPMI_ERR_ARG, "patchify: null pointer");
   CLIPMI_REQUIRE(B > 0 && P > 0 && R > 0 && R % P == 0, CLIPMI_ERR_SHAPE, "patchify: R=%d must be a multiple of P=%d", R, P);
   CLIPMI_REQUIRE(Kpad % 64 == 0 && Kpad >= 3 * P * P, CLIPMI_ERR_SHAPE, "patchify: Kpad=%d must be a multiple of 64 >= 3*P*P", Kpad);
   CLIPMI_REQUIRE((uintptr_t)col % 16 == 0, CLIPMI_ERR_ARG, "patchify: col must be 16-byte aligned");
@@ -331,8 +331,8 @@ int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream
 }
 
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s) {
-  CLIPMI_REQUIRE(in && out, CLIPMI_ERR_ARG, "l2_normalize: null pointer");
   if (rows == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(in && out, CLIPMI_ERR_ARG, "l2_normalize: null pointer");
   CLIPMI_REQUIRE(rows > 0 && E > 0, CLIPMI_ERR_SHAPE, "l2_normalize: bad shape");
   const dim3 grid((rows + 3) / 4);
   if (in_dtype == CLIPMI_F32)

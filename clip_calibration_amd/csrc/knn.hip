@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ q, c
 }  // namespace
 
 int launch_knn(const float* q, const float* refs, float* out, int Nq, int Nr, int E, int K, hipStream_t s) {
-  CLIPMI_REQUIRE(q && refs && out, CLIPMI_ERR_ARG, "knn: null pointer");
   if (Nq == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(q && refs && out, CLIPMI_ERR_ARG, "knn: null pointer");
   CLIPMI_REQUIRE(Nq > 0 && Nr > 0 && E > 0 && E % EC == 0, CLIPMI_ERR_SHAPE, "knn: Nq=%d Nr=%d E=%d (E %% 64 == 0)", Nq, Nr, E);
   CLIPMI_REQUIRE(K >= 1 && K <= KMAX && K <= Nr, CLIPMI_ERR_SHAPE, "knn: K=%d must be in [1, min(%d, Nr)]", K, KMAX);
   CLIPMI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)refs % 16 == 0, CLIPMI_ERR_ARG, "knn: unaligned pointer");

@@ -113,9 +113,9 @@ int dispatch(const void* x, int64_t in_stride, const int32_t* gather, const floa
 int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_t* gather_idx, const float* gamma,
                      const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
                      hipStream_t s, half_t* y16, float* stats_out) {
+  if (rows == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x && gamma && beta && y, CLIPMI_ERR_ARG, "layernorm: null pointer");
   CLIPMI_REQUIRE((!y16 && !stats_out) || (y16 && stats_out), CLIPMI_ERR_ARG, "layernorm: y16 and stats_out come together");
-  if (rows == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, CLIPMI_ERR_SHAPE,
                  "layernorm: rows=%d D=%d unsupported (D %% 4 == 0, D <= 4096)", rows, D);
   CLIPMI_REQUIRE(in_stride % 4 == 0 && out_stride % 4 == 0 && in_stride >= D && out_stride >= D, CLIPMI_ERR_SHAPE,

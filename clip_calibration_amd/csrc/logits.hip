@@ -160,9 +160,9 @@ int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs
 
 int launch_ece_accumulate(const float* conf, const int32_t* pred, const int64_t* labels, int n, double* bins, int n_bins,
                           hipStream_t s) {
+  if (n == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(conf && pred && labels && bins, CLIPMI_ERR_ARG, "ece: null pointer");
   CLIPMI_REQUIRE(n_bins > 0 && n_bins <= 1024, CLIPMI_ERR_SHAPE, "ece: n_bins=%d unsupported", n_bins);
-  if (n == 0) return CLIPMI_OK;
   int grid = (n + 255) / 256;
   grid = grid > 1024 ? 1024 : grid;
   hipLaunchKernelGGL(ece_accumulate_kernel, dim3(grid), dim3(256), 3 * (n_bins + 1) * sizeof(double), s, conf, pred, labels, n,

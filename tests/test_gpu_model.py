@@ -569,3 +569,41 @@ def test_stress_residual_magnitudes():
         ref = orc.encode_image(sd, images).numpy()
     assert np.isfinite(got).all()
     assert np.abs(_cos(got, ref) - _cos(ref, ref)).max() < 2e-3
+
+
+def test_empty_and_ragged_batches():
+    """Edge cases the reference meets at the end of a DataLoader epoch: a last batch of any size, including none at all."""
+    from clip_calibration_amd import ops
+    from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
+    from clip_calibration_amd.proximity import knn_dists_device
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    sd, model = _build("tiny")
+    g = syn.GEOMETRIES["tiny"]
+    ids = syn.synthetic_token_ids(3, "tiny", seed=70)
+    zs = ZeroshotCLIP(model, ids)
+    empty = torch.empty(0, 3, g.image_resolution, g.image_resolution, device="cuda")
+    f = model.image_features_f32(empty)
+    assert f.shape == (0, g.embed_dim)
+    assert model.encode_image(empty).shape == (0, g.embed_dim) and model.encode_image(empty).dtype == model.dtype
+    assert model.text_features_f32(ids[:0].cuda()).shape == (0, g.embed_dim)
+    logits, imf, txf, conf, pred = zs.model_inference(empty, want_conf_pred=True)
+    assert logits.shape == (0, 3) and conf.shape == (0,) and pred.shape == (0,)
+    ev = DeviceCalibrationEvaluator(10, keep_samples=True)
+    ev.process(conf, pred, torch.empty(0, dtype=torch.int64))
+    assert float(ev.bins.sum()) == 0.0
+    assert knn_dists_device(torch.empty(0, 128, device="cuda"), torch.randn(5, 128, device="cuda"), 3).shape == (0, 3)
+    # batch sizes around the kernels' internal tile edges give the same rows as the big batch (batch invariance)
+    images = syn.synthetic_images(19, "tiny", seed=70).cuda()
+    full = model.image_features_f32(images).cpu().numpy()
+    for lo, hi in ((0, 1), (1, 4), (4, 19), (7, 8)):
+        part = model.image_features_f32(images[lo:hi]).cpu().numpy()
+        assert np.abs(part - full[lo:hi]).max() < 2e-3 * np.abs(full).max(), (lo, hi)
+    # errors, not garbage
+    with pytest.raises(ValueError):
+        model.image_features_f32(torch.zeros(2, 3, g.image_resolution + 16, g.image_resolution, device="cuda"))
+    with pytest.raises(ValueError):
+        model.text_features_f32(torch.zeros(2, g.context_length - 1, dtype=torch.int64, device="cuda"))
+    with pytest.raises(Exception):
+        knn_dists_device(torch.randn(4, 128, device="cuda"), torch.randn(5, 128, device="cuda"), 6)     # K > Nr
+    with pytest.raises(Exception):
+        model.image_features_f32(torch.zeros(1, 3, g.image_resolution, g.image_resolution))             # host tensor: no CPU path
