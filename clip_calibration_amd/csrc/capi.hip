@@ -140,13 +140,14 @@ int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L,
   return launch_gemm(a, s);
 }
 
-// CLIPMI_LN_FOLD=1 applies ln_1 / ln_2 inside the GEMM epilogues (needs the folded operands).  Off by default: on
-// MI355X at B=256 it measures within 1 % of the separate LayerNorm kernels (the 76 us/layer of LayerNorm it removes
-// come back as exposed epilogue time in the two residual GEMMs; profiles/r01_ln_fold.txt), and the unfused path keeps
-// the two-pass variance.
+// ln_1 / ln_2 are applied inside the GEMM epilogues whenever the folded operands are bound (CLIPMI_LN_FOLD=0 switches
+// back to the separate LayerNorm kernels).  Per residual block at B = 256 (profiles/r01_ln_fold.txt): the two LayerNorm
+// launches (2 x 39 us) disappear; the consumers pay +5-6 us each (row parameters are formed once per tile in the kernel
+// prologue) and the residual producers +13 us each (the fp16 shadow of the stream is another 77 MB in their store
+// burst): net -41 us per block, +3 % end to end.
 bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
   const char* e = getenv("CLIPMI_LN_FOLD");
-  if (!(e && e[0] == '1')) return false;
+  if (e && e[0] == '0') return false;
   for (const auto& b : blocks)
     if (!b.w_qkv_f) return false;
   return !blocks.empty();
@@ -463,6 +464,12 @@ int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspa
   GemmArgs a{};
   a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_fc; a.ldw = D; a.bias = b.b_fc; a.out = w.hid; a.ldo = 4 * D;
   a.out_dtype = CLIPMI_F16; a.M = batch * L; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
+  if (fold_enabled(m->vblocks)) {   // time the kernel exactly as the tower launches it (LayerNorm folded into the epilogue)
+    a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = (D + 255) / 256; a.ln_g = b.g_fc; a.ln_dim = D;
+    a.ln_eps = 1e-5f;
+    if (a.ln_parts > LN_MAX_PARTS) a.ln_parts = LN_MAX_PARTS;
+    (void)hipMemsetAsync(w.stats, 0, (size_t)2 * a.ln_parts * a.M * sizeof(float), s);   // defined row statistics for the timing runs
+  }
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     set_error("profile: hipEventCreate failed");

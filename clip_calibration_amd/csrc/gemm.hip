@@ -106,7 +106,7 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int tiles_m, int& ti
 // The caller must have passed a workgroup barrier after the last main-loop LDS read.
 template <typename T, int EPI, int CH>
 __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
-                                                    int wave_n, int lane, char* patch) {
+                                                    int wave_n, int lane, char* patch, const float2* lnp = nullptr) {
   constexpr int TM = T::TM, TN = T::TN;
   static_assert(T::WTN % 64 == 0 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue works on 64-column slices of the wave tile");
   constexpr int NH = T::WTN / 64;        // 64-column slices per wave tile (1 for the 64-wide wave tiles, 2 for 128)
@@ -136,7 +136,16 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) {
         float rs = 1.f, mrs = 0.f;
-        if (fold) ln_row_params(a, m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16, rs, mrs);
+        if (fold) {
+          const int ml = wave_m * T::WTM + (jc * CH + jj) * 16 + r16;
+          if (lnp) {   // (rstd, mean*rstd) of the tile's rows, put in LDS by the kernel prologue
+            const float2 pr = lnp[ml];
+            rs = pr.x;
+            mrs = pr.y;
+          } else {
+            ln_row_params(a, m0 + ml, rs, mrs);
+          }
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = h * 4 + ii;
@@ -240,7 +249,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 
 template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
-                                         int lane, int wave, char* smem) {
+                                         int lane, int wave, char* smem, const float2* lnp = nullptr) {
   if constexpr (EPI == EPI_RESIDUAL_FOLD) {
     epilogue_residual_fold<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
     return;
@@ -248,7 +257,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
     if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {   // wave-uniform
       __syncthreads();                           // every wave is done with the main-loop LDS image
-      epilogue_f16_staged<T, EPI, 2>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * 144));
+      epilogue_f16_staged<T, EPI, 2>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * 144), lnp);
       return;
     }
   }
@@ -375,6 +384,19 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     a.stamps[blockIdx.x * 8 + 5] = (long long)__smid();
   }
   stage(0, 0);
+  // LayerNorm-fold consumer: the (rstd, mean*rstd) pair of each of the tile's rows, computed once here (behind the first
+  // stage's DMA latency) instead of per lane per row in the epilogue; visible after the loop's first barrier
+  float2* lnp = nullptr;
+  if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+    if (a.ln_stats) {   // block-uniform
+      lnp = reinterpret_cast<float2*>(smem + T::SMEM);
+      for (int t = tid; t < BM; t += NT) {
+        float rs, mrs;
+        ln_row_params(a, m0 + t, rs, mrs);
+        lnp[t] = make_float2(rs, mrs);
+      }
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   }
 
   if (stamp) a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
   if (a.stamps != nullptr) {
     if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -422,8 +444,9 @@ template <typename T, int EPI, bool OUT_F32>
 int launch_tile(KArgs k, hipStream_t s) {
   static bool attr_set = false;
   auto fn = gemm_f16_kernel<T, EPI, OUT_F32>;
+  constexpr int SMEM = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
       (void)hipGetLastError();
     }
     attr_set = true;
@@ -434,7 +457,7 @@ int launch_tile(KArgs k, hipStream_t s) {
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), T::SMEM, s, k);
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), SMEM, s, k);
   return check_launch("gemm_f16_kernel");
 }
 

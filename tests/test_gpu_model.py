@@ -252,9 +252,10 @@ def test_vit_large_towers_vs_oracle(gname, batch):
 
 @pytest.mark.parametrize("gname", ["tiny", "ViT-B/16"])
 def test_layernorm_fold_path(monkeypatch, gname):
-    """CLIPMI_LN_FOLD=1: ln_1 / ln_2 applied inside the GEMM epilogues (gamma folded into the weights, mean / rstd from
-    per-tile row partials).  Same tolerance as the default path, and bit-reproducible run to run."""
-    monkeypatch.setenv("CLIPMI_LN_FOLD", "1")
+    """Default path: ln_1 / ln_2 applied inside the GEMM epilogues (gamma folded into the weights, mean / rstd from
+    per-tile row partials), bit-reproducible run to run; CLIPMI_LN_FOLD=0 = separate LayerNorm kernels.  Both within the
+    same tolerance of the oracle and of each other."""
+    monkeypatch.delenv("CLIPMI_LN_FOLD", raising=False)
     sd, model = _build(gname)
     images = syn.synthetic_images(3, gname, seed=3)
     ids = syn.synthetic_token_ids(6, gname, seed=3)
@@ -270,6 +271,10 @@ def test_layernorm_fold_path(monkeypatch, gname):
     monkeypatch.setenv("CLIPMI_LN_FOLD", "0")
     with torch.no_grad():
         c = model.image_features_f32(images.cuda())
+        tc = model.text_features_f32(ids.cuda())
+    assert not torch.equal(a, c)                                   # really a different code path
+    _feat_close(c.cpu().numpy(), ref_i, "unfolded image tower")
+    _feat_close(tc.cpu().numpy(), ref_t, "unfolded text tower")
     assert np.abs(_cos(a.cpu().numpy(), c.cpu().numpy()) - _cos(c.cpu().numpy(), c.cpu().numpy())).max() < 5e-4
 
 
