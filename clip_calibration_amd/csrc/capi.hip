@@ -102,7 +102,7 @@ int check_block(const clipmi_block_weights& b) {
 // by the residual epilogues); ln_1 / ln_2 are applied inside the in-proj / c_fc GEMM epilogues.
 // folded == false: separate LayerNorm kernels.
 int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
-              hipStream_t s) {
+              hipStream_t s, bool f16res = false) {
   const int M = n_seq * L, H = D / 64;
   int rc;
   GemmArgs a{};
@@ -120,7 +120,7 @@ int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L,
   a = GemmArgs{};
   a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
   a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
-  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; }
+  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
   if ((rc = launch_gemm(a, s))) return rc;
   a = GemmArgs{};
   if (!folded) {
@@ -136,7 +136,7 @@ int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L,
   a = GemmArgs{};
   a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
   a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
-  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; }
+  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
   return launch_gemm(a, s);
 }
 
@@ -153,6 +153,20 @@ bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
   return !blocks.empty();
 }
 
+// Residual-stream precision (needs the fold).  The reference's GPU path keeps the stream in fp16 (clip/model.py:186-187
+// adds fp16 tensors); here it is
+//   image tower: fp16 by default -- the stream IS the fp16 operand copy the fold already writes, so the two residual
+//                GEMMs of a block move 154 MB each instead of 387 MB (+10 % end to end at B = 256); against the fp32
+//                stream the image-side cosine error goes 3.1e-5 -> 8.7e-5 (tools/precision_modes.py), tolerance 1e-3;
+//   text tower:  fp32 with an fp16 shadow -- its features are computed once per class list and reused for every image.
+// CLIPMI_RESIDUAL_F16 = 0 (fp32 everywhere) | v (default) | t | 1 (both towers fp16).
+bool residual_f16_enabled(bool folded, bool vision) {
+  if (!folded) return false;
+  const char* e = getenv("CLIPMI_RESIDUAL_F16");
+  const char mode = e ? e[0] : 'v';
+  return mode == '1' || (vision ? mode == 'v' : mode == 't');
+}
+
 int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
   if (!hook) return CLIPMI_OK;
   CLIPMI_REQUIRE(hook->n_ctx > 0 && hook->n_deep >= 0 && hook->n_deep <= layers - 1, CLIPMI_ERR_SHAPE,
@@ -166,6 +180,7 @@ int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
 int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, hipStream_t s) {
   const int L = m->g.context_length, D = m->g.text_width;
   const bool folded = fold_enabled(m->tblocks);
+  const bool f16res = residual_f16_enabled(folded, false);
   int rc, parts = 1;
   if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, 1, C, L, D, 0, L, s))) return rc;   // input rows of block 0
   for (int i = 0; i < m->g.text_layers; ++i) {
@@ -173,7 +188,7 @@ int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_promp
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * hook->n_ctx * D, C, L, D, 1, hook->n_ctx, s))) return rc;
       if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, C, L, D, 1, hook->n_ctx, s))) return rc;
     }
-    if ((rc = run_block(m->tblocks[i], w, C, L, D, 1, folded, &parts, s))) return rc;
+    if ((rc = run_block(m->tblocks[i], w, C, L, D, 1, folded, &parts, s, f16res))) return rc;
   }
   return CLIPMI_OK;
 }
@@ -182,10 +197,13 @@ int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_promp
 int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, hipStream_t s) {
   const int D = m->g.text_width, E = m->g.embed_dim;
   int rc;
-  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, w.xn, CLIPMI_F16, D, C, D, 1e-5f, s)))
-    return rc;
+  const bool f16res = residual_f16_enabled(fold_enabled(m->tblocks), false);
+  half_t* rows = f16res ? w.att : w.xn;   // fp16 stream mode: w.xn IS the stream, the gathered rows go to the idle attention buffer
+  if (f16res) rc = launch_layernorm(w.xn, CLIPMI_F16, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, rows, CLIPMI_F16, D, C, D, 1e-5f, s);
+  else rc = launch_layernorm(w.xres, CLIPMI_F32, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, rows, CLIPMI_F16, D, C, D, 1e-5f, s);
+  if (rc) return rc;
   GemmArgs a{};
-  a.A = w.xn; a.lda = D; a.W = (const half_t*)m->tw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
+  a.A = rows; a.lda = D; a.W = (const half_t*)m->tw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
   a.M = C; a.N = E; a.K = D; a.epilogue = CLIPMI_EPI_NONE;
   return launch_gemm(a, s);
 }
@@ -384,6 +402,7 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
                                     n_ctx, D, s)))
     return rc;
   const bool folded = fold_enabled(m->vblocks);
+  const bool f16res = residual_f16_enabled(folded, true);
   int parts = 1;
   if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, w.xres, CLIPMI_F32, D, batch * L, D, 1e-5f, s,
                              folded ? w.xn : nullptr, folded ? w.stats : nullptr)))
@@ -393,14 +412,15 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
       if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
     }
-    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s))) return rc;
+    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res))) return rc;
   }
   // ln_post on the class token only, then @ proj (clip/model.py:419-422)
-  if ((rc = launch_layernorm(w.xres, CLIPMI_F32, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, w.xn, CLIPMI_F16, D, batch, D,
-                             1e-5f, s)))
-    return rc;
+  half_t* cls_rows = f16res ? w.att : w.xn;
+  if (f16res) rc = launch_layernorm(w.xn, CLIPMI_F16, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, cls_rows, CLIPMI_F16, D, batch, D, 1e-5f, s);
+  else rc = launch_layernorm(w.xres, CLIPMI_F32, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, cls_rows, CLIPMI_F16, D, batch, D, 1e-5f, s);
+  if (rc) return rc;
   a = GemmArgs{};
-  a.A = w.xn; a.lda = D; a.W = (const half_t*)m->vw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
+  a.A = cls_rows; a.lda = D; a.W = (const half_t*)m->vw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
   a.M = batch; a.N = E; a.K = D; a.epilogue = CLIPMI_EPI_NONE;
   return launch_gemm(a, s);
 }
@@ -416,6 +436,7 @@ int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n
   const int L = m->g.context_length, D = m->g.text_width;
   if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, D, s))) return rc;
   if ((rc = run_text_blocks(m, w, n_prompts, hook, s))) return rc;
+  if (residual_f16_enabled(fold_enabled(m->tblocks), false)) return launch_cast_f16(w.xn, y, dtype, (int64_t)n_prompts * L * D, s);
   return launch_cast_f32(w.xres, y, dtype, (int64_t)n_prompts * L * D, s);
 }
 

@@ -48,7 +48,8 @@ int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
 
 // Extra epilogue used only by the vision tower: scatter patch rows into the token matrix and add the
 // positional embedding (clip/model.py:396-402).
-enum { EPI_PATCH_POS = 100, EPI_RESIDUAL_FOLD = 101 /* BIAS_RESIDUAL + fp16 copy + row partials: own kernel instantiation */ };
+enum { EPI_PATCH_POS = 100, EPI_RESIDUAL_FOLD = 101 /* BIAS_RESIDUAL + fp16 copy + row partials: own kernel instantiation */,
+       EPI_RESIDUAL_FOLD16 = 102 /* same, but the residual stream itself is the fp16 copy: read x16, write x16, no fp32 pass */ };
 
 struct GemmArgs {
   const half_t* A; int64_t lda;
@@ -67,6 +68,7 @@ struct GemmArgs {
   //   stats_out and report the number of partials per row (= its n-tile count) through *parts_out (host pointer)
   const float* ln_stats; int ln_parts; const float* ln_g; int ln_dim; float ln_eps;
   half_t* x16; float* stats_out; int* parts_out;
+  bool residual_f16 = false;   // producer: the residual operand is x16 itself (fp16 stream, updated in place); `residual`/`out` unused
 };
 constexpr int LN_MAX_PARTS = 8;
 int launch_gemm(const GemmArgs& a, hipStream_t s);
@@ -91,6 +93,7 @@ int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos
                         int L, int D, int vocab, hipStream_t s);
 int launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);  // rows[c] = c*L + eot[c]
 int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
+int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStream_t s);
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s);
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,

@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   }
 }
 
+template <typename TO>
+__global__ __launch_bounds__(256) void cast16_kernel(const half_t* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (TO)(float)src[i];
+}
+
 // out[r,:] = in[r,:] / ||in[r,:]||_2, one wave per row, fp32 math
 template <typename TI>
 __global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, float* __restrict__ out, int rows, int E) {
@@ -328,6 +334,21 @@ int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream
     return CLIPMI_ERR_ARG;
   }
   return check_launch("cast_kernel");
+}
+
+int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStream_t s) {
+  if (n == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(src && dst, CLIPMI_ERR_ARG, "cast16: null pointer");
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  if (dtype == CLIPMI_F32)
+    hipLaunchKernelGGL(cast16_kernel<float>, dim3(grid), dim3(256), 0, s, src, (float*)dst, n);
+  else if (dtype == CLIPMI_F16)
+    hipLaunchKernelGGL(cast16_kernel<half_t>, dim3(grid), dim3(256), 0, s, src, (half_t*)dst, n);
+  else {
+    set_error("cast16: bad dtype %d", dtype);
+    return CLIPMI_ERR_ARG;
+  }
+  return check_launch("cast16_kernel");
 }
 
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s) {

@@ -174,7 +174,10 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
 // stream, stores fp16(out) to x16 through the wave-private LDS transpose and writes this tile's row partials.
 // Worked in chunks of 32 rows with a scheduling fence between chunks, so that the residual loads of later chunks are
 // not hoisted over the whole epilogue (the 160-accumulator tile has no registers to spare).
-template <typename T>
+// F16RES: the residual stream IS the fp16 copy (the reference's own GPU precision: clip/model.py:186-187 adds in fp16):
+// the operand is read from x16, the sum is rounded to fp16 and written back in place, the row partials are taken from
+// the ROUNDED values (what the consumer's MFMA will read), and no fp32 pass is made -- 154 MB per launch instead of 387.
+template <typename T, bool F16RES = false>
 __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int tile_n,
                                                        int wave_m, int wave_n, int lane, int wave, char* smem) {
   constexpr int TM = T::TM, TN = T::TN;
@@ -206,8 +209,15 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
         const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m < a.M && n < a.N) {
-          v = acc[i][jc * 2 + jj] + bias[i] + *reinterpret_cast<const f32x4*>(a.residual + (int64_t)m * a.ldo + n);
-          *reinterpret_cast<f32x4*>(out + (int64_t)m * a.ldo + n) = v;
+          if constexpr (F16RES) {
+            const f16x4 r = *reinterpret_cast<const f16x4*>(a.x16 + (int64_t)m * a.ldo + n);
+            v = acc[i][jc * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
+          } else {
+            v = acc[i][jc * 2 + jj] + bias[i] + *reinterpret_cast<const f32x4*>(a.residual + (int64_t)m * a.ldo + n);
+            *reinterpret_cast<f32x4*>(out + (int64_t)m * a.ldo + n) = v;
+          }
           rsum += (v[0] + v[1]) + (v[2] + v[3]);
           rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
@@ -250,8 +260,8 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
                                          int lane, int wave, char* smem, const float2* lnp = nullptr) {
-  if constexpr (EPI == EPI_RESIDUAL_FOLD) {
-    epilogue_residual_fold<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
+  if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) {
+    epilogue_residual_fold<T, EPI == EPI_RESIDUAL_FOLD16>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
     return;
   }
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
@@ -1114,7 +1124,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
     case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s);
     case 12:
-      if constexpr (EPI == EPI_RESIDUAL_FOLD) return launch_tile<T256w16, EPI, OUT_F32>(k, s);   // fold epilogue: 64-column wave tiles only
+      if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) return launch_tile<T256w16, EPI, OUT_F32>(k, s);   // fold epilogue: 64-column wave tiles only
       else return launch_wide<T256w4, EPI, OUT_F32>(k, s);
     default: return launch_tile<T128, EPI, OUT_F32>(k, s);
   }
@@ -1123,7 +1133,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
 }  // namespace
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
-  CLIPMI_REQUIRE(a.A && a.W && a.out, CLIPMI_ERR_ARG, "gemm: null operand");
+  CLIPMI_REQUIRE(a.A && a.W && (a.out || a.residual_f16), CLIPMI_ERR_ARG, "gemm: null operand");
   CLIPMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, CLIPMI_ERR_SHAPE, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
   CLIPMI_REQUIRE(a.K % BK == 0, CLIPMI_ERR_SHAPE, "gemm: K=%d must be a multiple of %d", a.K, BK);
   CLIPMI_REQUIRE(a.N % 4 == 0, CLIPMI_ERR_SHAPE, "gemm: N=%d must be a multiple of 4", a.N);
@@ -1131,7 +1141,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
                  "gemm: leading dimensions must keep 16-byte alignment (lda=%lld ldw=%lld ldo=%lld)", (long long)a.lda,
                  (long long)a.ldw, (long long)a.ldo);
   CLIPMI_REQUIRE(a.lda >= a.K && a.ldw >= a.K && a.ldo >= a.N, CLIPMI_ERR_SHAPE, "gemm: leading dimension too small");
-  CLIPMI_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.out % 16 == 0),
+  CLIPMI_REQUIRE(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.x16 % 16 == 0),
                  CLIPMI_ERR_ARG, "gemm: operands must be 16-byte aligned");
   const bool f32 = a.out_dtype == CLIPMI_F32;
   CLIPMI_REQUIRE(f32 || a.out_dtype == CLIPMI_F16, CLIPMI_ERR_ARG, "gemm: bad out_dtype %d", a.out_dtype);
@@ -1165,6 +1175,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       return f32 ? launch_one<CLIPMI_EPI_BIAS_QUICKGELU, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS_QUICKGELU, false>(k, s, a.parts_out);
     case CLIPMI_EPI_BIAS_RESIDUAL:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
+      if (a.residual_f16) {
+        CLIPMI_REQUIRE(a.x16, CLIPMI_ERR_ARG, "gemm: residual_f16 needs the fp16 stream (x16)");
+        return launch_one<EPI_RESIDUAL_FOLD16, true>(k, s, a.parts_out);
+      }
       CLIPMI_REQUIRE(a.residual && (uintptr_t)a.residual % 16 == 0, CLIPMI_ERR_ARG, "gemm: residual missing/unaligned");
       CLIPMI_REQUIRE(f32, CLIPMI_ERR_ARG, "gemm: the residual stream is fp32");
       if (a.x16) return launch_one<EPI_RESIDUAL_FOLD, true>(k, s, a.parts_out);

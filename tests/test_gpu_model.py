@@ -221,7 +221,11 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle():
     with torch.no_grad():
         lg_ref, _, _ = orc.clip_logits(orc.encode_image(sd, images), t_new, np.exp(4.6052))
     lg_ref_dac = orc.dac_predict(lg_ref.numpy(), conf_ref)
-    assert np.abs(logits.cpu().numpy() - lg_ref_dac).max() < 100 * COS_TOL * 1.5
+    # the DAC factor itself carries the (rtol 5e-3) difference between device- and oracle-produced text features, which at
+    # |logit| ~ 30 would eat the whole logit tolerance: check the row scaling with the factor the device path actually used
+    lg_ref_own = orc.dac_predict(lg_ref.numpy(), cal.class_confidence)
+    assert np.abs(logits.cpu().numpy() - lg_ref_own).max() < 100 * COS_TOL * 1.5
+    assert np.abs(lg_ref_own - lg_ref_dac).max() < 5e-3 * np.abs(lg_ref_dac).max() * 1.01
     labels = syn.synthetic_labels(torch.from_numpy(lg_ref_dac.argmax(1)), C, seed=1)
     ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy(), labels.numpy(), conf_ref)
     from clip_calibration_amd.metrics import ECE
@@ -256,6 +260,7 @@ def test_layernorm_fold_path(monkeypatch, gname):
     per-tile row partials), bit-reproducible run to run; CLIPMI_LN_FOLD=0 = separate LayerNorm kernels.  Both within the
     same tolerance of the oracle and of each other."""
     monkeypatch.delenv("CLIPMI_LN_FOLD", raising=False)
+    monkeypatch.delenv("CLIPMI_RESIDUAL_F16", raising=False)
     sd, model = _build(gname)
     images = syn.synthetic_images(3, gname, seed=3)
     ids = syn.synthetic_token_ids(6, gname, seed=3)
@@ -268,6 +273,14 @@ def test_layernorm_fold_path(monkeypatch, gname):
     assert torch.equal(a, b)
     _feat_close(a.cpu().numpy(), ref_i, "folded image tower")
     _feat_close(t.cpu().numpy(), ref_t, "folded text tower")
+    # residual-stream precision: image tower fp16 by default (the reference's own GPU precision), fp32 on request
+    monkeypatch.setenv("CLIPMI_RESIDUAL_F16", "0")
+    with torch.no_grad():
+        a32 = model.image_features_f32(images.cuda())
+    assert not torch.equal(a, a32)
+    _feat_close(a32.cpu().numpy(), ref_i, "folded image tower, fp32 stream")
+    an, a32n, rn = (x / np.linalg.norm(x, axis=1, keepdims=True) for x in (a.cpu().numpy(), a32.cpu().numpy(), ref_i))
+    assert np.abs(a32n @ rn.T - rn @ rn.T).max() <= np.abs(an @ rn.T - rn @ rn.T).max() + 2e-5      # fp32 stream is at least as close
     monkeypatch.setenv("CLIPMI_LN_FOLD", "0")
     with torch.no_grad():
         c = model.image_features_f32(images.cuda())
@@ -377,7 +390,8 @@ def test_golden_cocoop_and_chunking():
         assert np.abs(txf.cpu().numpy() @ last.T - last @ last.T).max() < COS_TOL      # the LAST image's text features
         probs = orc.softmax_probs(g["cocoop_logits"].astype(np.float64))
         rc, rp = orc.conf_pred(probs)
-        assert np.array_equal(pred.cpu().numpy(), rp) and np.abs(conf.cpu().numpy() - rc).max() < 5e-3
+        # d conf <= |d logit| / 4 (softmax slope) with |d logit| < 100 * COS_TOL
+        assert np.array_equal(pred.cpu().numpy(), rp) and np.abs(conf.cpu().numpy() - rc).max() < 100 * COS_TOL / 4
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])       # chunking is bitwise neutral
 
 
@@ -397,9 +411,17 @@ def test_cocoop_vs_oracle_with_dac_larger_batch():
     with torch.no_grad():
         r_logits, r_f, _ = orc.cocoop_forward(sd, pl, images, ids)
     r_scaled = orc.dac_predict(r_logits.numpy(), dac.numpy())
-    assert np.abs(logits.cpu().numpy() - r_scaled).max() < 100 * COS_TOL * 1.5
+    # DAC scales a row by the factor of its ARG-MAX class: rows whose two best raw logits are closer than the logit
+    # tolerance may legitimately pick the other factor -- judge those on the raw logits only
+    top2 = np.sort(r_logits.numpy(), axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * 100 * COS_TOL
+    assert clear.sum() >= B // 2
+    got = logits.cpu().numpy()
+    assert np.abs(got[clear] - r_scaled[clear]).max() < 100 * COS_TOL * 1.5
+    for b in np.nonzero(~clear)[0]:
+        assert min(np.abs(got[b] - r_logits.numpy()[b] * f).max() for f in dac.numpy()[np.argsort(r_logits.numpy()[b])[-2:]]) < 100 * COS_TOL * 1.5
     rc, rp = orc.conf_pred(orc.softmax_probs(r_scaled.astype(np.float64)))
-    assert np.array_equal(pred.cpu().numpy(), rp)
+    assert np.array_equal(pred.cpu().numpy()[clear], rp[clear])
     assert np.abs(imf.cpu().numpy() @ r_f.numpy().T - (r_f @ r_f.t()).numpy()).max() < COS_TOL
 
 
