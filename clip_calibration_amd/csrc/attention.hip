@@ -345,6 +345,110 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming variant for sequences longer than one key block (ViT-L/14: 257 tokens, ViT-L/14@336: 577): the key
+// blocks (NKT*32 keys) of one (sequence, head) pass through a TWO-slot LDS ring -- block kb+1 is DMA'd while block kb
+// is computed, so the staging latency that the single-buffer kernel above pays once per block (load -> wait ->
+// barrier -> compute, only hidden by the co-resident workgroup) is off the critical path.  With NKT = 4 the ring is
+// 64 KiB, so two workgroups still share a CU and interleave their MFMA and softmax phases.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void attention_stream_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                                  int L, int H, int causal, int nkb) {
+  constexpr int KEYS = NKT * 32;
+  constexpr int OPB = KEYS * 128;      // one operand image
+  constexpr int BUF = 2 * OPB;         // K + V
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = nthr >> 6;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int D = H * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+  const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
+
+  const int q0 = (blockIdx.y * nwaves + wave) * 32;
+  const bool active = q0 < L;  // wave-uniform
+  const int q = q0 + r32;
+  const int qc = q < L ? q : L - 1;
+  f16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(base + (int64_t)qc * ld + ks * 16 + hh * 8);
+
+  const int kswz = (r32 >> 1) & 7;
+  int kro[4], vro[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  {
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int fq = (qq >> 1) & 1;
+    const int lane_base = OPB + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+    vro[0] = lane_base + fq * 64;
+    vro[1] = lane_base + (1 - fq) * 64;
+  }
+  auto stage = [&](int kb, int buf) {
+    char* Ks = smem + buf * BUF;
+    for (int it = wave; it < KEYS / 8; it += nwaves) {   // one wave-instruction = 8 rows x 128 B
+      const int pw = it * 64;
+      const int p = pw + lane;
+      const int row = p >> 3, cs = p & 7;
+      const int koff = ((kb * KEYS + row) * (int)ld + D) * 2;   // rows >= L are outside the descriptor: zero
+      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + pw * 16, koff + ((cs ^ ((row >> 1) & 7)) << 4), 0);
+      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + OPB + pw * 16, koff + D * 2 + ((cs ^ (((row >> 1) & 1) << 2)) << 4), 0);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  float m_run = NEG_BIG;
+  f32x16 lacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+
+  stage(0, 0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // block kb visible to all waves; everybody is done with the other slot (block kb-1)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));   // complete since the wait above (see the persistent kernel)
+    if (kb + 1 < nkb) stage(kb + 1, (kb + 1) & 1);
+    if (active) {
+      const char* b = smem + (kb & 1) * BUF;
+      const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
+      const char* const vread[2] = {b + vro[0], b + vro[1]};
+      const int kb0 = kb * KEYS;
+      if (!causal && kb0 + KEYS <= L)   // block-uniform: full block -> straight-line code
+        attend_block<NKT, NKT, true, 3>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      else
+        attend_block<NKT, NKT, true, 0>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+    }
+  }
+  if (active && q < L) store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
+}
+
+template <int NKT>
+int launch_stream(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
+  constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
+  static bool attr_set = false;
+  auto fn = attention_stream_kernel<NKT>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  const int nqt = (L + 31) / 32;
+  const int qsplit = (nqt + 7) / 8;
+  const int nw = (nqt + qsplit - 1) / qsplit < 4 ? 4 : (nqt + qsplit - 1) / qsplit;   // query tiles spread evenly over the splits
+  const int nkb = (L + NKT * 32 - 1) / (NKT * 32);
+  hipLaunchKernelGGL(fn, dim3(N * H, qsplit), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, nkb);
+  return check_launch("attention_stream_kernel");
+}
+
 template <int NKT, int GROUP, int DENSE>
 int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
@@ -414,6 +518,10 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
       if (!causal && L > 192) return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
       return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
     }
+    // two-slot ring of 128-key blocks: 257 tokens (ViT-L/14) 73 us against 81 us for the single-buffer kernel; at 577 tokens
+    // (ViT-L/14@336) the kernel is bound by its softmax / MFMA issue, not by staging, and the 224-key blocks below are as fast
+    const char* ns = getenv("CLIPMI_ATTN_NO_STREAM");   // A/B aid
+    if (L <= 320 && !(ns && ns[0] == '1')) return launch_stream<4>(qkv, out, N, L, H, causal, s);
   }
   if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
   return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);
