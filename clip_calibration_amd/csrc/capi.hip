@@ -280,6 +280,13 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
+int clipmi_adapter_blend(const float* feats, const float* w1, const float* w2, float ratio, float* out, int B, int E, int H,
+                         clipmi_stream_t stream) {
+  return launch_adapter_blend(feats, w1, w2, ratio, out, B, E, H, (hipStream_t)stream);
+}
+int clipmi_scale_add(const float* a, const float* b, float alpha, float* out, long long n, clipmi_stream_t stream) {
+  return launch_scale_add(a, b, alpha, out, (int64_t)n, (hipStream_t)stream);
+}
 int clipmi_group_mean(const float* in, float* out, int G, int P, int E, clipmi_stream_t stream) {
   return launch_group_mean(in, out, G, P, E, (hipStream_t)stream);
 }

@@ -93,7 +93,51 @@ __global__ __launch_bounds__(256) void per_image_logits_kernel(const float* __re
   }
 }
 
+// CLIP-Adapter (reference trainers/classification/clip_adapter.py:138-172): out[b] = ratio * relu(W2 relu(W1 f[b])) + (1 - ratio) * f[b],
+// both Linears without bias.  One workgroup per image; same shape of work as the CoCoOp meta-net.
+__global__ __launch_bounds__(256) void adapter_blend_kernel(const float* __restrict__ f, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, float ratio, float* __restrict__ out,
+                                                            int E, int H) {
+  extern __shared__ float hid[];   // [H]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* x = f + (int64_t)b * E;
+  for (int h = wave; h < H; h += 4) {
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += w1[(int64_t)h * E + e] * x[e];
+    s = wave_sum(s);
+    if (lane == 0) hid[h] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += w2[(int64_t)e * H + h] * hid[h];
+    out[(int64_t)b * E + e] = ratio * fmaxf(s, 0.f) + (1.f - ratio) * x[e];
+  }
+}
+
+// out = a + alpha * b  (TaskRes: base text features + alpha * learned residual, taskres.py:105-106)
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha,
+                                                        float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] + alpha * b[i];
+}
+
 }  // namespace
+
+int launch_adapter_blend(const float* f, const float* w1, const float* w2, float ratio, float* out, int B, int E, int H, hipStream_t s) {
+  if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(f && w1 && w2 && out, CLIPMI_ERR_ARG, "adapter_blend: null pointer");
+  CLIPMI_REQUIRE(B > 0 && E > 0 && H > 0 && H <= 8192, CLIPMI_ERR_SHAPE, "adapter_blend: B=%d E=%d H=%d", B, E, H);
+  hipLaunchKernelGGL(adapter_blend_kernel, dim3(B), dim3(256), H * sizeof(float), s, f, w1, w2, ratio, out, E, H);
+  return check_launch("adapter_blend_kernel");
+}
+
+int launch_scale_add(const float* a, const float* b, float alpha, float* out, int64_t n, hipStream_t s) {
+  if (n == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(a && b && out && n > 0, CLIPMI_ERR_ARG, "scale_add: null pointer");
+  hipLaunchKernelGGL(scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, alpha, out, n);
+  return check_launch("scale_add_kernel");
+}
 
 int launch_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,
                       float* ctx_shifted, int B, int E, int H, int D, int n_ctx, hipStream_t s) {

@@ -101,6 +101,8 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
 int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         hipStream_t s);
+int launch_adapter_blend(const float* f, const float* w1, const float* w2, float ratio, float* out, int B, int E, int H, hipStream_t s);
+int launch_scale_add(const float* a, const float* b, float alpha, float* out, int64_t n, hipStream_t s);
 int launch_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,
                       float* ctx_shifted, int B, int E, int H, int D, int n_ctx, hipStream_t s);
 int launch_cocoop_prompts(const void* base, int base_dtype, const float* ctx_shifted, half_t* prompts, int nb, int C, int L, int D,

@@ -230,3 +230,26 @@ def group_mean(x: torch.Tensor, group: int) -> torch.Tensor:
     out = torch.empty(rows // group, E, dtype=torch.float32, device=x.device)
     check(lib.clipmi_group_mean(x.data_ptr(), out.data_ptr(), rows // group, group, E, _stream()), "clipmi_group_mean")
     return out
+
+
+def adapter_blend(feats: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, ratio: float) -> torch.Tensor:
+    """ratio * relu(W2 relu(W1 f)) + (1 - ratio) * f  (CLIP-Adapter, clip_adapter.py:138-172)."""
+    feats, w1, w2 = (_dev(t, n, (torch.float32,)) for t, n in ((feats, "feats"), (w1, "w1"), (w2, "w2")))
+    B, E = feats.shape
+    H = w1.shape[0]
+    if w1.shape != (H, E) or w2.shape != (E, H):
+        raise ValueError("adapter_blend: adapter shapes do not chain")
+    out = torch.empty_like(feats)
+    check(lib.clipmi_adapter_blend(feats.data_ptr(), w1.data_ptr(), w2.data_ptr(), float(ratio), out.data_ptr(), B, E, H, _stream()),
+          "clipmi_adapter_blend")
+    return out
+
+
+def scale_add(a: torch.Tensor, b: torch.Tensor, alpha: float) -> torch.Tensor:
+    """a + alpha * b (TaskRes, taskres.py:105-106)."""
+    a, b = _dev(a, "a", (torch.float32,)), _dev(b, "b", (torch.float32,))
+    if a.shape != b.shape:
+        raise ValueError("scale_add: shapes differ")
+    out = torch.empty_like(a)
+    check(lib.clipmi_scale_add(a.data_ptr(), b.data_ptr(), float(alpha), out.data_ptr(), a.numel(), _stream()), "clipmi_scale_add")
+    return out

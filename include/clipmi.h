@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 5
+#define CLIPMI_ABI_VERSION 6
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -108,6 +108,15 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
  * alias logits); conf / pred as above, may be NULL. */
 int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred,
                         int B, int C, clipmi_stream_t stream);
+
+/* CLIP-Adapter's feature blend (trainers/classification/clip_adapter.py:138-172): out[b,:] = ratio * relu(W2 relu(W1 f[b,:]))
+ * + (1 - ratio) * f[b,:]; feats [B,E] (un-normalised image features), w1 [H,E], w2 [E,H], no biases; all fp32. */
+int clipmi_adapter_blend(const float* feats, const float* w1, const float* w2, float ratio, float* out, int B, int E,
+                         int H, clipmi_stream_t stream);
+
+/* TaskRes' classifier (trainers/classification/taskres.py:105-106): out = a + alpha * b over n fp32 elements
+ * (a = base text features, b = learned residual).  out may alias a. */
+int clipmi_scale_add(const float* a, const float* b, float alpha, float* out, long long n, clipmi_stream_t stream);
 
 /* ProDA's classifier (trainers/classification/proda.py:316-333): out[g,:] = mean over the P prompts of class g of the
  * (already L2-normalised) text features in [(g*P + p), :].  fp32; the mean is NOT re-normalised, as in the reference. */

@@ -503,6 +503,44 @@ def test_proda_and_prograd_mirrors():
     assert np.abs(lg.cpu().numpy() - want.numpy()).max() < 100 * COS_TOL
 
 
+def test_clip_adapter_and_taskres_mirrors():
+    """CLIP-Adapter: bias-free bottleneck blended into the image features (clip_adapter.py:138-187); TaskRes: base text
+    features (mean over templates) + alpha * residual (taskres.py:96-210).  Checked against plain fp32 restatements."""
+    from clip_calibration_amd.trainers import CLIPAdapterCLIP, TaskResCLIP
+    sd, model = _build("tiny")
+    C, n_ctx = 5, 4
+    images = syn.synthetic_images(4, "tiny", seed=80)
+    # --- CLIP-Adapter
+    ids = syn.synthetic_token_ids(C, "tiny", seed=80, n_ctx_placeholders=n_ctx)
+    ad = CLIPAdapterCLIP(model, ids, n_ctx=n_ctx, ratio=0.2, seed=6)
+    with torch.no_grad():
+        for p in ad.adapter.parameters():
+            p.copy_((torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.3).to(p))
+    w1, w2 = ad.adapter.fc[0].weight.detach().float().cpu(), ad.adapter.fc[2].weight.detach().float().cpu()
+    ctx = ad.prompt_learner.ctx.detach().float().cpu()
+    logits, imf, txf = ad(images.cuda())
+    with torch.no_grad():
+        f = orc.encode_image(sd, images)
+        f = 0.2 * torch.relu(torch.relu(f @ w1.t()) @ w2.t()) + 0.8 * f                   # clip_adapter.py:170-172
+        t = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids, ctx), ids))
+        want, fi, _ = orc.clip_logits(f, t, sd["logit_scale"].exp())
+    assert np.abs(logits.cpu().numpy() - want.numpy()).max() < 100 * COS_TOL
+    assert np.abs(imf.cpu().numpy() @ fi.numpy().T - (fi @ fi.t()).numpy()).max() < COS_TOL
+    # --- TaskRes (3 templates per class)
+    T = 3
+    tmpl = torch.stack([syn.synthetic_token_ids(C, "tiny", seed=81 + i) for i in range(T)], dim=1)      # [C, T, 77]
+    tr = TaskResCLIP(model, tmpl, alpha=0.5)
+    res = torch.randn(C, syn.GEOMETRIES["tiny"].embed_dim, generator=torch.Generator().manual_seed(3)) * 0.05
+    with torch.no_grad():
+        tr.prompt_learner.text_feature_residuals.copy_(res.to(tr.prompt_learner.text_feature_residuals))
+    logits, imf, txf = tr(images.cuda())
+    with torch.no_grad():
+        base = torch.stack([orc.encode_text(sd, tmpl[:, i]) for i in range(T)], dim=1).mean(dim=1)        # taskres.py:131
+        want, _, tn = orc.clip_logits(orc.encode_image(sd, images), base + 0.5 * res, sd["logit_scale"].exp())
+    assert np.abs(logits.cpu().numpy() - want.numpy()).max() < 100 * COS_TOL
+    assert np.abs(txf.cpu().numpy() @ tn.numpy().T - (tn @ tn.t()).numpy()).max() < COS_TOL
+
+
 def test_runner_base_to_new_calibration_flow(tmp_path):
     """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
     -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of
