@@ -157,7 +157,7 @@ bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
 // adds fp16 tensors); here it is
 //   image tower: fp16 by default -- the stream IS the fp16 operand copy the fold already writes, so the two residual
 //                GEMMs of a block move 154 MB each instead of 387 MB (+10 % end to end at B = 256); against the fp32
-//                stream the image-side cosine error goes 3.1e-5 -> 8.7e-5 (tools/precision_modes.py), tolerance 1e-3;
+//                stream the image-side cosine error goes 3.1e-5 -> 8.7e-5 (tests/precision_modes.py), tolerance 1e-3;
 //   text tower:  fp32 with an fp16 shadow -- its features are computed once per class list and reused for every image.
 // CLIPMI_RESIDUAL_F16 = 0 (fp32 everywhere) | v (default) | t | 1 (both towers fp16).
 bool residual_f16_enabled(bool folded, bool vision) {

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Tuning aid: cosine-logit error of the towers against the CPU oracle under the residual-stream precision modes
+"""Checker script (lives under tests/ because it uses the oracle): cosine-logit error of the towers against the CPU oracle under the residual-stream precision modes
 (CLIPMI_RESIDUAL_F16 unset / v / t / 1), ViT-B/16 geometry, zero-shot and CoOp text sides."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from clip_calibration_amd import synthetic as syn
 from clip_calibration_amd.model import build_model
 from clip_calibration_amd.trainers import CoOpCLIP
