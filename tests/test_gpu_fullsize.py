@@ -1,0 +1,133 @@
+"""BASELINE configs[1] at FULL size on a real MI355X (ViT-B/16, batch 256, 1000 prompts): size-independent properties of
+the path, plus the oracle on a subset of the rows.  The oracle cannot run 256 images x 1000 prompts in a test's time, so
+the full-size run is pinned by properties that do not depend on knowing the answer:
+
+* determinism (bitwise) and batch invariance (an image's features do not depend on what else is in the batch);
+* equivariance: permuting images permutes logit rows, permuting prompts permutes logit columns (bitwise);
+* linearity of the logits in the scale (exact for a power of two), DAC with unit factors is the identity;
+* conf / pred are the softmax top-1 of the returned logits (pred exact);
+* ECE accumulators are additive over any split of the batch (counts exact) and invariant to sample order;
+* a 16-image slice of the full batch agrees with the CPU oracle to the north-star tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clip_calibration_amd import synthetic as syn  # noqa: E402
+from oracle import clip_oracle as orc  # noqa: E402  (checker only)
+
+COS_TOL = 1e-3
+G, B, C = "ViT-B/16", 256, 1000
+
+
+@pytest.fixture(scope="module")
+def full():
+    from clip_calibration_amd.model import build_model
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    sd = syn.synthetic_state_dict(G, seed=0)
+    model = build_model(dict(sd), {"trainer": "ZeroshotCLIP"}).cuda()
+    ids = syn.synthetic_token_ids(C, G, seed=0)
+    zs = ZeroshotCLIP(model, ids)
+    images = syn.synthetic_images(B, G, seed=0, device="cuda")
+    with torch.no_grad():
+        out = zs.model_inference(images, want_conf_pred=True)
+    return dict(sd=sd, model=model, ids=ids, zs=zs, images=images, out=out)
+
+
+def test_determinism_and_batch_invariance(full):
+    zs, images = full["zs"], full["images"]
+    logits, imf, txf, conf, pred = full["out"]
+    with torch.no_grad():
+        again = zs.model_inference(images, want_conf_pred=True)
+    assert all(torch.equal(a, b) for a, b in zip(full["out"], again))              # bitwise, run to run
+    assert logits.shape == (B, C) and torch.isfinite(logits).all()
+    np.testing.assert_allclose(imf.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    np.testing.assert_allclose(txf.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+    # the same images in batches of 32 / 1 / ragged: same features up to the accumulation order of a different tile shape
+    with torch.no_grad():
+        parts = torch.cat([zs.model_inference(images[i:i + 32])[1] for i in range(0, B, 32)])
+        single = zs.model_inference(images[77:78])[1]
+        ragged = zs.model_inference(images[200:256 - 13])[1]
+    assert (parts - imf).abs().max() < 2e-4
+    assert (single - imf[77:78]).abs().max() < 2e-4
+    assert (ragged - imf[200:243]).abs().max() < 2e-4
+
+
+def test_equivariance_and_linearity(full):
+    from clip_calibration_amd import ops
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    zs, images, ids, model = full["zs"], full["images"], full["ids"], full["model"]
+    logits, imf, txf, conf, pred = full["out"]
+    g = torch.Generator().manual_seed(5)
+    pi, pc = torch.randperm(B, generator=g), torch.randperm(C, generator=g)
+    with torch.no_grad():
+        lp = zs.model_inference(images[pi.cuda()])[0]
+        zs_c = ZeroshotCLIP(model, ids[pc])
+        lc = zs_c.model_inference(images)[0]
+    # a row's arithmetic does not depend on its position inside a 256-row tile, nor a prompt's on its column
+    assert (lp - logits[pi.cuda()]).abs().max() < 100 * 2e-4
+    assert (lc - logits[:, pc.cuda()]).abs().max() < 100 * 2e-4
+    assert torch.equal(zs_c.text_features, zs.text_features[pc.cuda()]) or (zs_c.text_features - zs.text_features[pc.cuda()]).abs().max() < 2e-4
+    # the fused tail alone: exact equivariance, exact scale linearity, unit DAC = identity
+    l1, c1, p1 = ops.logits_fused(imf, txf, zs.scale, None, True)
+    assert torch.equal(l1, logits) and torch.equal(p1, pred) and torch.equal(c1, conf)
+    l2, _, _ = ops.logits_fused(imf[pi.cuda()].contiguous(), txf[pc.cuda()].contiguous(), zs.scale, None, True)
+    assert torch.equal(l2, logits[pi.cuda()][:, pc.cuda()])
+    l3, _, p3 = ops.logits_fused(imf, txf, 2.0 * zs.scale, None, True)
+    assert torch.equal(l3, 2.0 * logits) and torch.equal(p3, pred)
+    l4, c4, p4 = ops.logits_fused(imf, txf, zs.scale, torch.ones(C, device="cuda"), True)
+    assert torch.equal(l4, logits) and torch.equal(p4, pred) and torch.equal(c4, conf)
+    # conf / pred are the softmax top-1 of the logits that came back
+    lg = logits.double().cpu().numpy()
+    probs = orc.softmax_probs(lg)
+    rc, rp = orc.conf_pred(probs)
+    assert np.array_equal(pred.cpu().numpy(), rp)
+    assert np.abs(conf.cpu().numpy() - rc).max() < 1e-5
+
+
+def test_ece_accumulation_is_additive(full):
+    from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
+    from clip_calibration_amd.metrics import ECE, MCE
+    logits, imf, txf, conf, pred = full["out"]
+    labels = syn.synthetic_labels(pred, C, seed=1).cuda()
+    whole = DeviceCalibrationEvaluator(10, keep_samples=True)
+    whole.process(conf, pred, labels)
+    pieces = DeviceCalibrationEvaluator(10)
+    for lo, hi in ((0, 1), (1, 100), (100, 100), (100, 256)):
+        pieces.process(conf[lo:hi], pred[lo:hi], labels[lo:hi])
+    shuffled = DeviceCalibrationEvaluator(10)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(9)).cuda()
+    shuffled.process(conf[perm].contiguous(), pred[perm].contiguous(), labels[perm].contiguous())
+    bw = whole.bins.cpu().numpy().reshape(3, 11)
+    for other in (pieces, shuffled):
+        bo = other.bins.cpu().numpy().reshape(3, 11)
+        assert np.array_equal(bw[0], bo[0]) and np.array_equal(bw[2], bo[2])       # counts and correct-counts exactly
+        np.testing.assert_allclose(bw[1], bo[1], rtol=1e-12, atol=1e-12)
+    assert bw[0].sum() == B
+    res = whole.evaluate()
+    c, p, l = conf.cpu().numpy().astype(np.float64), pred.cpu().numpy(), labels.cpu().numpy()
+    assert res["ece"] == pytest.approx(100.0 * orc.ece(c, p, l, 10), abs=1e-9)
+    assert res["mce"] == pytest.approx(100.0 * orc.mce(c, p, l, 10), abs=1e-9)
+    assert res["ace"] == pytest.approx(100.0 * orc.ace(c, p, l, 10), abs=1e-6)
+    assert res["ece"] == pytest.approx(100.0 * ECE(c, p, l, 10), abs=1e-9) and res["mce"] == pytest.approx(100.0 * MCE(c, p, l, 10), abs=1e-9)
+    assert 0.0 <= res["accuracy"] <= 100.0 and 60.0 < res["accuracy"] < 80.0       # labels agree with pred w.p. 0.7 + 0.3/C
+
+
+def test_slice_of_the_full_batch_against_the_oracle(full):
+    """16 rows of the 256-image batch x all 1000 prompts against the CPU oracle (north-star tolerance)."""
+    sd, ids, images = full["sd"], full["ids"], full["images"]
+    logits, imf, txf, conf, pred = full["out"]
+    rows = torch.arange(120, 136)
+    with torch.no_grad():
+        ri = orc.l2_normalize(orc.encode_image(sd, images[rows.cuda()].cpu()))
+        rt = orc.l2_normalize(orc.encode_text(sd, ids))
+        r_logits = (sd["logit_scale"].exp() * ri) @ rt.t()
+    got = logits[rows.cuda()].cpu().numpy()
+    scale = float(sd["logit_scale"].exp())
+    assert np.abs(got - r_logits.numpy()).max() / scale < COS_TOL
+    labels = syn.synthetic_labels(torch.from_numpy(r_logits.numpy().argmax(1)), C, seed=2)
+    ece_ref, _, _ = orc.calibrated_ece(r_logits.numpy(), labels.numpy(), None)
+    from clip_calibration_amd.metrics import ECE
+    assert abs(ECE(conf[rows.cuda()].cpu().numpy(), pred[rows.cuda()].cpu().numpy(), labels.numpy()) - ece_ref) < 1e-3
