@@ -131,3 +131,65 @@ def test_slice_of_the_full_batch_against_the_oracle(full):
     ece_ref, _, _ = orc.calibrated_ece(r_logits.numpy(), labels.numpy(), None)
     from clip_calibration_amd.metrics import ECE
     assert abs(ECE(conf[rows.cuda()].cpu().numpy(), pred[rows.cuda()].cpu().numpy(), labels.numpy()) - ece_ref) < 1e-3
+
+
+def test_config3_coop_dac_full_size(full):
+    """BASELINE configs[2]: CoOp (16 context tokens) base->new with DAC, 256 images x 500 classes.  Properties: cached text
+    features are reused; the fused DAC equals the unfused logits followed by the stand-alone row pass (bitwise); a positive
+    per-class factor never changes the prediction; TempScaling's scalar commutes with the matmul."""
+    from clip_calibration_amd import ops
+    from clip_calibration_amd.dac import DistanseAwareCalibration, scale_logits_
+    from clip_calibration_amd.trainers import CoOpCLIP, CustomCLIPCalibration, ZeroshotCLIP
+    model, images = full["model"], full["images"]
+    Cn, n_ctx = 500, 16
+    ids_new = syn.synthetic_token_ids(Cn, G, seed=21, n_ctx_placeholders=n_ctx)
+    ids_base = syn.synthetic_token_ids(Cn, G, seed=20, n_ctx_placeholders=n_ctx)
+    coop_new = CoOpCLIP(model, ids_new, n_ctx=n_ctx, logit_scale=1.0, seed=3)
+    coop_base = CoOpCLIP(model, ids_base, n_ctx=n_ctx, logit_scale=1.0, seed=3)
+    zs_new = ZeroshotCLIP(model, syn.synthetic_token_ids(Cn, G, seed=21))
+    zs_base = ZeroshotCLIP(model, syn.synthetic_token_ids(Cn, G, seed=20))
+    t_new = coop_new.text_features()
+    assert coop_new.text_features() is t_new
+    cal = DistanseAwareCalibration()
+    cal.fit(zs_base.text_features.cpu().numpy(), zs_new.text_features.cpu().numpy(),
+            coop_base.text_features().cpu().numpy(), t_new.cpu().numpy(), 5)
+    cc = cal.class_confidence
+    assert cc.shape == (Cn,) and np.isfinite(cc).all() and (cc > 0).all()
+    dacc = cal.class_confidence_device("cuda")
+    calib = CustomCLIPCalibration(coop_new).cuda()
+    with torch.no_grad():
+        fused = calib(images, dac_conf=dacc, want_conf_pred=True)
+        plain = calib(images, want_conf_pred=True)
+    assert torch.equal(fused[4], plain[4])                                        # positive factors keep the arg-max
+    manual = plain[0].clone()
+    scale_logits_(manual, dacc)
+    assert torch.equal(manual, fused[0])                                          # fused DAC == logits then the row pass
+    # numpy-contract predict on a slice agrees with the fused rows
+    sl = cal.predict(plain[0][:32].cpu().numpy().astype(np.float64))
+    assert np.array_equal(sl, fused[0][:32].cpu().numpy())
+    # TempScaling scalar: cosine base logits x exp(4.6052) == logits at that scale
+    cos = ops.logits_fused(plain[1], plain[2], 1.0, None, False)[0]
+    assert (cos * float(np.exp(4.6052)) - plain[0]).abs().max() < 1e-3
+    assert cos.abs().max() <= 1.0 + 1e-5
+
+
+def test_config5_vit_l14_336_full_batch():
+    """BASELINE configs[4] per-GPU shape: ViT-L/14@336px, batch 64 (577 tokens, 24 layers, width 1024).  Determinism, batch
+    invariance, and one image of the batch against the CPU oracle."""
+    from clip_calibration_amd.model import build_model
+    gname = "ViT-L/14@336px"
+    sd = syn.synthetic_state_dict(gname, seed=0)
+    model = build_model(dict(sd), None).cuda()
+    images = syn.synthetic_images(64, gname, seed=4, device="cuda")
+    with torch.no_grad():
+        a = model.image_features_f32(images)
+        b = model.image_features_f32(images)
+        parts = torch.cat([model.image_features_f32(images[i:i + 8]) for i in range(0, 64, 8)])
+        ref = orc.encode_image(sd, images[37:38].cpu()).numpy()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    an, pn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(parts, dim=1)
+    assert (an - pn).abs().max() < 2e-4
+    rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
+    got = an.cpu().numpy()
+    assert abs(float(got[37] @ rn[0]) - 1.0) < COS_TOL
+    assert np.abs(got @ rn.T)[np.arange(64) != 37].max() < 1.0 - 1e-3               # and the other rows are other images
