@@ -193,3 +193,34 @@ def test_config5_vit_l14_336_full_batch():
     got = an.cpu().numpy()
     assert abs(float(got[37] @ rn[0]) - 1.0) < COS_TOL
     assert np.abs(got @ rn.T)[np.arange(64) != 37].max() < 1.0 - 1e-3               # and the other rows are other images
+
+
+def test_config4_dataset_sweep_class_counts():
+    """BASELINE configs[3]: the 11-dataset base/new sweep at the per-GPU batch of 128 changes only C (SURVEY §8(d):
+    C_base / C_new of the 11 datasets).  Fused logits + DAC + softmax top-1 + ECE bins for every one of those class counts
+    against numpy on the same normalised features."""
+    from clip_calibration_amd import ops
+    from clip_calibration_amd.metrics import bin_statistics
+    counts = sorted({50, 19, 98, 51, 199, 24, 5, 500, 18, 198, 23})
+    rng = np.random.default_rng(4)
+    img = rng.normal(size=(128, 512)).astype(np.float32)
+    img /= np.linalg.norm(img, axis=1, keepdims=True)
+    imgd = torch.from_numpy(img).cuda()
+    for Cn in counts:
+        txt = rng.normal(size=(Cn, 512)).astype(np.float32)
+        txt /= np.linalg.norm(txt, axis=1, keepdims=True)
+        dac = rng.uniform(0.7, 1.3, Cn).astype(np.float32)
+        logits, conf, pred = ops.logits_fused(imgd, torch.from_numpy(txt).cuda(), 100.0, torch.from_numpy(dac).cuda(), True)
+        want = orc.dac_predict((100.0 * img.astype(np.float64)) @ txt.astype(np.float64).T, dac.astype(np.float64))
+        assert np.abs(logits.cpu().numpy() - want).max() < 2e-3, Cn
+        rc, rp = orc.conf_pred(orc.softmax_probs(want))
+        raw = (img.astype(np.float64)) @ txt.astype(np.float64).T
+        top2 = np.sort(raw, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-5
+        assert np.array_equal(pred.cpu().numpy()[clear], rp[clear]), Cn
+        assert np.abs(conf.cpu().numpy()[clear] - rc[clear]).max() < 1e-3, Cn
+        labels = torch.from_numpy(rng.integers(0, Cn, 128)).cuda()
+        bins = torch.zeros(33, dtype=torch.float64, device="cuda")
+        ops.ece_accumulate(conf, pred, labels, bins, 10)
+        ref_bins = bin_statistics(conf.cpu().numpy(), pred.cpu().numpy(), labels.cpu().numpy(), 10)
+        assert np.array_equal(bins.cpu().numpy().reshape(3, 11)[[0, 2]], ref_bins[[0, 2]]), Cn
