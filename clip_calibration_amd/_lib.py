@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL16_RELU = 0, 1, 2, 3, 4, 5
 
 
 class ClipmiError(RuntimeError):
@@ -74,6 +74,11 @@ _SIGNATURES = {
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipmi_calibrate_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "clipmi_im2col3x3_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_im2col3x3_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_avgpool_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_attnpool_tokens": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "clipmi_attnpool": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipmi_adapter_blend": (_i, [_vp, _vp, _vp, C.c_float, _vp, _i, _i, _i, _vp]),
     "clipmi_scale_add": (_i, [_vp, _vp, C.c_float, _vp, C.c_longlong, _vp]),
     "clipmi_group_mean": (_i, [_vp, _vp, _i, _i, _i, _vp]),

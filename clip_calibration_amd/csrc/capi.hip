@@ -244,9 +244,9 @@ const char* clipmi_strerror(int code) {
 const char* clipmi_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- operator level
-int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* residual,
+int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
                     void* out, int64_t ldo, int out_dtype, int M, int N, int K, int epilogue, clipmi_stream_t stream) {
-  CLIPMI_REQUIRE(epilogue >= CLIPMI_EPI_NONE && epilogue <= CLIPMI_EPI_BIAS_RESIDUAL, CLIPMI_ERR_ARG, "gemm: bad epilogue %d", epilogue);
+  CLIPMI_REQUIRE(epilogue >= CLIPMI_EPI_NONE && epilogue <= CLIPMI_EPI_BIAS_RESIDUAL16_RELU, CLIPMI_ERR_ARG, "gemm: bad epilogue %d", epilogue);
   if (M == 0) return CLIPMI_OK;
   GemmArgs a{};
   a.A = (const half_t*)A; a.lda = lda; a.W = (const half_t*)W; a.ldw = ldw; a.bias = bias; a.residual = residual;
@@ -279,6 +279,22 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
+}
+int clipmi_im2col3x3_nchw(const void* image, int image_dtype, void* col, int B, int Cin, int H, int W, int stride, int Kpad,
+                          clipmi_stream_t stream) {
+  return launch_im2col3x3_nchw(image, image_dtype, (half_t*)col, B, Cin, H, W, stride, Kpad, (hipStream_t)stream);
+}
+int clipmi_im2col3x3_nhwc(const void* x, void* col, int B, int H, int W, int C, int Kpad, clipmi_stream_t stream) {
+  return launch_im2col3x3_nhwc((const half_t*)x, (half_t*)col, B, H, W, C, Kpad, (hipStream_t)stream);
+}
+int clipmi_avgpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int k, clipmi_stream_t stream) {
+  return launch_avgpool_nhwc((const half_t*)x, (half_t*)y, B, H, W, C, k, (hipStream_t)stream);
+}
+int clipmi_attnpool_tokens(const void* x, const float* pos, void* tokens, int B, int HW, int C, clipmi_stream_t stream) {
+  return launch_attnpool_tokens((const half_t*)x, pos, (half_t*)tokens, B, HW, C, (hipStream_t)stream);
+}
+int clipmi_attnpool(const void* q, const void* kv, void* out, int B, int T, int heads, clipmi_stream_t stream) {
+  return launch_attnpool((const half_t*)q, (const half_t*)kv, (half_t*)out, B, T, heads, (hipStream_t)stream);
 }
 int clipmi_adapter_blend(const float* feats, const float* w1, const float* w2, float ratio, float* out, int B, int E, int H,
                          clipmi_stream_t stream) {

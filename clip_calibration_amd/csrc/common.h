@@ -55,7 +55,7 @@ struct GemmArgs {
   const half_t* A; int64_t lda;
   const half_t* W; int64_t ldw;
   const float* bias;
-  const float* residual;
+  const void* residual;   // fp32 [M,N] (BIAS_RESIDUAL) or fp16 [M,N] (BIAS_RESIDUAL16_RELU), ld = ldo
   void* out; int64_t ldo; int out_dtype;
   int M, N, K, epilogue;
   // EPI_PATCH_POS: out row = (m / patches) * tokens + (m % patches) + 1, plus pos[(m % patches) + 1][n]
@@ -101,6 +101,11 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
 int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         hipStream_t s);
+int launch_im2col3x3_nchw(const void* image, int dtype, half_t* col, int B, int Cin, int H, int W, int stride, int Kpad, hipStream_t s);
+int launch_im2col3x3_nhwc(const half_t* x, half_t* col, int B, int H, int W, int C, int Kpad, hipStream_t s);
+int launch_avgpool_nhwc(const half_t* x, half_t* y, int B, int H, int W, int C, int k, hipStream_t s);
+int launch_attnpool_tokens(const half_t* x, const float* pos, half_t* tokens, int B, int HW, int C, hipStream_t s);
+int launch_attnpool(const half_t* q, const half_t* kv, half_t* out, int B, int T, int heads, hipStream_t s);
 int launch_adapter_blend(const float* f, const float* w1, const float* w2, float ratio, float* out, int B, int E, int H, hipStream_t s);
 int launch_scale_add(const float* a, const float* b, float alpha, float* out, int64_t n, hipStream_t s);
 int launch_cocoop_ctx(const float* img_n, const float* w1, const float* b1, const float* w2, const float* b2, const float* ctx,

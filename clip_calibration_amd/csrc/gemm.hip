@@ -29,6 +29,7 @@ struct KArgs {
   const half_t* W; int64_t ldw;
   const float* bias;
   const float* residual;
+  const half_t* residual16;   // BIAS_RESIDUAL16_RELU
   void* out; int64_t ldo;
   int M, N, K;
   const float* pos; int patches; int tokens;
@@ -153,6 +154,18 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
+            const int mr = m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16;
+            const int nr = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+            if (mr < a.M && nr < a.N) {
+              const f16x4 r = *reinterpret_cast<const f16x4*>(a.residual16 + (int64_t)mr * a.ldo + nr);
+              v += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+            }
+          }
+          if constexpr (EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (ii * 16 + g4 * 4) * 2) =
               f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -306,9 +319,17 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
         if (a.ln_stats) b -= mrs * *reinterpret_cast<const f32x4*>(a.ln_g + n);
         v = v * rs + b;
       }
-      if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL) {
+      if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL || EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
         v += b;
+      }
+      if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(a.residual16 + orow * a.ldo + n);
+        v += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      }
+      if constexpr (EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
@@ -1099,6 +1120,16 @@ int pick_variant(const KArgs& k) {
   return best;
 }
 
+// the convolution epilogues (ModifiedResNet, SURVEY f-4) only come in the three cost-model configurations
+template <int EPI, bool OUT_F32>
+int launch_basic(const KArgs& k, hipStream_t s) {
+  switch (pick_variant(k)) {
+    case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
+    case 0: return launch_tile<T128, EPI, OUT_F32>(k, s);
+    default: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
+  }
+}
+
 template <int EPI, bool OUT_F32>
 int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
   int variant = pick_variant(k);
@@ -1147,7 +1178,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   CLIPMI_REQUIRE(f32 || a.out_dtype == CLIPMI_F16, CLIPMI_ERR_ARG, "gemm: bad out_dtype %d", a.out_dtype);
 
   KArgs k;
-  k.A = a.A; k.lda = a.lda; k.W = a.W; k.ldw = a.ldw; k.bias = a.bias; k.residual = a.residual;
+  k.A = a.A; k.lda = a.lda; k.W = a.W; k.ldw = a.ldw; k.bias = a.bias; k.residual = static_cast<const float*>(a.residual);
+  k.residual16 = static_cast<const half_t*>(a.residual);
   k.out = a.out; k.ldo = a.ldo; k.M = a.M; k.N = a.N; k.K = a.K;
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
@@ -1183,6 +1215,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       CLIPMI_REQUIRE(f32, CLIPMI_ERR_ARG, "gemm: the residual stream is fp32");
       if (a.x16) return launch_one<EPI_RESIDUAL_FOLD, true>(k, s, a.parts_out);
       return launch_one<CLIPMI_EPI_BIAS_RESIDUAL, true>(k, s, a.parts_out);
+    case CLIPMI_EPI_BIAS_RELU:
+      CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
+      return f32 ? launch_basic<CLIPMI_EPI_BIAS_RELU, true>(k, s) : launch_basic<CLIPMI_EPI_BIAS_RELU, false>(k, s);
+    case CLIPMI_EPI_BIAS_RESIDUAL16_RELU:
+      CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
+      CLIPMI_REQUIRE(a.residual && (uintptr_t)a.residual % 8 == 0 && !f32, CLIPMI_ERR_ARG, "gemm: BIAS_RESIDUAL16_RELU needs an fp16 residual and fp16 output");
+      return launch_basic<CLIPMI_EPI_BIAS_RESIDUAL16_RELU, false>(k, s);
     case EPI_PATCH_POS:
       CLIPMI_REQUIRE(a.pos && a.patches > 0 && a.tokens > a.patches && f32, CLIPMI_ERR_ARG, "gemm: bad patch epilogue");
       return launch_one<EPI_PATCH_POS, true>(k, s, a.parts_out);

@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from . import _lib, ops
 from ._lib import F16, F32, check, lib
-from .synthetic import ClipGeometry, geometry_from_state_dict
+from .resnet import ModifiedResNet
+from .synthetic import ClipGeometry, geometry_from_state_dict, resnet_config_from_state_dict
 
 _DT = {torch.float16: F16, torch.float32: F32}
 
@@ -79,7 +80,10 @@ class _Conv(nn.Module):
 
 
 _FP16_SUFFIXES = ("attn.in_proj_weight", "attn.in_proj_bias", "out_proj.weight", "out_proj.bias", "c_fc.weight",
-                  "c_fc.bias", "c_proj.weight", "c_proj.bias", "conv1.weight")
+                  "c_fc.bias", "c_proj.weight", "c_proj.bias", "conv1.weight",
+                  # ModifiedResNet: every Conv2d and the attention pool's Linears (clip/model.py:636-639)
+                  "conv2.weight", "conv3.weight", "downsample.0.weight", "q_proj.weight", "q_proj.bias", "k_proj.weight",
+                  "k_proj.bias", "v_proj.weight", "v_proj.bias")
 _FP16_NAMES = ("visual.proj", "text_projection")
 
 
@@ -142,13 +146,17 @@ class VisionTransformer(nn.Module):
 class CLIP(nn.Module):
     """Attribute surface of the reference ``CLIP`` (clip/model.py:481-629), HIP inside."""
 
-    def __init__(self, geom: ClipGeometry, design_details: Optional[dict] = None):
+    def __init__(self, geom: ClipGeometry, design_details: Optional[dict] = None, resnet: Optional[dict] = None):
         super().__init__()
         self.geometry = geom
         self.design_details = dict(design_details or {"trainer": "CoOp"})
         self.context_length = geom.context_length
         self.vocab_size = geom.vocab_size
-        self.visual = VisionTransformer(self, geom)
+        self.is_resnet = resnet is not None
+        if resnet is not None:      # clip/model.py:502-510: vision_layers is a tuple -> ModifiedResNet, heads = width * 32 // 64
+            self.visual = ModifiedResNet(resnet["layers"], geom.embed_dim, resnet["width"] * 32 // 64, geom.image_resolution, resnet["width"])
+        else:
+            self.visual = VisionTransformer(self, geom)
         self.transformer = TextTransformer(self, geom.transformer_width, geom.transformer_layers)
         self.token_embedding = nn.Embedding(geom.vocab_size, geom.transformer_width)
         self.positional_embedding = nn.Parameter(torch.empty(geom.context_length, geom.transformer_width))
@@ -182,6 +190,8 @@ class CLIP(nn.Module):
 
     def ivlp_vision_prompts(self):
         """(shallow, deep list) for the image tower, (None, None) for every other design."""
+        if self.is_resnet:
+            return None, None
         vpt = getattr(self.visual, "VPT", None)
         if vpt is None:
             return None, None
@@ -273,16 +283,18 @@ class CLIP(nn.Module):
             return arr
 
         v = self.visual
-        k = 3 * g.vision_patch_size ** 2
-        kpad = (k + 63) // 64 * 64
-        conv = torch.zeros(g.vision_width, kpad, dtype=torch.float16, device=dev)
-        conv[:, :k] = v.conv1.weight.detach().reshape(g.vision_width, k).to(torch.float16)
-        keep.append(conv)
-        vb = blocks(v.transformer.resblocks)
-        vw = _lib.VisionWeights(conv.data_ptr(), f32(v.class_embedding), f32(v.positional_embedding),
-                                f32(v.ln_pre.weight), f32(v.ln_pre.bias), f32(v.ln_post.weight), f32(v.ln_post.bias),
-                                f16(v.proj.detach().t()), vb)
-        check(lib.clipmi_set_vision_weights(self._handle, C.byref(vw)), "clipmi_set_vision_weights")
+        vb = None
+        if not self.is_resnet:      # the ModifiedResNet tower packs its own operands (resnet.py) and runs op by op
+            k = 3 * g.vision_patch_size ** 2
+            kpad = (k + 63) // 64 * 64
+            conv = torch.zeros(g.vision_width, kpad, dtype=torch.float16, device=dev)
+            conv[:, :k] = v.conv1.weight.detach().reshape(g.vision_width, k).to(torch.float16)
+            keep.append(conv)
+            vb = blocks(v.transformer.resblocks)
+            vw = _lib.VisionWeights(conv.data_ptr(), f32(v.class_embedding), f32(v.positional_embedding),
+                                    f32(v.ln_pre.weight), f32(v.ln_pre.bias), f32(v.ln_post.weight), f32(v.ln_post.bias),
+                                    f16(v.proj.detach().t()), vb)
+            check(lib.clipmi_set_vision_weights(self._handle, C.byref(vw)), "clipmi_set_vision_weights")
         tb = blocks(self.transformer.resblocks)
         tw = _lib.TextWeights(f32(self.token_embedding.weight), f32(self.positional_embedding),
                               f32(self.ln_final.weight), f32(self.ln_final.bias),
@@ -315,7 +327,11 @@ class CLIP(nn.Module):
     # ---- towers -------------------------------------------------------------------------------------------------
     def image_features_f32(self, image: torch.Tensor, shared_ctx: Optional[torch.Tensor] = None,
                            deep_prompts: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
-        """VisionTransformer.forward with fp32 output (un-normalised)."""
+        """VisionTransformer.forward / ModifiedResNet.forward with fp32 output (un-normalised)."""
+        if self.is_resnet:
+            if shared_ctx is not None:
+                raise ValueError("prompt tokens apply to the ViT towers only")
+            return self.visual.features_f32(image)
         self._ensure_bound()
         g = self.geometry
         image = ops._dev(image, "image", (torch.float16, torch.float32))
@@ -426,9 +442,11 @@ def convert_weights(model: nn.Module) -> None:
 
 def build_model(state_dict: Dict[str, torch.Tensor], design_details: Optional[dict] = None) -> CLIP:
     """Same contract as the reference factory (clip/model.py:656-699): geometry from tensor shapes, fp16 weight
-    conversion, strict load with a printed non-strict fallback, eval mode.  ViT towers only."""
+    conversion, strict load with a printed non-strict fallback, eval mode.  ViT towers, or a ModifiedResNet image tower
+    when the checkpoint has no ``visual.proj`` (clip/model.py:659-672)."""
+    resnet = None if "visual.proj" in state_dict else resnet_config_from_state_dict(state_dict)
     geom = geometry_from_state_dict(state_dict)
-    model = CLIP(geom, design_details)
+    model = CLIP(geom, design_details, resnet)
     for key in ("input_resolution", "context_length", "vocab_size"):
         if key in state_dict:
             del state_dict[key]

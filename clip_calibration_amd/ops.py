@@ -46,7 +46,9 @@ def gemm_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     if w.shape[1] != K:
         raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
     bias, pb = _opt(bias, "bias", (torch.float32,))
-    residual, pr = _opt(residual, "residual", (torch.float32,))
+    residual, pr = _opt(residual, "residual", (torch.float16,) if epilogue == _lib.EPI_BIAS_RESIDUAL16_RELU else (torch.float32,))
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise ValueError(f"gemm: residual is {tuple(residual.shape)}, expected [{M},{N}]")
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     check(lib.clipmi_gemm_f16(a.data_ptr(), K, w.data_ptr(), K, pb, pr, out.data_ptr(), N, _DT[out.dtype],

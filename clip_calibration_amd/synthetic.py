@@ -50,6 +50,8 @@ GEOMETRIES: Dict[str, ClipGeometry] = {
     "ViT-B/32": ClipGeometry(512, 224, 12, 768, 32, 77, 49408, 512, 8, 12),
     "ViT-L/14": ClipGeometry(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12),
     "ViT-L/14@336px": ClipGeometry(768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12),
+    # RN50 (clip/clip.py:30): ModifiedResNet (3, 4, 6, 3) x width 64 image tower -- the ViT fields are placeholders; text tower 512 / 8 / 12
+    "RN50": ClipGeometry(1024, 224, 1, 64, 224, 77, 49408, 512, 8, 12),
     # committed-fixture geometry: 2 layers, 4x4 grid, 2 heads; EOT id = vocab-1
     "tiny": ClipGeometry(128, 64, 2, 128, 16, 77, 256, 128, 2, 2),
     # odd token count + 3 layers: exercises M-edge handling in the GEMM tiles
@@ -57,15 +59,31 @@ GEOMETRIES: Dict[str, ClipGeometry] = {
 }
 
 
+def resnet_config_from_state_dict(sd: Dict[str, torch.Tensor]) -> Dict:
+    """ModifiedResNet branch of the reference's shape inference (clip/model.py:666-672)."""
+    if "visual.layer1.0.conv1.weight" not in sd or "visual.attnpool.positional_embedding" not in sd:
+        raise ValueError("checkpoint has neither visual.proj (ViT) nor visual.layer1 / visual.attnpool (ModifiedResNet) keys")
+    layers = tuple(len(set(k.split(".")[2] for k in sd if k.startswith(f"visual.layer{b}"))) for b in (1, 2, 3, 4))
+    width = sd["visual.layer1.0.conv1.weight"].shape[0]
+    out_w = round((sd["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+    if out_w ** 2 + 1 != sd["visual.attnpool.positional_embedding"].shape[0]:
+        raise ValueError("ModifiedResNet: attnpool.positional_embedding is not (w*w + 1) rows")
+    return {"layers": layers, "width": int(width), "image_resolution": out_w * 32}
+
+
 def geometry_from_state_dict(sd: Dict[str, torch.Tensor]) -> ClipGeometry:
-    """Shape inference, same rules as reference ``build_model`` (clip/model.py:657-681, ViT branch)."""
-    if "visual.proj" not in sd:
-        raise ValueError("only ViT checkpoints are on the hot path (ModifiedResNet is out of scope, SURVEY §2 row 1)")
+    """Shape inference, same rules as reference ``build_model`` (clip/model.py:657-681)."""
+    tw = sd["ln_final.weight"].shape[0]
+    if "visual.proj" not in sd:     # ModifiedResNet image tower: the ViT fields are placeholders the RN path never reads
+        rn = resnet_config_from_state_dict(sd)
+        return ClipGeometry(embed_dim=sd["text_projection"].shape[1], image_resolution=rn["image_resolution"], vision_layers=1,
+                            vision_width=64, vision_patch_size=rn["image_resolution"], context_length=sd["positional_embedding"].shape[0],
+                            vocab_size=sd["token_embedding.weight"].shape[0], transformer_width=tw, transformer_heads=tw // 64,
+                            transformer_layers=len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks"))))
     vw = sd["visual.conv1.weight"].shape[0]
     vl = len([k for k in sd if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
     ps = sd["visual.conv1.weight"].shape[-1]
     grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
-    tw = sd["ln_final.weight"].shape[0]
     tl = len(set(k.split(".")[2] for k in sd if k.startswith("transformer.resblocks")))
     return ClipGeometry(
         embed_dim=sd["text_projection"].shape[1],
@@ -141,6 +159,47 @@ def synthetic_state_dict(geom: ClipGeometry | str = "ViT-B/16", seed: int = 0,
     sd["ln_final.bias"] = randn(tw, std=0.05)
     sd["text_projection"] = randn(tw, geom.embed_dim, std=tw ** -0.5)
     sd["logit_scale"] = torch.tensor(float(logit_scale))
+    return sd
+
+
+def synthetic_resnet_state_dict(layers=(1, 1, 1, 1), width: int = 64, image_resolution: int = 64, text_geom: str = "tiny",
+                                seed: int = 0, logit_scale: float = 4.6052) -> Dict[str, torch.Tensor]:
+    """Seeded checkpoint with a ModifiedResNet image tower (key names of clip/model.py:10-150: ``visual.conv1.weight``,
+    ``visual.bn1.running_mean``, ``visual.layer2.0.downsample.0.weight``, ``visual.attnpool.q_proj.bias`` ...) and the text tower
+    of ``text_geom``.  BatchNorm running statistics are non-trivial so that the fold is exercised."""
+    tg = GEOMETRIES[text_geom]
+    sd = {k: v for k, v in synthetic_state_dict(tg, seed=seed, logit_scale=logit_scale).items() if not k.startswith("visual.")}
+    g = torch.Generator().manual_seed(seed + 77)
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = _r16(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+
+    def bn(name, c):
+        sd[name + ".weight"] = _r16(1.0 + 0.1 * torch.randn(c, generator=g))
+        sd[name + ".bias"] = _r16(0.05 * torch.randn(c, generator=g))
+        sd[name + ".running_mean"] = _r16(0.1 * torch.randn(c, generator=g))
+        sd[name + ".running_var"] = _r16(1.0 + 0.2 * torch.rand(c, generator=g))
+        sd[name + ".num_batches_tracked"] = torch.tensor(100, dtype=torch.long)
+
+    conv("visual.conv1", width // 2, 3, 3); bn("visual.bn1", width // 2)
+    conv("visual.conv2", width // 2, width // 2, 3); bn("visual.bn2", width // 2)
+    conv("visual.conv3", width, width // 2, 3); bn("visual.bn3", width)
+    inplanes = width
+    for li, (mult, n, stride) in enumerate(zip((1, 2, 4, 8), layers, (1, 2, 2, 2)), start=1):
+        planes = width * mult
+        for bi in range(n):
+            p = f"visual.layer{li}.{bi}"
+            conv(p + ".conv1", planes, inplanes, 1); bn(p + ".bn1", planes)
+            conv(p + ".conv2", planes, planes, 3); bn(p + ".bn2", planes)
+            conv(p + ".conv3", planes * 4, planes, 1); bn(p + ".bn3", planes * 4)
+            if bi == 0 and (stride > 1 or inplanes != planes * 4):
+                conv(p + ".downsample.0", planes * 4, inplanes, 1); bn(p + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    ed = width * 32
+    sd["visual.attnpool.positional_embedding"] = _r16(torch.randn((image_resolution // 32) ** 2 + 1, ed, generator=g) * ed ** -0.5)
+    for nm, out in (("q_proj", ed), ("k_proj", ed), ("v_proj", ed), ("c_proj", tg.embed_dim)):
+        sd[f"visual.attnpool.{nm}.weight"] = _r16(torch.randn(out, ed, generator=g) * ed ** -0.5)
+        sd[f"visual.attnpool.{nm}.bias"] = _r16(0.02 * torch.randn(out, generator=g))
     return sd
 
 

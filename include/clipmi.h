@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 6
+#define CLIPMI_ABI_VERSION 7
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -48,7 +48,10 @@ enum {
   CLIPMI_EPI_NONE = 0,          /* out = acc */
   CLIPMI_EPI_BIAS = 1,          /* out = acc + bias[n] */
   CLIPMI_EPI_BIAS_QUICKGELU = 2,/* t = acc + bias[n]; out = t * sigmoid(1.702 t)   (clip/model.py:162-164) */
-  CLIPMI_EPI_BIAS_RESIDUAL = 3  /* out = residual[m,n] + acc + bias[n]             (clip/model.py:186-187) */
+  CLIPMI_EPI_BIAS_RESIDUAL = 3, /* out = residual[m,n] + acc + bias[n]             (clip/model.py:186-187) */
+  CLIPMI_EPI_BIAS_RELU = 4,     /* out = max(acc + bias[n], 0): conv + folded BatchNorm + ReLU (clip/model.py:45-46,139) */
+  CLIPMI_EPI_BIAS_RESIDUAL16_RELU = 5 /* out = max(acc + bias[n] + residual16[m,n], 0): the tail of a Bottleneck
+                                         (clip/model.py:48-55); `residual` points at fp16 [M,N] (ld = ldo), fp16 out only */
 };
 
 int clipmi_abi_version(void);
@@ -61,10 +64,10 @@ const char* clipmi_last_error(void);
 
 /* nn.Linear / in_proj / out_proj / c_fc / c_proj / `x @ proj` (clip/model.py:174-176,183,422,611):
  * out[M,N] = epilogue(A[M,K] @ W[N,K]^T).  A, W fp16 row-major with leading dimensions lda, ldw (elements);
- * bias fp32[N] or NULL; residual fp32 [M,N] (ld = ldo) or NULL; out fp16 or fp32 (out_dtype), ld = ldo.
+ * bias fp32[N] or NULL; residual fp32 [M,N] (fp16 for BIAS_RESIDUAL16_RELU; ld = ldo) or NULL; out fp16 or fp32 (out_dtype), ld = ldo.
  * Requires K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0; M, N otherwise arbitrary. */
 int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                    const float* residual, void* out, int64_t ldo, int out_dtype,
+                    const void* residual, void* out, int64_t ldo, int out_dtype,
                     int M, int N, int K, int epilogue, clipmi_stream_t stream);
 
 /* LayerNorm subclass with fp32 statistics (clip/model.py:153-159): y[r,:] = (x[row(r),:] - mean) * rsqrt(var+eps)
@@ -108,6 +111,23 @@ int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int
  * alias logits); conf / pred as above, may be NULL. */
 int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred,
                         int B, int C, clipmi_stream_t stream);
+
+/* ModifiedResNet image tower (clip/model.py:10-150) -- SURVEY f-4.  Activations NHWC fp16; a 1x1 convolution is
+ * clipmi_gemm_f16 on the [B*H*W, C] rows with the folded BatchNorm as bias (CLIPMI_EPI_BIAS_RELU / _RESIDUAL16_RELU).
+ *  clipmi_im2col3x3_nchw   stem conv1 (clip/model.py:106, stride 2, pad 1) from the NCHW image (fp32|fp16):
+ *                          col fp16 [B*Ho*Wo, Kpad], column c*9 + ky*3 + kx, zero padded (Kpad % 64 == 0)
+ *  clipmi_im2col3x3_nhwc   every other 3x3 convolution (stride 1, pad 1; clip/model.py:20,108,110):
+ *                          col[(b,y,x), (ky*3+kx)*C + c] = x[b, y+ky-1, x+kx-1, c]; C % 8 == 0
+ *  clipmi_avgpool_nhwc     nn.AvgPool2d(k) (clip/model.py:23,33,112): x [B,H,W,C] -> y [B,H/k,W/k,C]
+ *  clipmi_attnpool_tokens  AttentionPool2d token build (clip/model.py:69-71): tokens fp16 [B, HW+1, C] = [mean | x] + pos (fp32 [HW+1, C])
+ *  clipmi_attnpool         its attention with the mean token as the only query (clip/model.py:72-90): q fp16 [B,C] (projected,
+ *                          biased), kv fp16 [B*T, 2C] (k | v projected, biased), head_dim 64 -> out fp16 [B, C] (before c_proj) */
+int clipmi_im2col3x3_nchw(const void* image, int image_dtype, void* col, int B, int Cin, int H, int W, int stride, int Kpad,
+                          clipmi_stream_t stream);
+int clipmi_im2col3x3_nhwc(const void* x, void* col, int B, int H, int W, int C, int Kpad, clipmi_stream_t stream);
+int clipmi_avgpool_nhwc(const void* x, void* y, int B, int H, int W, int C, int k, clipmi_stream_t stream);
+int clipmi_attnpool_tokens(const void* x, const float* pos, void* tokens, int B, int HW, int C, clipmi_stream_t stream);
+int clipmi_attnpool(const void* q, const void* kv, void* out, int B, int T, int heads, clipmi_stream_t stream);
 
 /* CLIP-Adapter's feature blend (trainers/classification/clip_adapter.py:138-172): out[b,:] = ratio * relu(W2 relu(W1 f[b,:]))
  * + (1 - ratio) * f[b,:]; feats [B,E] (un-normalised image features), w1 [H,E], w2 [E,H], no biases; all fp32. */

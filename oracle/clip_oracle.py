@@ -128,6 +128,56 @@ def encode_image(sd: SD, image: Tensor, dtype: torch.dtype = torch.float32,
     return x @ sd["visual.proj"].to(dtype)
 
 
+def encode_image_resnet(sd: SD, image: Tensor, dtype: torch.dtype = torch.float32) -> Tensor:
+    """ModifiedResNet.forward (clip/model.py:93-150): 3-conv stem (+BatchNorm, ReLU) and AvgPool2d(2); four stages of
+    Bottlenecks (:10-56: 1x1 -> 3x3 -> AvgPool2d(stride) -> 1x1, BatchNorm after each conv, ReLU after the first two and after
+    the residual add; the shortcut is AvgPool2d(stride) -> 1x1 -> BatchNorm when shapes change); AttentionPool2d (:58-90):
+    tokens [mean | HW] + positional embedding, multi-head attention with the mean token as the query, c_proj."""
+    import torch.nn.functional as F
+
+    def bn(x, p):
+        return F.batch_norm(x, sd[p + ".running_mean"].to(dtype), sd[p + ".running_var"].to(dtype), sd[p + ".weight"].to(dtype),
+                            sd[p + ".bias"].to(dtype), False, 0.0, 1e-5)
+
+    def conv(x, p, stride=1, pad=0):
+        return F.conv2d(x, sd[p + ".weight"].to(dtype), None, stride, pad)
+
+    x = image.to(dtype)
+    x = F.relu(bn(conv(x, "visual.conv1", 2, 1), "visual.bn1"))
+    x = F.relu(bn(conv(x, "visual.conv2", 1, 1), "visual.bn2"))
+    x = F.relu(bn(conv(x, "visual.conv3", 1, 1), "visual.bn3"))
+    x = F.avg_pool2d(x, 2)
+    for li, stride0 in zip((1, 2, 3, 4), (1, 2, 2, 2)):
+        bi = 0
+        while f"visual.layer{li}.{bi}.conv1.weight" in sd:
+            p = f"visual.layer{li}.{bi}"
+            stride = stride0 if bi == 0 else 1
+            out = F.relu(bn(conv(x, p + ".conv1"), p + ".bn1"))
+            out = F.relu(bn(conv(out, p + ".conv2", 1, 1), p + ".bn2"))
+            if stride > 1:
+                out = F.avg_pool2d(out, stride)
+            out = bn(conv(out, p + ".conv3"), p + ".bn3")
+            identity = x
+            if p + ".downsample.0.weight" in sd:
+                identity = bn(conv(F.avg_pool2d(x, stride) if stride > 1 else x, p + ".downsample.0"), p + ".downsample.1")
+            x = F.relu(out + identity)
+            bi += 1
+    b, c, h, w = x.shape
+    tok = x.reshape(b, c, h * w).permute(0, 2, 1)                                    # [B, HW, C]
+    tok = torch.cat([tok.mean(dim=1, keepdim=True), tok], dim=1) + sd["visual.attnpool.positional_embedding"].to(dtype)
+    ap = "visual.attnpool."
+    heads = c // 64
+    q = tok[:, :1] @ sd[ap + "q_proj.weight"].to(dtype).t() + sd[ap + "q_proj.bias"].to(dtype)
+    k = tok @ sd[ap + "k_proj.weight"].to(dtype).t() + sd[ap + "k_proj.bias"].to(dtype)
+    v = tok @ sd[ap + "v_proj.weight"].to(dtype).t() + sd[ap + "v_proj.bias"].to(dtype)
+    t = tok.shape[1]
+    qh = q.reshape(b, 1, heads, 64).transpose(1, 2) * 64 ** -0.5
+    kh, vh = k.reshape(b, t, heads, 64).transpose(1, 2), v.reshape(b, t, heads, 64).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) @ vh                       # [B, heads, 1, 64]
+    out = att.transpose(1, 2).reshape(b, c)
+    return out @ sd[ap + "c_proj.weight"].to(dtype).t() + sd[ap + "c_proj.bias"].to(dtype)
+
+
 # --------------------------------------------------------------------------------------
 # text tower (a-7, a-8, a-9 text side)
 # --------------------------------------------------------------------------------------

@@ -204,6 +204,23 @@ def main():
         np.savez_compressed(os.path.join(OUT, fname), **out)
         print("wrote", fname, {k: np.shape(v) for k, v in out.items() if not k.startswith("sd:")})
 
+    # ---------------- ModifiedResNet image tower (clip/model.py:10-150): inputs by seed, outputs stored ----------------
+    import contextlib, io
+    rn_sd = syn.synthetic_resnet_state_dict((1, 2, 1, 1), 64, 64, "tiny", seed=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rn = ref_model.build_model(dict(rn_sd), dict(PLAIN)).float()
+    assert type(rn.visual).__name__ == "ModifiedResNet"
+    rn_images = syn.synthetic_images(3, syn.ClipGeometry(128, 64, 1, 64, 64, 77, 256, 128, 2, 2), seed=5)
+    rn_ids = syn.synthetic_token_ids(4, "tiny", seed=5)
+    with torch.no_grad():
+        rn_img = rn.encode_image(rn_images)
+        rn_txt = rn.encode_text(rn_ids)
+        rn_lpi, _ = rn(rn_images, rn_ids)
+    np.savez_compressed(os.path.join(OUT, "resnet_tiny.npz"), image_features=_np(rn_img), text_features=_np(rn_txt), logits=_np(rn_lpi),
+                        ids=rn_ids.numpy(), sd_checksum=np.float64(sd_checksum({k: v for k, v in rn_sd.items() if v.dtype.is_floating_point})),
+                        n_keys=np.int64(len(rn.state_dict())))
+    print("wrote resnet_tiny.npz", len(rn.state_dict()), "keys")
+
     # ---------------- full ViT-B/16 geometry: inputs by seed, outputs stored ----------------
     _, _, out = ref_forward(ref_model, "ViT-B/16", seed=0, n_img=2, n_cls=8)
     out.pop("images")  # regenerated from the seed; ids are tiny so they stay

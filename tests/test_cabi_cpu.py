@@ -92,7 +92,7 @@ def test_boundary_state_dict_surface():
     m2 = build_model(missing_ok | {"visual.proj": sd["visual.proj"]}, None)   # non-strict fallback prints and continues
     assert float(m2.logit_scale) == pytest.approx(np.log(1 / 0.07))
     with pytest.raises(ValueError):
-        build_model({k: v for k, v in sd.items() if k != "visual.proj"}, None)   # ModifiedResNet: out of scope
+        build_model({k: v for k, v in sd.items() if k != "visual.proj"}, None)   # neither a ViT nor a ModifiedResNet checkpoint
 
 
 def test_host_ece_matches_reference_goldens():
@@ -212,3 +212,20 @@ def test_quantile_bins_match_sklearn():
                 want = sk.KBinsDiscretizer(n_bins=nb, encode="ordinal", strategy="quantile").fit_transform(x[:, None])[:, 0]
             assert np.array_equal(metrics.quantile_bin_index(x, nb), want.astype(np.int64))
             assert np.array_equal(orc.quantile_bins(x, nb), want.astype(np.int64))
+
+
+def test_modified_resnet_boundary_surface():
+    """f-4: a checkpoint without ``visual.proj`` builds the ModifiedResNet tower (clip/model.py:659-672) under the reference's key
+    names and dtype policy; nothing runs without a GPU."""
+    sd = syn.synthetic_resnet_state_dict((1, 2, 1, 1), 64, 64, "tiny", seed=0)
+    g = load_golden("resnet_tiny.npz")
+    m = build_model(dict(sd), None)
+    keys = set(m.state_dict())
+    assert keys == set(sd) and len(keys) == int(g["n_keys"])
+    assert m.is_resnet and m.visual.input_resolution == 64 and m.visual.output_dim == 128 and m.visual.attnpool.num_heads == 32
+    sdm = m.state_dict()
+    assert sdm["visual.layer2.0.downsample.0.weight"].dtype == torch.float16 and sdm["visual.attnpool.q_proj.bias"].dtype == torch.float16
+    assert sdm["visual.bn1.running_var"].dtype == torch.float32 and sdm["visual.attnpool.positional_embedding"].dtype == torch.float32
+    assert m.dtype == torch.float16
+    with pytest.raises(RuntimeError):
+        m.encode_image(torch.zeros(1, 3, 64, 64))                       # no CPU path

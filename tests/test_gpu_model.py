@@ -541,6 +541,51 @@ def test_clip_adapter_and_taskres_mirrors():
     assert np.abs(txf.cpu().numpy() @ tn.numpy().T - (tn @ tn.t()).numpy()).max() < COS_TOL
 
 
+def test_golden_modified_resnet_tower():
+    """f-4: ModifiedResNet image tower (clip/model.py:10-150) -- BatchNorm folded into NHWC GEMM convolutions, attention pool --
+    against the reference's own output on the seeded checkpoint and against the oracle on other inputs; zero-shot flow on top."""
+    from clip_calibration_amd.model import build_model
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    g = load_golden("resnet_tiny.npz")
+    sd = syn.synthetic_resnet_state_dict((1, 2, 1, 1), 64, 64, "tiny", seed=0)
+    model = build_model(dict(sd), None).cuda()
+    geom = syn.ClipGeometry(128, 64, 1, 64, 64, 77, 256, 128, 2, 2)
+    images = syn.synthetic_images(3, geom, seed=5)
+    ids = torch.from_numpy(g["ids"])
+    with torch.no_grad():
+        img = model.image_features_f32(images.cuda()).cpu().numpy()
+        txt = model.text_features_f32(ids.cuda()).cpu().numpy()
+    _feat_close(img, g["image_features"], "ModifiedResNet image tower vs reference")
+    _feat_close(txt, g["text_features"], "text tower of the RN checkpoint")
+    assert np.abs(img - g["image_features"]).max() < 2e-2 * np.abs(g["image_features"]).max()     # magnitudes too, not only directions
+    zs = ZeroshotCLIP(model, ids)
+    logits, imf, txf = zs.model_inference(images.cuda())
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 100 * COS_TOL
+    assert model.encode_image(images.cuda()).dtype == torch.float16
+    # other batch sizes / inputs against the oracle; batch invariance
+    more = syn.synthetic_images(9, geom, seed=6)
+    with torch.no_grad():
+        got = model.image_features_f32(more.cuda()).cpu().numpy()
+        one = model.image_features_f32(more[4:5].cuda()).cpu().numpy()
+        ref = orc.encode_image_resnet(sd, more).numpy()
+    _feat_close(got, ref, "ModifiedResNet vs oracle, batch 9")
+    assert np.abs(one - got[4:5]).max() < 1e-3 * np.abs(got).max()
+    assert model.image_features_f32(more[:0].cuda()).shape == (0, 128)
+
+
+def test_rn50_geometry_vs_oracle():
+    """The published RN50 shape (layers 3-4-6-3, width 64, 224 px, 7x7 + 1 pooled tokens, embed 1024) on two images."""
+    from clip_calibration_amd.model import build_model
+    sd = syn.synthetic_resnet_state_dict((3, 4, 6, 3), 64, 224, "RN50", seed=1)
+    model = build_model(dict(sd), None).cuda()
+    assert model.visual.layers_cfg == (3, 4, 6, 3) and model.visual.attnpool.num_heads == 32 and model.visual.output_dim == 1024
+    images = syn.synthetic_images(2, "RN50", seed=1)
+    with torch.no_grad():
+        got = model.image_features_f32(images.cuda()).cpu().numpy()
+        ref = orc.encode_image_resnet(sd, images).numpy()
+    _feat_close(got, ref, "RN50 image tower vs oracle")
+
+
 def test_runner_base_to_new_calibration_flow(tmp_path):
     """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
     -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of

@@ -120,6 +120,24 @@ def test_ivlp_vpt_blocks(tag):
     assert np.abs(img.numpy() - g["image_features"]).max() > 1e-3
 
 
+RN_GEOM = syn.ClipGeometry(128, 64, 1, 64, 64, 77, 256, 128, 2, 2)     # image side: only the resolution is read
+
+
+def test_modified_resnet_tower():
+    """f-4: ModifiedResNet image tower (clip/model.py:10-150) -- oracle against the reference's own build of the seeded checkpoint."""
+    g = load_golden("resnet_tiny.npz")
+    sd = syn.synthetic_resnet_state_dict((1, 2, 1, 1), 64, 64, "tiny", seed=0)
+    assert len(sd) == int(g["n_keys"])                                 # the reference's ModifiedResNet CLIP has exactly these keys
+    images = syn.synthetic_images(3, RN_GEOM, seed=5)
+    with torch.no_grad():
+        img = orc.encode_image_resnet(sd, images)
+        txt = orc.encode_text(sd, torch.from_numpy(g["ids"]))
+        logits, _, _ = orc.clip_logits(img, txt, sd["logit_scale"].exp())
+    np.testing.assert_allclose(img.numpy(), g["image_features"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(txt.numpy(), g["text_features"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(logits.numpy() / 100.0, g["logits"] / 100.0, atol=2e-5)
+
+
 def test_vitb16_full_geometry():
     g = load_golden("vitb16_seed0.npz")
     sd = syn.synthetic_state_dict("ViT-B/16", seed=0)
