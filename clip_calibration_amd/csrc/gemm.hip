@@ -382,14 +382,30 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   for (int i = 0; i < T::WI; ++i) woff[i] = ((i * (NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
   const int lds_wave_off = wave * 1024;  // 64 lanes x 16 B
 
+  // Tall tiles are at the 256-VGPR limit: keeping the XI + WI per-thread source offsets live across the loop made hipcc
+  // spill them and reload seven of them from scratch in front of EVERY barrier (~1 us per K-step).  They are rebuilt from
+  // one base per operand with a v_add each (volatile asm, so that it is not hoisted back out of the loop).
+  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
   auto stage = [&](int buf, int kt) {
     char* xs = smem + buf * T::STAGE + lds_wave_off;
     char* ws = xs + T::XBYTES;
     const int k0 = kt * BK * 2;
+    if constexpr (TM > 8) {
 #pragma unroll
-    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+      for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff[0], i * xstep), k0);
 #pragma unroll
-    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+      for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff[0], i * wstep), k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+#pragma unroll
+      for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+    }
   };
 
   // ---- fragment read offsets (bytes inside an operand tile): lane reads row (lane&15) of its 16-row tile,
@@ -436,6 +452,30 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     const char* st = smem + (kt & 1) * T::STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (TM > 8) {
+        // tall wave tiles (160 x 64: 160 accumulator registers): the activation fragments are read in two halves that
+        // share registers -- with all ten live next to the accumulators the kernel needs more than the 256 VGPRs two
+        // waves per SIMD may have, and hipcc spills to scratch INSIDE this loop (observed: 2.2 us per K-step)
+        constexpr int H0 = TM / 2;
+        f16x8 wf[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j0 = h ? H0 : 0, j1 = h ? TM : H0;
+          f16x8 xf[TM - H0];
+#pragma unroll
+          for (int j = j0; j < j1; ++j) xf[j - j0] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = j0; j < j1; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j - j0], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);   // keep the second half's reads behind the first half's MFMAs
+        }
+      } else {
       f16x8 xf[TM], wf[TN];
 #pragma unroll
       for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
@@ -448,6 +488,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
