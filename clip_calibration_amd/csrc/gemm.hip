@@ -698,14 +698,22 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     m0 = tm * BM;
     n0 = (b * a.band + (within - tm * gw)) * BN;
   };
+  // per-thread source offsets rebuilt from one base per operand (see gemm_f16_kernel): at the 128-VGPR cap of 16 waves
+  // the eight of them were spilled and reloaded from scratch inside the K loop
+  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
   auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
     char* xs = smem + buf * T::STAGE + lds_wave_off;
     char* ws = xs + T::XBYTES;
     const int k0 = kt * BK * 2;
 #pragma unroll
-    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
+    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff[0], i * xstep), k0);
 #pragma unroll
-    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff[0], i * wstep), k0);
   };
 
   int vb = blockIdx.x;
@@ -715,6 +723,24 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
   __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
   int first_buf = 0;
   stage(xrs, wrs, first_buf, 0);
+  // LayerNorm-fold consumer: (rstd, mean*rstd) of a tile's rows in LDS, double buffered by tile parity -- tile i+1's
+  // are written while tile i's epilogue may still read its own
+  constexpr int LNP_OFF = (PATCH_ALIASED ? T::SMEM : T::SMEM + T::NW * 16 * ROWB);
+  constexpr bool CONSUMER = EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU;
+  int par = 0;
+  auto row_params = [&](int row0, int which) {
+    if constexpr (CONSUMER) {
+      if (a.ln_stats) {   // block-uniform
+        float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
+        for (int t = tid; t < BM; t += NT) {
+          float rs, mrs;
+          ln_row_params(a, row0 + t, rs, mrs);
+          dst[t] = make_float2(rs, mrs);
+        }
+      }
+    }
+  };
+  row_params(m0, 0);
 
   const bool stamp = a.stamps != nullptr && tid == 0;
   while (true) {
@@ -739,18 +765,22 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       const char* st = smem + buf * T::STAGE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        f16x8 xf[TM], wf[TN];
+        // weight fragments one tile ahead instead of all TN at once: 24 live fragment registers instead of 32 -- at the
+        // 128-VGPR cap of a 16-wave workgroup the difference is a scratch reload inside this loop
+        f16x8 xf[TM], wcur, wnext;
 #pragma unroll
         for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i) {
+          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          wcur = wnext;
+        }
       }
     }
     const int last_buf = (first_buf + nk - 1) & 1;
@@ -767,7 +797,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
       first_buf = last_buf ^ 1;
       stage(xrs, wrs, first_buf, 0);
+      row_params(m0, par ^ 1);
     }
+    const float2* lnp = (CONSUMER && a.ln_stats) ? reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM : nullptr;
+    par ^= 1;
     if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
       if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {
         if constexpr (PATCH_ALIASED) {
@@ -775,9 +808,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
           // K-step (the prefetch above went to the other one).  Everyone must be done reading it first; the barrier
           // at the top of the next tile's first K-step keeps stage(.., 1) out of it until every epilogue has finished.
           __syncthreads();
-          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + last_buf * T::STAGE + wave * (16 * ROWB));
+          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + last_buf * T::STAGE + wave * (16 * ROWB), lnp);
         } else {
-          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB));
+          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB), lnp);
         }
       } else {
         epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
@@ -793,7 +826,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
 template <typename T, int EPI, bool OUT_F32>
 int launch_persist(KArgs k, hipStream_t s) {
   constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
-  constexpr int SMEM = SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP;
+  constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2);   // + LayerNorm-fold row parameters
   static bool attr_set = false;
   static int n_cu = 0;
   auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
