@@ -105,25 +105,30 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int tiles_m, int& ti
 // fp16 outputs: each wave transposes its tile through a private LDS patch (32 rows x 64 cols at a time) so that the
 // global stores are 16 B per lane and 128 contiguous bytes per row, instead of 8-byte pieces of 32-byte row segments.
 // The caller must have passed a workgroup barrier after the last main-loop LDS read.
-template <typename T, int EPI, int CH>
+// COLP_LDS: bias and the fold's g vector are read from an LDS copy of the tile's columns (colp: [BN] bias | [BN] g) at
+// each use instead of being held in 8 * TN registers across the whole epilogue (persistent 16-wave kernel: 128-VGPR cap).
+template <typename T, int EPI, int CH, bool COLP_LDS = false>
 __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
-                                                    int wave_n, int lane, char* patch, const float2* lnp = nullptr) {
+                                                    int wave_n, int lane, char* patch, const float2* lnp = nullptr,
+                                                    const float* colp = nullptr) {
   constexpr int TM = T::TM, TN = T::TN;
   static_assert(T::WTN % 64 == 0 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue works on 64-column slices of the wave tile");
   constexpr int NH = T::WTN / 64;        // 64-column slices per wave tile (1 for the 64-wide wave tiles, 2 for 128)
   constexpr int ROWB = 64 * 2 + 16;      // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
   const int r16 = lane & 15, g4 = lane >> 4;
-  f32x4 bias[TN], lng[TN];
+  f32x4 bias[COLP_LDS ? 1 : TN], lng[COLP_LDS ? 1 : TN];
   const bool fold = a.ln_stats != nullptr;   // wave-uniform
+  if constexpr (!COLP_LDS) {
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    lng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (EPI != CLIPMI_EPI_NONE) {
-      const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
-      if (n < a.N) {
-        bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
-        if (fold) lng[i] = *reinterpret_cast<const f32x4*>(a.ln_g + n);
+    for (int i = 0; i < TN; ++i) {
+      bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (EPI != CLIPMI_EPI_NONE) {
+        const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+        if (n < a.N) {
+          bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
+          if (fold) lng[i] = *reinterpret_cast<const f32x4*>(a.ln_g + n);
+        }
       }
     }
   }
@@ -150,7 +155,15 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = h * 4 + ii;
-          f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
+          f32x4 v;
+          if constexpr (COLP_LDS) {
+            const int nl = wave_n * T::WTN + i * 16 + g4 * 4;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + T::BN + nl);
+            v = acc[i][jc * CH + jj] * rs + (bb - mrs * gg);
+          } else {
+            v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
+          }
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -727,8 +740,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
   // are written while tile i's epilogue may still read its own
   constexpr int LNP_OFF = (PATCH_ALIASED ? T::SMEM : T::SMEM + T::NW * 16 * ROWB);
   constexpr bool CONSUMER = EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU;
+  constexpr int COLP_OFF = LNP_OFF + 2 * BM * (int)sizeof(float2);   // then 2 x ([BN] bias | [BN] g)
+  constexpr bool COLP = EPI != CLIPMI_EPI_NONE && !OUT_F32 && EPI != EPI_PATCH_POS;
   int par = 0;
-  auto row_params = [&](int row0, int which) {
+  auto row_params = [&](int row0, int col0, int which) {
     if constexpr (CONSUMER) {
       if (a.ln_stats) {   // block-uniform
         float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
@@ -739,8 +754,16 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
         }
       }
     }
+    if constexpr (COLP) {
+      float* dst = reinterpret_cast<float*>(smem + COLP_OFF) + which * 2 * BN;
+      for (int t = tid; t < BN; t += NT) {
+        const int n = col0 + t;
+        dst[t] = n < a.N ? a.bias[n] : 0.f;
+        dst[BN + t] = (n < a.N && a.ln_stats) ? a.ln_g[n] : 0.f;
+      }
+    }
   };
-  row_params(m0, 0);
+  row_params(m0, n0, 0);
 
   const bool stamp = a.stamps != nullptr && tid == 0;
   while (true) {
@@ -797,10 +820,16 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
       first_buf = last_buf ^ 1;
       stage(xrs, wrs, first_buf, 0);
-      row_params(m0, par ^ 1);
+      row_params(m0, n0, par ^ 1);
     }
     const float2* lnp = (CONSUMER && a.ln_stats) ? reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM : nullptr;
+    const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
     par ^= 1;
+    // the epilogue's lane-derived address constants are loop invariants of the tile loop: hipcc hoists them out, runs out of
+    // registers in the K loop and spills them -- and every reload waits vmcnt(0), i.e. for the next tile's prefetch.
+    // An opaque copy of the lane id makes them recomputed (a handful of VALU) per tile instead.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
       if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {
         if constexpr (PATCH_ALIASED) {
@@ -808,15 +837,15 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
           // K-step (the prefetch above went to the other one).  Everyone must be done reading it first; the barrier
           // at the top of the next tile's first K-step keeps stage(.., 1) out of it until every epilogue has finished.
           __syncthreads();
-          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + last_buf * T::STAGE + wave * (16 * ROWB), lnp);
+          epilogue_f16_staged<T, EPI, 1, COLP>(acc, a, cm0, cn0, wave_m, wave_n, lane_e, smem + last_buf * T::STAGE + wave * (16 * ROWB), lnp, colp);
         } else {
-          epilogue_f16_staged<T, EPI, 1>(acc, a, cm0, cn0, wave_m, wave_n, lane, smem + T::SMEM + wave * (16 * ROWB), lnp);
+          epilogue_f16_staged<T, EPI, 1, COLP>(acc, a, cm0, cn0, wave_m, wave_n, lane_e, smem + T::SMEM + wave * (16 * ROWB), lnp, colp);
         }
       } else {
-        epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
+        epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane_e);
       }
     } else {
-      epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane);
+      epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane_e);
     }
     if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
     if (!has_next) break;
@@ -826,7 +855,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
 template <typename T, int EPI, bool OUT_F32>
 int launch_persist(KArgs k, hipStream_t s) {
   constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
-  constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2);   // + LayerNorm-fold row parameters
+  constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2) + 4 * T::BN * (int)sizeof(float);   // + row / column parameters
   static bool attr_set = false;
   static int n_cu = 0;
   auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
