@@ -13,22 +13,30 @@
 namespace clipmi {
 namespace {
 
+// 8 consecutive K columns (16 B) per thread
 template <typename TI>
 __global__ __launch_bounds__(256) void im2col3x3_nchw_kernel(const TI* __restrict__ img, half_t* __restrict__ col, int B, int Cin,
                                                              int H, int W, int Ho, int Wo, int stride, int Kpad, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one output element
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 8-column group
   if (i >= total) return;
-  const int k = (int)(i % Kpad);
-  const int64_t row = i / Kpad;
-  half_t v = (half_t)0.f;
-  if (k < Cin * 9) {
-    const int c = k / 9, t = k - c * 9, ky = t / 3, kx = t - ky * 3;
-    const int xo = (int)(row % Wo), yo = (int)((row / Wo) % Ho);
-    const int64_t b = row / ((int64_t)Wo * Ho);
-    const int y = yo * stride + ky - 1, x = xo * stride + kx - 1;
-    if (y >= 0 && y < H && x >= 0 && x < W) v = (half_t)(float)img[((b * Cin + c) * H + y) * W + x];
+  const int kv = Kpad >> 3;
+  const int k0 = (int)(i % kv) << 3;
+  const int64_t row = i / kv;
+  const int xo = (int)(row % Wo), yo = (int)((row / Wo) % Ho);
+  const int64_t b = row / ((int64_t)Wo * Ho);
+  f16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    float val = 0.f;
+    if (k < Cin * 9) {
+      const int c = k / 9, t = k - c * 9, ky = t / 3, kx = t - ky * 3;
+      const int y = yo * stride + ky - 1, x = xo * stride + kx - 1;
+      if (y >= 0 && y < H && x >= 0 && x < W) val = (float)img[((b * Cin + c) * H + y) * W + x];
+    }
+    v[e] = (half_t)val;
   }
-  col[i] = v;
+  *reinterpret_cast<f16x8*>(col + row * Kpad + k0) = v;
 }
 
 // 8 channels (16 B) per thread; C % 8 == 0
@@ -50,18 +58,40 @@ __global__ __launch_bounds__(256) void im2col3x3_nhwc_kernel(const half_t* __res
   *reinterpret_cast<f16x8*>(col + row * Kpad + k) = v;
 }
 
+// 8 channels (16 B) per thread when C % 8 == 0
+template <int VEC>
 __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int C, int H, int W,
                                                            int k, int64_t total) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one output element
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one group of VEC output channels
   if (i >= total) return;
-  const int Ho = H / k, Wo = W / k;
-  const int c = (int)(i % C);
-  const int xo = (int)((i / C) % Wo), yo = (int)((i / ((int64_t)C * Wo)) % Ho);
-  const int64_t b = i / ((int64_t)C * Wo * Ho);
-  float s = 0.f;
+  const int Ho = H / k, Wo = W / k, cv = C / VEC;
+  const int c = (int)(i % cv) * VEC;
+  const int xo = (int)((i / cv) % Wo), yo = (int)((i / ((int64_t)cv * Wo)) % Ho);
+  const int64_t b = i / ((int64_t)cv * Wo * Ho);
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
   for (int dy = 0; dy < k; ++dy)
-    for (int dx = 0; dx < k; ++dx) s += (float)x[((b * H + yo * k + dy) * W + xo * k + dx) * C + c];
-  y[i] = (half_t)(s / (float)(k * k));
+    for (int dx = 0; dx < k; ++dx) {
+      const half_t* p = x + ((b * H + yo * k + dy) * W + xo * k + dx) * C + c;
+      if constexpr (VEC == 8) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      } else {
+        s[0] += (float)p[0];
+      }
+    }
+  const float inv = 1.0f / (float)(k * k);
+  half_t* q = y + ((b * Ho + yo) * Wo + xo) * C + c;
+  if constexpr (VEC == 8) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(s[e] * inv);
+    *reinterpret_cast<f16x8*>(q) = o;
+  } else {
+    q[0] = (half_t)(s[0] * inv);
+  }
 }
 
 // tokens[b, 0, :] = mean_hw x[b, hw, :] + pos[0, :]; tokens[b, 1 + hw, :] = x[b, hw, :] + pos[1 + hw, :]
@@ -111,7 +141,7 @@ int launch_im2col3x3_nchw(const void* image, int dtype, half_t* col, int B, int 
   CLIPMI_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && Kpad >= Cin * 9 && Kpad % 64 == 0, CLIPMI_ERR_SHAPE,
                  "im2col3x3_nchw: B=%d Cin=%d H=%d W=%d stride=%d Kpad=%d", B, Cin, H, W, stride, Kpad);
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  const int64_t total = (int64_t)B * Ho * Wo * Kpad;
+  const int64_t total = (int64_t)B * Ho * Wo * (Kpad / 8);
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (dtype == CLIPMI_F32)
     hipLaunchKernelGGL(im2col3x3_nchw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)image, col, B, Cin, H, W, Ho, Wo, stride, Kpad, total);
@@ -139,8 +169,13 @@ int launch_avgpool_nhwc(const half_t* x, half_t* y, int B, int H, int W, int C, 
   if (B == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x && y, CLIPMI_ERR_ARG, "avgpool: null pointer");
   CLIPMI_REQUIRE(B > 0 && C > 0 && k >= 1 && H % k == 0 && W % k == 0, CLIPMI_ERR_SHAPE, "avgpool: B=%d H=%d W=%d C=%d k=%d", B, H, W, C, k);
-  const int64_t total = (int64_t)B * (H / k) * (W / k) * C;
-  hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, C, H, W, k, total);
+  if (C % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) {
+    const int64_t total = (int64_t)B * (H / k) * (W / k) * (C / 8);
+    hipLaunchKernelGGL(avgpool_nhwc_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, C, H, W, k, total);
+  } else {
+    const int64_t total = (int64_t)B * (H / k) * (W / k) * C;
+    hipLaunchKernelGGL(avgpool_nhwc_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, C, H, W, k, total);
+  }
   return check_launch("avgpool_nhwc_kernel");
 }
 
