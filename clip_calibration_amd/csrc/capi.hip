@@ -280,6 +280,10 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
   return launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, (hipStream_t)stream);
 }
+int clipmi_conv3x3_nhwc(const void* x, const void* w, const float* bias, void* out, int B, int H, int W, int C, int Cout, int relu,
+                        clipmi_stream_t stream) {
+  return launch_conv3x3((const half_t*)x, (const half_t*)w, bias, (half_t*)out, B, H, W, C, Cout, relu, (hipStream_t)stream);
+}
 int clipmi_im2col3x3_nchw(const void* image, int image_dtype, void* col, int B, int Cin, int H, int W, int stride, int Kpad,
                           clipmi_stream_t stream) {
   return launch_im2col3x3_nchw(image, image_dtype, (half_t*)col, B, Cin, H, W, stride, Kpad, (hipStream_t)stream);

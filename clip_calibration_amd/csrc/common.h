@@ -101,6 +101,8 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
 int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         hipStream_t s);
+int launch_conv3x3(const half_t* x, const half_t* w, const float* bias, half_t* out, int B, int H, int W, int C, int Cout, int relu,
+                   hipStream_t s);
 int launch_im2col3x3_nchw(const void* image, int dtype, half_t* col, int B, int Cin, int H, int W, int stride, int Kpad, hipStream_t s);
 int launch_im2col3x3_nhwc(const half_t* x, half_t* col, int B, int H, int W, int C, int Kpad, hipStream_t s);
 int launch_avgpool_nhwc(const half_t* x, half_t* y, int B, int H, int W, int C, int k, hipStream_t s);

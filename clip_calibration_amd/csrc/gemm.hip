@@ -1223,6 +1223,130 @@ int pick_variant(const KArgs& k) {
   return best;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM 3x3 convolution (stride 1, pad 1) on NHWC fp16 activations -- ModifiedResNet's Bottleneck.conv2
+// (clip/model.py:20), SURVEY f-4.  out[(b,y,x), n] = relu(bias[n] + sum_{ky,kx,c} x[b, y+ky-1, x+kx-1, c] * W[n, (ky*3+kx)*C + c]).
+// Same tile machinery as gemm_f16_kernel; the only difference is the activation operand: K-step kt covers channels
+// [c0, c0+64) of ONE tap (C % 64 == 0), so a thread's LDS-DMA source is its pixel row shifted by ((ky-1)*W + (kx-1)) rows,
+// and a tap that falls outside the image is pointed past the end of the buffer descriptor, where the hardware returns
+// zeros -- the padding costs no instruction and no im2col matrix (9x the activation bytes) is ever written.
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvArgs {
+  int H, W, C;
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_conv3x3_kernel(const KArgs a, const ConvArgs cv) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A, (int64_t)a.M * cv.C * 2);                      // the whole activation tensor
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  // per DMA instruction of this thread: byte offset of its pixel row and the 9-bit mask of taps that stay inside the image
+  int xrow[T::XI], xmask[T::XI], woff[T::WI];
+#pragma unroll
+  for (int i = 0; i < T::XI; ++i) {
+    const int m = m0 + i * (NT / 8) + srow;
+    const int x = m % cv.W, y = (m / cv.W) % cv.H;
+    int mask = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      mask |= (m < a.M && yy >= 0 && yy < cv.H && xx >= 0 && xx < cv.W) ? (1 << t) : 0;
+    }
+    xmask[i] = mask;
+    xrow[i] = (m * cv.C + schunk * 8) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < T::WI; ++i) woff[i] = ((i * (NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+  const int cpk = cv.C / BK;   // K-steps per tap
+
+  auto stage = [&](int buf, int kt) {
+    char* xs = smem + buf * T::STAGE + lds_wave_off;
+    char* ws = xs + T::XBYTES;
+    const int tap = kt / cpk, c0 = (kt - tap * cpk) * BK;                       // scalar
+    const int shift = (((tap / 3 - 1) * cv.W + (tap % 3 - 1)) * cv.C + c0) * 2;  // bytes, may be negative
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) {
+      const int voff = ((xmask[i] >> tap) & 1) ? xrow[i] + shift : (int)0xFFFFFFF0;   // past the descriptor: reads as zero
+      CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), voff, 0);
+    }
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * T::WTM * 128;
+  const int wbase = T::XBYTES + wave_n * T::WTN * 128;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* st = smem + (kt & 1) * T::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  epilogue<T, EPI, false>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
+}
+
+template <typename T, int EPI>
+int launch_conv_tile(KArgs k, const ConvArgs& cv, hipStream_t s) {
+  static bool attr_set = false;
+  auto fn = gemm_conv3x3_kernel<T, EPI>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "conv3x3: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), T::SMEM, s, k, cv);
+  return check_launch("gemm_conv3x3_kernel");
+}
+
 // the convolution epilogues (ModifiedResNet, SURVEY f-4) only come in the three cost-model configurations
 template <int EPI, bool OUT_F32>
 int launch_basic(const KArgs& k, hipStream_t s) {
@@ -1332,6 +1456,25 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       set_error("gemm: unknown epilogue %d", a.epilogue);
       return CLIPMI_ERR_ARG;
   }
+}
+
+int launch_conv3x3(const half_t* x, const half_t* w, const float* bias, half_t* out, int B, int H, int W, int C, int Cout, int relu,
+                   hipStream_t s) {
+  if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(x && w && bias && out, CLIPMI_ERR_ARG, "conv3x3: null pointer");
+  CLIPMI_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 64 == 0 && Cout > 0 && Cout % 8 == 0, CLIPMI_ERR_SHAPE,
+                 "conv3x3: B=%d H=%d W=%d C=%d Cout=%d unsupported (C %% 64 == 0, Cout %% 8 == 0)", B, H, W, C, Cout);
+  CLIPMI_REQUIRE((int64_t)B * H * W * C * 2 < 0xFFFFFFF0ll && (int64_t)B * H * W < (1ll << 31), CLIPMI_ERR_SHAPE, "conv3x3: activation tensor too large for 32-bit offsets");
+  CLIPMI_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)bias % 16 == 0, CLIPMI_ERR_ARG,
+                 "conv3x3: pointers must be 16-byte aligned");
+  KArgs k{};
+  k.A = x; k.lda = C; k.W = w; k.ldw = 9 * (int64_t)C; k.bias = bias; k.out = out; k.ldo = Cout;
+  k.M = B * H * W; k.N = Cout; k.K = 9 * C;
+  const ConvArgs cv{H, W, C};
+  if (Cout <= 128) {
+    return relu ? launch_conv_tile<T128, CLIPMI_EPI_BIAS_RELU>(k, cv, s) : launch_conv_tile<T128, CLIPMI_EPI_BIAS>(k, cv, s);
+  }
+  return relu ? launch_conv_tile<T256w8, CLIPMI_EPI_BIAS_RELU>(k, cv, s) : launch_conv_tile<T256w8, CLIPMI_EPI_BIAS>(k, cv, s);
 }
 
 }  // namespace clipmi

@@ -136,6 +136,11 @@ class ModifiedResNet(nn.Module):
     @staticmethod
     def _conv3x3(x: torch.Tensor, B: int, H: int, W: int, C: int, wb, epilogue=EPI_BIAS_RELU) -> torch.Tensor:
         w, bias = wb
+        if C % 64 == 0 and w.shape[1] == 9 * C and w.shape[0] % 8 == 0:      # implicit GEMM: no im2col matrix
+            out = torch.empty(B * H * W, w.shape[0], dtype=torch.float16, device=x.device)
+            check(lib.clipmi_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W, C, w.shape[0],
+                                          1 if epilogue == EPI_BIAS_RELU else 0, ops._stream()), "clipmi_conv3x3_nhwc")
+            return out
         col = torch.empty(B * H * W, w.shape[1], dtype=torch.float16, device=x.device)
         check(lib.clipmi_im2col3x3_nhwc(x.data_ptr(), col.data_ptr(), B, H, W, C, w.shape[1], ops._stream()), "clipmi_im2col3x3_nhwc")
         return ops.gemm_f16(col, w, bias, None, epilogue, torch.float16)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 7
+#define CLIPMI_ABI_VERSION 8
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -121,7 +121,12 @@ int clipmi_softmax_rows(const float* logits, const float* dac_conf, float* probs
  *  clipmi_avgpool_nhwc     nn.AvgPool2d(k) (clip/model.py:23,33,112): x [B,H,W,C] -> y [B,H/k,W/k,C]
  *  clipmi_attnpool_tokens  AttentionPool2d token build (clip/model.py:69-71): tokens fp16 [B, HW+1, C] = [mean | x] + pos (fp32 [HW+1, C])
  *  clipmi_attnpool         its attention with the mean token as the only query (clip/model.py:72-90): q fp16 [B,C] (projected,
- *                          biased), kv fp16 [B*T, 2C] (k | v projected, biased), head_dim 64 -> out fp16 [B, C] (before c_proj) */
+ *                          biased), kv fp16 [B*T, 2C] (k | v projected, biased), head_dim 64 -> out fp16 [B, C] (before c_proj)
+ *  clipmi_conv3x3_nhwc     Bottleneck.conv2 + bn2 (+ ReLU) as an IMPLICIT GEMM (no im2col matrix): x fp16 [B,H,W,C], w fp16
+ *                          [Cout, 9*C] tap-major ((ky*3+kx)*C + c, BatchNorm folded), bias fp32 [Cout] -> out fp16 [B,H,W,Cout];
+ *                          stride 1, pad 1, C % 64 == 0, Cout % 8 == 0 */
+int clipmi_conv3x3_nhwc(const void* x, const void* w, const float* bias, void* out, int B, int H, int W, int C, int Cout,
+                        int relu, clipmi_stream_t stream);
 int clipmi_im2col3x3_nchw(const void* image, int image_dtype, void* col, int B, int Cin, int H, int W, int stride, int Kpad,
                           clipmi_stream_t stream);
 int clipmi_im2col3x3_nhwc(const void* x, void* col, int B, int H, int W, int C, int Kpad, clipmi_stream_t stream);

@@ -259,3 +259,31 @@ def test_softmax_rows_vs_oracle(ops, B, C, dac):
     check(lib.clipmi_softmax_rows(lg.data_ptr(), None if cc is None else torch.from_numpy(cc).cuda().data_ptr(), lg.data_ptr(),
                                   None, None, B, C, torch.cuda.current_stream().cuda_stream), "alias")
     assert np.abs(lg.cpu().numpy() - want).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,relu", [(2, 8, 8, 64, 64, 1), (3, 7, 5, 128, 136, 1), (1, 14, 14, 256, 256, 0), (5, 3, 9, 64, 8, 1),
+                                               (0, 4, 4, 64, 64, 1)])
+def test_conv3x3_implicit_gemm(B, H, W, C, Cout, relu):
+    """clipmi_conv3x3_nhwc (Bottleneck.conv2 + folded bn2 + ReLU, clip/model.py:20,46): implicit GEMM with hardware zero
+    padding against a plain fp32 torch convolution of the same fp16-rounded operands."""
+    import torch.nn.functional as F
+    from clip_calibration_amd._lib import check, lib
+    g = torch.Generator().manual_seed(B * 1000 + H * 100 + C)
+    x = torch.randn(B, H, W, C, generator=g).half()
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).half()
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xd = x.cuda().contiguous()
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous().cuda()      # tap-major: (ky*3+kx)*C + c
+    bd = bias.cuda()
+    out = torch.full((B * H * W, Cout), float("nan"), dtype=torch.float16, device="cuda")
+    check(lib.clipmi_conv3x3_nhwc(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, C, Cout, relu,
+                                  torch.cuda.current_stream().cuda_stream), "clipmi_conv3x3_nhwc")
+    if B == 0:
+        return
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
