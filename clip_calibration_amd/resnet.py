@@ -93,19 +93,27 @@ class ModifiedResNet(nn.Module):
         return res
 
     @staticmethod
-    def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, order: str, kpad: Optional[int] = None):
-        """(fp16 weight [Cout, Kpad], fp32 bias [Cout]) of conv followed by eval-mode bn.  ``order``: 'ckk' keeps the
-        checkpoint's (c, ky, kx) column order (stem conv1, fed by the NCHW im2col), 'kkc' puts the tap first (NHWC im2col)."""
+    def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, order: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None):
+        """(fp16 weight [Cout_p, Kpad], fp32 bias [Cout_p]) of conv followed by eval-mode bn.  ``order``: 'ckk' keeps the
+        checkpoint's (c, ky, kx) column order (stem conv1, fed by the NCHW im2col), 'kkc' puts the tap first (NHWC operands).
+        ``cin_pad`` / ``cout_pad`` add zero input / output channels (the stem's 32-channel activations are carried as 64 so that
+        the implicit-GEMM convolution applies: a padded output channel is relu(0 + 0) = 0 and meets zero weights downstream)."""
         w = conv.weight.detach().float()
         s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
         w = w * s[:, None, None, None]
-        w2 = (w.permute(0, 2, 3, 1) if order == "kkc" else w).reshape(w.shape[0], -1)
+        bias = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+        cout, cin = w.shape[0], w.shape[1]
+        ci, co = cin_pad or cin, cout_pad or cout
+        wp = torch.zeros(co, ci, w.shape[2], w.shape[3], dtype=torch.float32, device=w.device)
+        wp[:cout, :cin] = w
+        bp = torch.zeros(co, dtype=torch.float32, device=w.device)
+        bp[:cout] = bias
+        w2 = (wp.permute(0, 2, 3, 1) if order == "kkc" else wp).reshape(co, -1)
         k = w2.shape[1]
-        kp = kpad or _round_up(k, 64)
-        out = torch.zeros(w2.shape[0], kp, dtype=torch.float16, device=w.device)
+        kp = (k + 63) // 64 * 64
+        out = torch.zeros(co, kp, dtype=torch.float16, device=w.device)
         out[:, :k] = w2.to(torch.float16)
-        bias = (bn.bias.detach().float() - bn.running_mean.detach().float() * s).contiguous()
-        return out.contiguous(), bias
+        return out.contiguous(), bp.contiguous()
 
     def _ensure_packed(self):
         if self._packed is not None:
@@ -113,7 +121,10 @@ class ModifiedResNet(nn.Module):
         if self.conv1.weight.device.type != "cuda":
             raise RuntimeError("clipmi: the model must be on a ROCm GPU before it is run; there is no CPU path")
         p: Dict[str, object] = {}
-        p["stem"] = [self._fold(self.conv1, self.bn1, "ckk"), self._fold(self.conv2, self.bn2, "kkc"), self._fold(self.conv3, self.bn3, "kkc")]
+        hp = _round_up(self.width // 2, 64)      # stem activations carried with zero channels up to a multiple of 64
+        p["stem"] = [self._fold(self.conv1, self.bn1, "ckk", None, hp), self._fold(self.conv2, self.bn2, "kkc", hp, hp),
+                     self._fold(self.conv3, self.bn3, "kkc", hp, None)]
+        p["stem_c"] = hp
         blocks = []
         for li in range(1, 5):
             for b in getattr(self, f"layer{li}"):
@@ -169,8 +180,8 @@ class ModifiedResNet(nn.Module):
         check(lib.clipmi_im2col3x3_nchw(image.data_ptr(), _lib.F32 if image.dtype == torch.float32 else _lib.F16, col.data_ptr(), B, 3, R, R,
                                         2, w1.shape[1], ops._stream()), "clipmi_im2col3x3_nchw")
         x = ops.gemm_f16(col, w1, b1, None, EPI_BIAS_RELU, torch.float16)
-        x = self._conv3x3(x, B, H, W, w // 2, c2)
-        x = self._conv3x3(x, B, H, W, w // 2, c3)
+        x = self._conv3x3(x, B, H, W, p["stem_c"], c2)
+        x = self._conv3x3(x, B, H, W, p["stem_c"], c3)
         x = self._avgpool(x, B, H, W, w, 2)
         H, W, C = H // 2, W // 2, w
         # bottlenecks (clip/model.py:42-56)
