@@ -518,10 +518,10 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
       if (!causal && L > 192) return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
       return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
     }
-    // two-slot ring of 128-key blocks: 257 tokens (ViT-L/14) 73 us against 81 us for the single-buffer kernel; at 577 tokens
-    // (ViT-L/14@336) the kernel is bound by its softmax / MFMA issue, not by staging, and the 224-key blocks below are as fast
+    // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks 73 us against 81 us for the single-buffer kernel;
+    // 577 tokens (ViT-L/14@336) with 224-key blocks 205 us against 210 us (that shape is bound by softmax / MFMA issue)
     const char* ns = getenv("CLIPMI_ATTN_NO_STREAM");   // A/B aid
-    if (L <= 320 && !(ns && ns[0] == '1')) return launch_stream<4>(qkv, out, N, L, H, causal, s);
+    if (!(ns && ns[0] == '1')) return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
   }
   if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
   return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);
