@@ -883,6 +883,245 @@ int launch_persist(KArgs k, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Deferred-store persistent variant (fp16-out epilogues only): 256 x 192 tile, TWELVE waves of 64 x 64 (three per SIMD,
+// 170 VGPRs each), one workgroup per CU walking its tiles.  What it changes against the kernels above: the output of
+// tile i is converted to fp16 right after its main loop (bias / LayerNorm fold / QuickGELU) and HELD in 32 registers
+// per wave; its LDS transpose and global stores are then issued in four 16-row slices spread over the K loop of tile
+// i+1.  Every tile of the other kernels ends in a burst -- 256 CUs x 128 KB of stores at once, then a relaunch or a
+// vmcnt(0) that waits for that burst to be acknowledged (phase stamps: 2.6-5 us per 23-26 us tile).  Here the HBM write
+// stream is continuous and the only epilogue work left on the critical path is the element-wise math.
+// ---------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(768, 3) void gemm_defer_kernel(const KArgs a) {
+  constexpr int BM = 256, BN = 192, NT = 768, TM = 4, TN = 4, WGM = 4;
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int XI = 3, WI = 2;                       // 2048 / 768 (last one partial) and 1536 / 768 DMA instructions per stage
+  constexpr int ROWB = 64 * 2 + 16, PATCH = 16 * ROWB;
+  constexpr int PATCH_OFF = 2 * STAGE, LNP_OFF = PATCH_OFF + 12 * PATCH, COLP_OFF = LNP_OFF + 2 * BM * 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % WGM, wave_n = wave / WGM;
+  const int tiles_m = (a.M + BM - 1) / BM;
+
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
+  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
+  const int lds_wave_off = wave * 1024;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * 64 * 128;
+  const int wbase = XBYTES + wave_n * 64 * 128;
+  const int nk = a.K / BK;
+  const int step = nk >= 4 ? nk / 4 : 1;              // a store slice every `step` K-steps
+
+  auto coords = [&](int vb, int& m0, int& n0) {
+    const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_band = tiles_m * a.band;
+    const int b = wg / per_band;
+    const int within = wg - b * per_band;
+    const int rem = a.tiles_n - b * a.band;
+    const int gw = rem < a.band ? rem : a.band;
+    const int tm = within / gw;
+    m0 = tm * BM;
+    n0 = (b * a.band + (within - tm * gw)) * BN;
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
+    char* xs = smem + buf * STAGE + lds_wave_off;
+    char* ws = xs + XBYTES;
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      if (i * NT + wave * 64 < BM * 8)   // wave-uniform: the third instruction covers slots 1536..2047 only
+        CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff0, i * xstep), k0);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff0, i * wstep), k0);
+  };
+  constexpr bool CONSUMER = EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU;
+  auto params = [&](int row0, int col0, int which) {   // (rstd, mean*rstd) per row and (bias, g) per column of a tile -> LDS
+    if constexpr (CONSUMER) {
+      if (a.ln_stats) {
+        float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
+        for (int t = tid; t < BM; t += NT) {
+          float rs, mrs;
+          ln_row_params(a, row0 + t, rs, mrs);
+          dst[t] = make_float2(rs, mrs);
+        }
+      }
+    }
+    float* dst = reinterpret_cast<float*>(smem + COLP_OFF) + which * 2 * BN;
+    for (int t = tid; t < BN; t += NT) {
+      const int n = col0 + t;
+      dst[t] = (EPI != CLIPMI_EPI_NONE && n < a.N) ? a.bias[n] : 0.f;
+      dst[BN + t] = (n < a.N && a.ln_stats) ? a.ln_g[n] : 0.f;
+    }
+  };
+
+  int vb = blockIdx.x;
+  int m0, n0;
+  coords(vb, m0, n0);
+  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int first_buf = 0, par = 0;
+  stage(xrs, wrs, first_buf, 0);
+  params(m0, n0, 0);
+
+  f16x4 held[TN][TM];        // the previous tile's outputs of this wave, fp16
+  int hm0 = 0, hn0 = 0;      // its origin
+  int pending = TM;          // next 16-row slice (j) of `held` to store; TM = nothing held
+  half_t* out = static_cast<half_t*>(a.out);
+  char* patch = smem + PATCH_OFF + wave * PATCH;
+  auto flush = [&](int j) {  // slice j of the held tile: LDS transpose, then 16-byte stores, 128 contiguous bytes per row
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int er16 = le & 15, eg4 = le >> 4, rrow = le >> 3, rcol = le & 7;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) *reinterpret_cast<f16x4*>(patch + er16 * ROWB + (i * 16 + eg4 * 4) * 2) = held[i][j];
+    const int n_st = hn0 + wave_n * 64 + rcol * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t * 8 + rrow;
+      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+      const int m = hm0 + wave_m * 64 + j * 16 + row;
+      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
+    }
+  };
+
+  while (true) {
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = (first_buf + kt) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage kt (and the store slice issued a K-step ago)
+      __syncthreads();
+      if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
+      if (pending < TM && kt >= 1 + pending * step) {     // wave-uniform
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          if (j == pending) flush(j);
+        ++pending;
+      }
+      const char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f16x8 xf[TM], wcur, wnext;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          wcur = wnext;
+        }
+      }
+    }
+    // anything of the previous tile still held (short K): out it goes before `held` is overwritten
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      if (j >= pending) flush(j);
+
+    const int last_buf = (first_buf + nk - 1) & 1;
+    const int cm0 = m0, cn0 = n0;
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < a.nwg;
+    if (has_next) {
+      vb = nvb;
+      coords(vb, m0, n0);
+      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+      first_buf = last_buf ^ 1;
+      stage(xrs, wrs, first_buf, 0);
+      params(m0, n0, par ^ 1);
+    }
+    // ---- element-wise epilogue into `held` (row / column parameters from LDS)
+    {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int er16 = le & 15, eg4 = le >> 4;
+      const bool fold = CONSUMER && a.ln_stats != nullptr;
+      const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM;
+      const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float rs = 1.f, mrs = 0.f;
+        if (fold) {
+          const float2 pr = lnp[wave_m * 64 + j * 16 + er16];
+          rs = pr.x;
+          mrs = pr.y;
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nl = wave_n * 64 + i * 16 + eg4 * 4;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + BN + nl);
+          f32x4 v = acc[i][j] * rs + (bb - mrs * gg);
+          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          held[i][j] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+      }
+    }
+    hm0 = cm0;
+    hn0 = cn0;
+    pending = 0;
+    par ^= 1;
+    if (!has_next) break;
+  }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) flush(j);   // the last tile's outputs
+}
+
+template <int EPI>
+int launch_defer(KArgs k, hipStream_t s) {
+  constexpr int SMEM = 2 * (256 + 192) * 128 + 12 * 16 * 144 + 2 * 256 * 8 + 2 * 2 * 192 * 4;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  auto fn = gemm_defer_kernel<EPI>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+    n_cu &= ~7;
+    attr_set = true;
+  }
+  const int tiles_m = (k.M + 255) / 256;
+  k.tiles_n = (k.N + 191) / 192;
+  k.band = pick_band(k.tiles_n, 192, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  const int grid = k.nwg < n_cu ? k.nwg : n_cu;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(768), SMEM, s, k);
+  return check_launch("gemm_defer_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Pipelined variant (the default for large problems): 256 x 256 tile, 8 waves of 128(m) x 64(n), BK = 32 stages in
 // the 4-slot ring, loads three stages ahead.  Each stage is two clusters of 16 MFMAs (m-tiles 0-3, then 4-7, against
 // the stage's 4 n-tile fragments); the LDS reads of a cluster are issued one cluster ahead into a second register
@@ -1203,6 +1442,7 @@ int pick_variant(const KArgs& k) {
   if (e && e[0] == 'a') return 10;
   if (e && e[0] == 'b') return 11;
   if (e && e[0] == 'c') return 12;
+  if (e && e[0] == 'f') return 15;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
@@ -1381,6 +1621,11 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
     case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s);
+    case 15:   // deferred-store persistent kernel: fp16-out epilogues on 8-column-aligned outputs only
+      if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
+        if ((k.N & 7) == 0 && (k.ldo & 7) == 0) return launch_defer<EPI>(k, s);
+      }
+      return launch_tile<T256w16, EPI, OUT_F32>(k, s);
     case 12:
       if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) return launch_tile<T256w16, EPI, OUT_F32>(k, s);   // fold epilogue: 64-column wave tiles only
       else return launch_wide<T256w4, EPI, OUT_F32>(k, s);

@@ -61,7 +61,7 @@ def test_gemm(ops, M, N, K, epi):
     assert err <= tol * scale, f"max err {err} vs scale {scale}"
 
 
-@pytest.mark.parametrize("variant", [str(v) for v in range(10)] + ["a", "b", "c"])
+@pytest.mark.parametrize("variant", [str(v) for v in range(10)] + ["a", "b", "c", "f"])
 @pytest.mark.parametrize("M,N,K,epi", [(200, 192, 128, "gelu"), (1000, 2304, 768, "bias"), (333, 512, 3072, "residual"),
                                         (50432, 768, 768, "residual"), (513, 260, 64, "none"), (5000, 3072, 768, "gelu")])
 def test_gemm_tile_variants(ops, monkeypatch, variant, M, N, K, epi):
