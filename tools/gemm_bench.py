@@ -46,6 +46,8 @@ def main():
     for name, m, n, k, epi, odt in SHAPES:
         a = torch.randn(m, k, device="cuda", generator=g).half()
         w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).half()
+        if os.environ.get("ZERO") == "1":      # power / clock probe: the same instruction stream on all-zero operands
+            a.zero_(); w.zero_()
         bias = torch.randn(n, device="cuda", generator=g) * 0.1
         res = torch.randn(m, n, device="cuda", generator=g) if epi == _lib.EPI_BIAS_RESIDUAL else None
         flop = 2.0 * m * n * k
