@@ -1452,7 +1452,10 @@ int pick_variant(const KArgs& k) {
     const int64_t tiles = (int64_t)((k.M + c.bm - 1) / c.bm) * ((k.N + c.bn - 1) / c.bn);
     const int64_t slots = (int64_t)cus * c.per_cu;
     const int64_t rounds = (tiles + slots - 1) / slots;
-    const double cost = (double)rounds * c.bm * c.bn * c.per_cu * c.penalty;
+    double cost = (double)rounds * c.bm * c.bn * c.per_cu * c.penalty;
+    // short K (the text tower's width-512 GEMMs): the per-tile fixed cost weighs more, and the 320-row tile has 20 % fewer
+    // tiles -- measured +4 % on the whole text tower at 4000-16000 prompts, equal at 1000 (tools/text_bench.py)
+    if (c.id == 10 && k.K <= 512) cost *= 0.93;
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
   // CLIPMI_GEMM_PERSIST=1: use the persistent form of (1) (variant b: next tile's first stage prefetched before the
