@@ -5,16 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one synthetic batch that is already resident in HBM: image tower (HIP) ->
-L2 normalise -> [N > 1: one RCCL all-gather of the per-GPU normalised image embeddings] -> scale * img @ txt^T ->
-softmax top-1 (conf, pred) -> device-side ECE accumulation.  Workload at N=1 = BASELINE config[1]: ImageNet-1k
-zero-shot shape (1000 prompts), batch 256 per GPU, seeded random ViT-B/16 weights (no checkpoints offline).  Text
-features are computed once before the timed region (zsclip.py:90-92) and their time is reported separately.
+One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  N = 1:  image tower (HIP)  ->  ONE fused tail launch: L2 normalise, scale * img @ txt^T, softmax top-1 (conf, pred),
+          ECE bin accumulation (clipmi_fused_tail).
+  N > 1:  image tower -> L2 normalise to fp16 -> ONE RCCL all-gather of the per-GPU embeddings over xGMI
+          (clipmi_allgather) -> the same fused tail on the gathered batch (every rank).
+Workload (default, the headline) = BASELINE configs[1]: ImageNet-1k zero-shot shape (1000 prompts), batch 256 per GPU,
+seeded random ViT-B/16 weights (no checkpoints offline).  Text features are computed once before the timed region
+(zsclip.py:90-92) and their time is reported separately.  `--workload coop_dac` = BASELINE configs[2] (second,
+non-headline line): CoOp 16-shot prompts (n_ctx 16, 500 classes), DAC per-class factors fitted on base / new text
+features, TempScaling scalar; reported with the text features cached and with the text tower re-run every batch (the
+reference's behaviour, trainers/classification/coop.py:208-210).
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
+HBM_PEAK_BYTES_PER_S = 8.0e12        # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 
 
 def parse():
@@ -35,10 +43,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("zeroshot", "coop_dac"), default="zeroshot")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--classes", type=int, default=1000)
+    ap.add_argument("--classes", type=int, default=None, help="default: 1000 (zeroshot) / 500 (coop_dac)")
     ap.add_argument("--model", default="ViT-B/16")
+    ap.add_argument("--exchange-f16", action="store_true",
+                    help="N = 1 only: pass the embeddings through the fp16 exchange format of the N > 1 path (no gather), "
+                         "so that a 1-process run is bitwise comparable with any N-process run on the same images")
+    ap.add_argument("--images-seed", type=int, default=None, help="seed of the per-rank image shard (default: rank)")
+    ap.add_argument("--virtual-ranks", type=int, default=1,
+                    help="N = 1 only: process the image shards of this many ranks in ONE process (batch = ranks x --batch); with "
+                         "--exchange-f16 the outputs equal rank 0's of the real N-process run bit for bit (self-test aid)")
+    ap.add_argument("--dump", default=None, help="rank 0: save logits / conf / pred / ECE bins of the last step to this .npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel profile (functional multi-rank self-tests)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-classes", type=int, default=100, help="BASELINE configs[0]: Caltech101-sized prompt set")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -46,13 +64,13 @@ def parse():
 
 
 def cpu_baseline(sd, geom_name, n_cls, batch, budget_s):
-    """The oracle (CPU restatement of the reference path, fp32, all host cores) on BASELINE config[0]'s shape:
-    image tower -> normalise -> logits -> softmax -> ECE.  Returns (images/s, cores, sample text, logits, images)."""
+    """The oracle (CPU restatement of the reference path, fp32) on BASELINE config[0]'s shape: image tower -> normalise ->
+    logits -> softmax -> ECE.  Returns (images/s, cores, cores available, sample text, logits, images, labels)."""
     from clip_calibration_amd import synthetic as syn
     from oracle import clip_oracle as orc  # timed baseline + checker only
 
     # torch CPU kernels collapse when oversubscribed (256 logical CPUs on the GPU box -> 0.5 img/s): take the CPUs
-    # this process may actually run on, capped at 32, and report that count.
+    # this process may actually run on, capped at 32, and report both counts.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -82,7 +100,67 @@ def cpu_baseline(sd, geom_name, n_cls, batch, budget_s):
     med = float(np.median(times))
     sample = (f"{len(times)} timed iterations (1 warm-up) of batch {batch} x {n_cls} prompts, fp32 oracle on {cores} host "
               f"threads, median {med:.3f} s/batch; text tower once {t_text:.2f} s (excluded)")
-    return batch / med, cores, sample, logits, images, labels
+    return batch / med, cores, avail, sample, logits, images, labels
+
+
+def timed_ms(fn, iters):
+    """Mean milliseconds per call, torch events on the current stream (the stream every launch of the path goes to)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_roofline(model, syn, geom, model_name, B, images):
+    """Per-kernel roofline measured live: hipEvents on the launch stream around every launch (clipmi_profile_block), the
+    five per-layer kernels exactly as the tower launches them, on the activations the last step left in the workspace."""
+    L, D = geom.vision_tokens, geom.vision_width
+    M = B * L
+    blk_ms = model.profile_block_ms(B, iters=24)
+    blk_flop = {"in_proj": 2.0 * M * 3 * D * D, "attention": 4.0 * B * L * L * D, "out_proj": 2.0 * M * D * D,
+                "c_fc": 2.0 * M * 4 * D * D, "c_proj": 2.0 * M * 4 * D * D}
+    blk_shape = {"in_proj": {"M": M, "N": 3 * D, "K": D}, "attention": {"sequences": B, "tokens": L, "heads": D // 64},
+                 "out_proj": {"M": M, "N": D, "K": D}, "c_fc": {"M": M, "N": 4 * D, "K": D}, "c_proj": {"M": M, "N": D, "K": 4 * D}}
+    kernels = []
+    for name in model.BLOCK_KERNELS:
+        tf = blk_flop[name] / (blk_ms[name] * 1e-3) / 1e12
+        kernels.append({"kernel": name, "shape": blk_shape[name], "flop_per_launch": blk_flop[name], "us_per_launch": 1e3 * blk_ms[name],
+                        "achieved": tf, "frac": tf / MFMA_F16_DENSE_PEAK_TFLOPS})
+    dom = max(kernels, key=lambda k: k["us_per_launch"])
+    with torch.no_grad():
+        tower_ms = timed_ms(lambda: model.image_features_f32(images), 10)
+    tower_flop = syn.flops_per_image(model_name) * B
+    tower_tf = tower_flop / (tower_ms * 1e-3) / 1e12
+    # HBM-side bytes per launch of the dominant kernel come from PMC passes (rocprofv3 cannot run inside this process):
+    # tools/measure_traffic.sh writes profiles/gemm_traffic.json stamped with the sha256 of the kernel source it measured;
+    # reported only when shape AND source still match, otherwise null.
+    traffic, note = None, "no PMC profile for this kernel source (tools/measure_traffic.sh regenerates it)"
+    try:
+        with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
+            prof = json.load(f)
+        with open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "gemm.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+        ent = prof.get("kernels", {}).get(dom["kernel"])
+        if prof.get("gemm_hip_sha256") == sha and ent and ent["shape"] == dom["shape"]:
+            traffic = ent["traffic_bytes"]
+            note = ("HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 --pmc in separate passes with the gfx950 "
+                    "FETCH_SIZE x2 correction (profiles/gemm_traffic.json, measured on this gemm.hip); algorithmic bytes = "
+                    f"{ent.get('algorithmic_bytes')}")
+        else:
+            note = "profiles/gemm_traffic.json was measured on a different gemm.hip: dropped"
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "mfma", "kernel": dom["kernel"] + " (dominant launch: one per layer, 12 per step)", "shape": dom["shape"],
+            "flop_per_launch": dom["flop_per_launch"], "avg_launch_ms": dom["us_per_launch"] * 1e-3, "achieved": dom["achieved"],
+            "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_note": note,
+            "kernels": kernels,
+            "tower": {"ms": tower_ms, "flop": tower_flop, "achieved": tower_tf, "frac": tower_tf / MFMA_F16_DENSE_PEAK_TFLOPS},
+            "tower_frac": tower_tf / MFMA_F16_DENSE_PEAK_TFLOPS}
 
 
 def main():
@@ -96,7 +174,7 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # BENCH_SAME_GPU=1 is a functional self-test of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the
-    # collectives go through gloo (RCCL refuses two ranks on one device).  Never use it for a measurement.
+    # exchange goes through torch.distributed/gloo (RCCL refuses two ranks on one device).  Never a measurement.
     same_gpu = os.environ.get("BENCH_SAME_GPU") == "1"
     if same_gpu:
         local_rank = 0
@@ -106,84 +184,147 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if same_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # the process group only carries the RCCL unique id and the timing barrier: gloo is enough for that
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from clip_calibration_amd import ops, synthetic as syn
     from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
     from clip_calibration_amd.model import build_model
-    from clip_calibration_amd.parallel import all_gather_embeddings
-    from clip_calibration_amd.trainers import ZeroshotCLIP
+    from clip_calibration_amd.parallel import EmbeddingExchange
+    from clip_calibration_amd.trainers import CoOpCLIP, ZeroshotCLIP
 
     geom = syn.GEOMETRIES[args.model]
-    B, Cn = args.batch, args.classes
+    coop = args.workload == "coop_dac"
+    B = args.batch
+    Cn = args.classes or (500 if coop else 1000)
+    E = geom.embed_dim
     sd = syn.synthetic_state_dict(args.model, seed=0)
-    model = build_model(dict(sd), {"trainer": "ZeroshotCLIP"}).to(dev)
-    ids = syn.synthetic_token_ids(Cn, args.model, seed=0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    zs = ZeroshotCLIP(model, ids)
-    torch.cuda.synchronize()
-    text_s_cold = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    zs.build_model(ids)
-    torch.cuda.synchronize()
-    text_s = time.perf_counter() - t0
+    model = build_model(dict(sd), {"trainer": "CoOp" if coop else "ZeroshotCLIP"}).to(dev)
+    exchange = EmbeddingExchange(dev, backend="torch" if same_gpu else "rccl") if world > 1 else None
 
-    images = syn.synthetic_images(B, args.model, seed=rank, device=dev)   # resident in HBM before the timed region
-    scale = zs.scale
+    # ---- text side: computed once, outside the timed region (zsclip.py:90-92; CoOp: cached while ctx is unchanged)
+    extra = {}
+    dac_conf = None
+    text_again = None
+    if coop:
+        from clip_calibration_amd.dac import DistanseAwareCalibration
+        n_ctx = 16
+        ids_new = syn.synthetic_token_ids(Cn, args.model, seed=11, n_ctx_placeholders=n_ctx)
+        ids_base = syn.synthetic_token_ids(Cn, args.model, seed=10, n_ctx_placeholders=n_ctx)
+        tuned_new = CoOpCLIP(model, ids_new, n_ctx=n_ctx, logit_scale=1.0, seed=3)     # cosine base model (base_model/coop.py:222-224)
+        tuned_base = CoOpCLIP(model, ids_base, n_ctx=n_ctx, logit_scale=1.0, seed=3)
+        zs_new = ZeroshotCLIP(model, syn.synthetic_token_ids(Cn, args.model, seed=11))
+        zs_base = ZeroshotCLIP(model, syn.synthetic_token_ids(Cn, args.model, seed=10))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        text_features = tuned_new.text_features()
+        torch.cuda.synchronize()
+        text_s_cold = time.perf_counter() - t0
+        cal = DistanseAwareCalibration()
+        cal.fit(zs_base.text_features.cpu().numpy(), zs_new.text_features.cpu().numpy(),
+                tuned_base.text_features().cpu().numpy(), text_features.cpu().numpy(), 5)
+        dac_conf = cal.class_confidence_device(dev)
+        scale = float(np.exp(4.6052))                                                   # TempScaling scalar (tempscaling.py:34)
+
+        def text_again():
+            tuned_new._cache = None
+            tuned_new._cache_key = None
+            return tuned_new.text_features()
+        with torch.no_grad():
+            text_s = timed_ms(text_again, 5) * 1e-3
+        text_features = tuned_new.text_features()
+    else:
+        ids = syn.synthetic_token_ids(Cn, args.model, seed=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        zs = ZeroshotCLIP(model, ids)
+        torch.cuda.synchronize()
+        text_s_cold = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        zs.build_model(ids)
+        torch.cuda.synchronize()
+        text_s = time.perf_counter() - t0
+        text_features, scale = zs.text_features, zs.scale
+
+    img_seed = rank if args.images_seed is None else args.images_seed + rank
+    if args.virtual_ranks > 1:
+        assert world == 1, "--virtual-ranks is a single-process aid"
+        images = torch.cat([syn.synthetic_images(B, args.model, seed=img_seed + k, device=dev) for k in range(args.virtual_ranks)])
+        B = B * args.virtual_ranks
+    else:
+        images = syn.synthetic_images(B, args.model, seed=img_seed, device=dev)   # resident in HBM before the timed region
     evaluator = DeviceCalibrationEvaluator(10, dev)
+    n_bins = evaluator.n_bins
+    f16_exchange = world > 1 or args.exchange_f16
 
-    def step(labels):
-        img_n = ops.l2_normalize(model.image_features_f32(images))
-        all_n = all_gather_embeddings(img_n) if world > 1 else img_n
-        logits, conf, pred = ops.logits_fused(all_n, zs.text_features, scale, None, True)
-        if labels is not None:
-            evaluator.process(conf, pred, labels)
-        return logits, conf, pred
+    def tail(feats, labels, txt):
+        bins = evaluator.bins if labels is not None else None
+        if f16_exchange:
+            emb = ops.l2_normalize(feats, torch.float16)                               # [B, E] fp16: 2*B*E bytes per rank on the wire
+            if exchange is not None:
+                emb = exchange.all_gather(emb)                                         # [world*B, E], rank-major
+            return ops.fused_tail(emb, txt, scale, dac_conf, True, False, labels, bins, n_bins)
+        return ops.fused_tail(feats, txt, scale, dac_conf, True, True, labels, bins, n_bins)
 
-    with torch.no_grad():
-        _, _, pred0 = step(None)                                   # also sizes the workspaces
-        labels = syn.synthetic_labels(pred0, Cn, seed=1).to(dev)  # 70 % agree with the prediction: non-degenerate ECE
-        for _ in range(args.warmup):
-            step(labels)
+    def step(labels, recompute_text=False):
+        txt = text_again() if recompute_text else text_features
+        return tail(model.image_features_f32(images), labels, txt)
+
+    def run(labels, n_steps, recompute_text=False):
         evaluator.reset()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(labels)
+        for _ in range(n_steps):
+            out_ = step(labels, recompute_text)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res = evaluator.evaluate()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out_
 
-    # ---- dominant kernel: MLP up-projection GEMM (bias + QuickGELU epilogue), 12 launches per step --------------
-    M, N, K = B * geom.vision_tokens, 4 * geom.vision_width, geom.vision_width
-    gemm_ms = model.profile_mlp_gemm_ms(B, iters=24)              # hipEvents on the launch stream, per launch
-    gemm_flop = 2.0 * M * N * K
-    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
-    # HBM-side bytes per launch of that kernel come from the PMC passes committed under profiles/ (rocprofv3 cannot
-    # run inside this process); only reported when the profile is for exactly this shape.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_mlp_gemm_traffic.json")) as f:
-            prof = json.load(f)
-        if prof["shape"] == {"M": M, "N": N, "K": K}:
-            traffic = prof["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    rows = world * B if exchange is not None else B
+    with torch.no_grad():
+        _, _, _, pred0 = step(None)                               # also sizes the workspaces
+        # labels for every row the tail sees (the gathered batch when N > 1): 70 % agree with the prediction -> non-degenerate ECE
+        labels = syn.synthetic_labels(pred0.cpu(), Cn, seed=1).to(dev)
+        assert labels.numel() == rows
+        for _ in range(args.warmup):
+            step(labels)
+        elapsed, last = run(labels, args.steps)
+        res = evaluator.evaluate()
+        bins_np = evaluator.bins.cpu().numpy().copy()
+        if coop:
+            n_rt = max(2, args.steps // 2)
+            for _ in range(2):
+                step(labels, True)
+            elapsed_rt, _ = run(labels, n_rt, True)
+            extra["coop_dac"] = {
+                "images_per_s_text_cached": world * B * args.steps / elapsed,
+                "images_per_s_text_recomputed_every_batch": world * B * n_rt / elapsed_rt,
+                "text_tower_prompts_per_s": Cn / text_s, "text_tower_ms": 1e3 * text_s,
+                "text_tower_tflops": 5.960e9 * Cn / text_s / 1e12 if args.model == "ViT-B/16" else None,
+                "note": "the reference recomputes the text tower on every batch (trainers/classification/coop.py:208-210); "
+                        "ctx is frozen at eval, so the features are cached here (precedent: proda.py:315-333)",
+                "n_ctx": 16, "dac": "on (k = 5)", "tempscaling_logit_scale": 4.6052}
 
+    if args.dump and rank == 0:
+        np.savez(args.dump, logits=last[0].cpu().numpy(), conf=last[2].cpu().numpy(), pred=last[3].cpu().numpy(), bins=bins_np,
+                 ece=res["ece"])
+
+    tail_bytes = (2.0 if f16_exchange else 4.0) * rows * E + 4.0 * Cn * E + 4.0 * rows * Cn + 16.0 * rows
+    workload = (f"BASELINE configs[2]: CoOp 16-shot {args.model} base->new eval + DAC + TempScaling scalar, {Cn} classes, batch {B} per GPU, "
+                "text features cached" if coop else
+                f"BASELINE configs[1]: zero-shot CLIP {args.model}, ImageNet-1k shape ({Cn} text prompts), batch {B} per GPU, "
+                f"224x224 randn images, seeded random weights")
     out = {
-        "metric": "images/sec ViT-B/16 224px zero-shot + ECE",
+        "metric": ("images/sec ViT-B/16 224px zero-shot + ECE" if not coop
+                   else "images/sec ViT-B/16 CoOp base->new + DAC + ECE (BASELINE configs[2]; not the headline metric)"),
         "value": world * B * args.steps / elapsed,
         "unit": "images/s",
         "n_gpus": world,
@@ -195,27 +336,36 @@ def main():
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: zero-shot CLIP {args.model}, ImageNet-1k shape ({Cn} text prompts), "
-                               f"batch {B} per GPU, 224x224 randn images, seeded random weights",
-                   "batch_per_gpu": B, "global_batch": world * B, "classes": Cn,
-                   "parallelism": f"dp{world}: batch sharded, one RCCL all-gather of [B,{geom.embed_dim}] fp32 embeddings per step"
+        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": world * B, "classes": Cn,
+                   "parallelism": (f"dp{world}: batch sharded, one {'RCCL' if exchange.backend == 'rccl' else 'gloo (same-GPU self-test)'} "
+                                   f"all-gather of [B,{E}] fp16 embeddings per step, logits on the gathered batch on every rank")
                    if world > 1 else "single GPU"},
         "images_per_sec_per_gpu": B * args.steps / elapsed,
         "tower_tflops": syn.flops_per_image(args.model) * world * B * args.steps / elapsed / 1e12,
         "text_tower_once_s": text_s, "text_tower_first_call_s": text_s_cold,
         "ece_percent": res["ece"], "accuracy_percent": res["accuracy"],
-        "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<Tile<256,256,4,4,4>, BIAS_QUICKGELU, f16> (MLP c_fc)",
-                     "shape": {"M": M, "N": N, "K": K}, "flop_per_launch": gemm_flop, "avg_launch_ms": gemm_ms,
-                     "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_note": "HBM-side bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01_mlp_gemm_traffic.json; "
-                                     "algorithmic bytes = 2*(M*K + N*K + M*N)"},
     }
+    out.update(extra)
+    if world > 1:
+        out["exchange"] = {"backend": exchange.backend, "rccl_ranks": exchange.rccl_ranks, "bytes_per_rank_per_step": 2 * B * E,
+                           "world_size": world}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, cores, sample, lg_ref, cpu_images, cpu_labels = cpu_baseline(sd, args.model, args.cpu_classes, args.cpu_batch,
-                                                                         args.cpu_seconds)
-        out["cpu_baseline"] = {"value": v, "unit": "images/s", "cores": cores, "kind": "port", "sample": sample}
+    if not args.no_roofline:
+        with torch.no_grad():
+            out["roofline"] = kernel_roofline(model, syn, geom, args.model, B, images)
+            feats = model.image_features_f32(images)
+            tail_ms = timed_ms(lambda: tail(feats, labels, text_features), 50)
+        out["tail"] = {"what": "ONE launch (fused_tail_kernel): L2-normalise + scale*img@txt^T" + (" + DAC row scale" if coop else "") +
+                               " + softmax top-1 (conf, pred) + ECE bin accumulation" +
+                               (" [preceded by the fp16 normalise kernel" + (" and the all-gather]" if world > 1 else "]") if f16_exchange else ""),
+                       "bound": "hbm", "bytes": tail_bytes, "us": 1e3 * tail_ms, "achieved": tail_bytes / (tail_ms * 1e-3) / 1e9, "unit": "GB/s",
+                       "peak": HBM_PEAK_BYTES_PER_S / 1e9, "frac": tail_bytes / (tail_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                       "bytes_note": "algorithmic: image features in + text features in + fp32 logits out + (conf, pred, label) per row"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not coop:
+        v, cores, avail, sample, lg_ref, cpu_images, cpu_labels = cpu_baseline(sd, args.model, args.cpu_classes, args.cpu_batch,
+                                                                                args.cpu_seconds)
+        out["cpu_baseline"] = {"value": v, "unit": "images/s", "cores": cores, "cores_available": avail, "kind": "port", "sample": sample}
         # parity on exactly that sample: HIP path vs oracle
         zs_cpu = ZeroshotCLIP(model, syn.synthetic_token_ids(args.cpu_classes, args.model, seed=0))
         with torch.no_grad():
@@ -223,11 +373,13 @@ def main():
         from clip_calibration_amd.metrics import ECE
         from oracle import clip_oracle as orc
         ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy(), cpu_labels.numpy())
-        out["parity"] = {"max_abs_cosine_logit_err": float(np.abs(lg.cpu().numpy() - lg_ref.numpy()).max() / scale),
+        out["parity"] = {"max_abs_cosine_logit_err": float(np.abs(lg.cpu().numpy() - lg_ref.numpy()).max() / zs_cpu.scale),
                          "ece_delta": abs(ECE(conf.cpu().numpy(), pred.cpu().numpy(), cpu_labels.numpy()) - ece_ref),
                          "sample": f"{args.cpu_batch} images x {args.cpu_classes} prompts"}
     if rank == 0:
         print(json.dumps(out))
+    if exchange is not None:
+        exchange.close()
     if world > 1:
         dist.destroy_process_group()
 

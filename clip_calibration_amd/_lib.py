@@ -10,13 +10,15 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libclipmi.so")
+# CLIPMI_LIBRARY selects another BUILD of the same library (the tuning build with phase stamps); never a different backend
+LIB_PATH = os.environ.get("CLIPMI_LIBRARY") or os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 10
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
+COMM_ID_BYTES = 128
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL16_RELU = 0, 1, 2, 3, 4, 5
 
 
@@ -67,12 +69,22 @@ _SIGNATURES = {
     "clipmi_abi_version": (C.c_int, []),
     "clipmi_strerror": (C.c_char_p, [_i]),
     "clipmi_last_error": (C.c_char_p, []),
+    "clipmi_set_option": (_i, [C.c_char_p, _i]),
+    "clipmi_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "clipmi_gemm_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "clipmi_layernorm": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp]),
     "clipmi_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "clipmi_fused_tail_workspace_bytes": (_sz, [_i]),
+    "clipmi_l2_normalize_to": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "clipmi_comm_unique_id": (_i, [_vp]),
+    "clipmi_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "clipmi_comm_destroy": (_i, [_vp]),
+    "clipmi_comm_ranks": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "clipmi_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "clipmi_fused_tail": (_i, [_vp, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "clipmi_calibrate_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "clipmi_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "clipmi_im2col3x3_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -99,7 +111,7 @@ _SIGNATURES = {
     "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _vp]),
     "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _vp]),
     "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "clipmi_profile_mlp_gemm": (_i, [_vp, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
+    "clipmi_profile_block": (_i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -121,6 +133,45 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != OK:
         raise ClipmiError(rc, what, last_error() or (lib.clipmi_strerror(rc) or b"").decode())
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide runtime switch (include/clipmi.h, clipmi_set_option)."""
+    check(lib.clipmi_set_option(name.encode(), int(value)), "clipmi_set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib.clipmi_get_option(name.encode(), C.byref(v)), "clipmi_get_option")
+    return v.value
+
+
+class option:
+    """``with option("ln_fold", 0): ...`` -- set a switch for a block and restore the previous value."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
+
+
+_VARIANT_LETTERS = {"a": 10, "b": 11, "c": 12, "f": 15}
+
+
+def gemm_variant_id(v) -> int:
+    """'0'..'9' / 'a' 'b' 'c' 'f' (the historical CLIPMI_GEMM_VARIANT spellings) or an int -> option value; None -> -1."""
+    if v is None:
+        return -1
+    if isinstance(v, int):
+        return v
+    return _VARIANT_LETTERS.get(v, None) if v in _VARIANT_LETTERS else int(v)
 
 
 def exported_symbols():

@@ -434,13 +434,9 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const half_t* 
 template <int NKT>
 int launch_stream(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = attention_stream_kernel<NKT>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-      (void)hipGetLastError();
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, SMEM, attr_once);
   const int nqt = (L + 31) / 32;
   const int qsplit = (nqt + 7) / 8;
   const int nw = (nqt + qsplit - 1) / qsplit < 4 ? 4 : (nqt + qsplit - 1) / qsplit;   // query tiles spread evenly over the splits
@@ -452,25 +448,16 @@ int launch_stream(const half_t* qkv, half_t* out, int N, int L, int H, int causa
 template <int NKT, int GROUP, int DENSE>
 int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
-  static bool attr_set = false;
-  static int n_cu = 0;
+  static DeviceOnce attr_once;
   auto fn = attention_persist_kernel<NKT, GROUP, DENSE>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-      (void)hipGetLastError();
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, SMEM, attr_once);
+  const int n_cu = device_cus();
   const int nqt = (L + 31) / 32;
   const int nw = nqt < 4 ? 4 : nqt;                  // <= 7 here
   const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
   const int n_items = N * H;
   const int grid = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
-  const char* st = getenv("CLIPMI_ATTN_STAGGER");
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items, st ? atoi(st) : 0);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items, options().attn_stagger.load(std::memory_order_relaxed));
   return check_launch("attention_persist_kernel");
 }
 
@@ -478,13 +465,9 @@ template <int NKT, int GROUP, bool TR>
 int launch_t(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int KEYS = NKT * 32;
   constexpr int SMEM = KEYS * 128 + (TR ? KEYS * 128 : 64 * (NKT * 64 + 8));
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = attention_kernel<NKT, GROUP, TR>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
-      (void)hipGetLastError();
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, SMEM, attr_once);
   const int nqt = (L + 31) / 32;
   const int nw = nqt < 4 ? 4 : (nqt > 8 ? 8 : nqt);
   const int qsplit = (nqt + nw - 1) / nw;
@@ -496,10 +479,7 @@ int launch_t(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hi
 }  // namespace
 
 // CLIPMI_ATTN_NO_TR=1 selects the register-transposed V image instead of ds_read_b64_tr_b16 (A/B + bring-up aid).
-static bool use_tr() {
-  const char* e = getenv("CLIPMI_ATTN_NO_TR");
-  return !(e && e[0] == '1');
-}
+static bool use_tr() { return options().attn_no_tr.load(std::memory_order_relaxed) != 1; }
 
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   if (N == 0) return CLIPMI_OK;
@@ -508,8 +488,7 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   CLIPMI_REQUIRE((int64_t)N * H < (1ll << 31), CLIPMI_ERR_SHAPE, "attention: grid too large");
   CLIPMI_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, CLIPMI_ERR_ARG, "attention: unaligned pointer");
   const bool tr = use_tr();
-  const char* np = getenv("CLIPMI_ATTN_NO_PERSIST");
-  if (tr && !(np && np[0] == '1')) {
+  if (tr && options().attn_no_persist.load(std::memory_order_relaxed) != 1) {
     if (L <= 96) {
       if (causal && L > 64) return launch_persist<3, 3, 2>(qkv, out, N, L, H, causal, s);
       return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);
@@ -520,8 +499,8 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
     }
     // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks 73 us against 81 us for the single-buffer kernel;
     // 577 tokens (ViT-L/14@336) with 224-key blocks 205 us against 210 us (that shape is bound by softmax / MFMA issue)
-    const char* ns = getenv("CLIPMI_ATTN_NO_STREAM");   // A/B aid
-    if (!(ns && ns[0] == '1')) return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
+    if (options().attn_no_stream.load(std::memory_order_relaxed) != 1)   // A/B aid
+      return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
   }
   if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
   return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);

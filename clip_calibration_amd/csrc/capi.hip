@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -28,6 +29,80 @@ int check_launch(const char* what) {
     return CLIPMI_ERR_HIP;
   }
   return CLIPMI_OK;
+}
+
+namespace {
+
+struct OptionDesc { const char* name; const char* env; std::atomic<int> Options::*field; };
+const OptionDesc kOptions[] = {
+    {"gemm_variant", "CLIPMI_GEMM_VARIANT", &Options::gemm_variant},
+    {"gemm_band", "CLIPMI_GEMM_BAND", &Options::gemm_band},
+    {"gemm_persist", "CLIPMI_GEMM_PERSIST", &Options::gemm_persist},
+    {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
+    {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
+    {"attn_no_tr", "CLIPMI_ATTN_NO_TR", &Options::attn_no_tr},
+    {"attn_no_persist", "CLIPMI_ATTN_NO_PERSIST", &Options::attn_no_persist},
+    {"attn_no_stream", "CLIPMI_ATTN_NO_STREAM", &Options::attn_no_stream},
+    {"attn_stagger", "CLIPMI_ATTN_STAGGER", &Options::attn_stagger},
+    {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
+};
+
+// environment spelling -> option value: decimal integers, plus the historical letters of two switches
+// (CLIPMI_GEMM_VARIANT a/b/c/f = 10/11/12/15, CLIPMI_RESIDUAL_F16 v/t = 2/3)
+int parse_option(const char* name, const char* text) {
+  if (!strcmp(name, "gemm_variant")) {
+    switch (text[0]) { case 'a': return 10; case 'b': return 11; case 'c': return 12; case 'f': return 15; default: break; }
+  }
+  if (!strcmp(name, "residual_f16")) {
+    switch (text[0]) { case 'v': return 2; case 't': return 3; default: break; }
+  }
+  return atoi(text);
+}
+
+Options g_options;
+std::once_flag g_options_once;
+
+std::atomic<int> g_cus[64];
+
+}  // namespace
+
+#ifdef CLIPMI_TUNING
+std::atomic<long long*> g_tuning_stamps{nullptr};
+#endif
+
+Options& options() {
+  std::call_once(g_options_once, [] {
+    for (const OptionDesc& d : kOptions) {
+      const char* e = getenv(d.env);
+      if (e && e[0]) (g_options.*(d.field)).store(parse_option(d.name, e), std::memory_order_relaxed);
+    }
+  });
+  return g_options;
+}
+
+int current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return dev;
+}
+
+int device_cus() {
+  const int dev = current_device();
+  if (dev >= 0 && dev < 64) {
+    const int cached = g_cus[dev].load(std::memory_order_relaxed);
+    if (cached > 0) return cached;
+  }
+  int n = 0;
+  if (dev >= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  if (n <= 0) n = 256;
+  if (dev >= 0 && dev < 64) g_cus[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 }  // namespace clipmi
@@ -97,47 +172,61 @@ int check_block(const clipmi_block_weights& b) {
   return CLIPMI_OK;
 }
 
-// One ResidualAttentionBlock (clip/model.py:185-188) over M = n_seq*L rows.
+// One ResidualAttentionBlock (clip/model.py:185-188) over M = n_seq*L rows, as five launches:
+//   0 in-proj (+ ln_1)   1 attention   2 out-proj + residual   3 c_fc + QuickGELU (+ ln_2)   4 c_proj + residual
 // folded == true: on entry AND on exit w.xn holds fp16(xres) and w.stats the *parts row-sum partials of xres (written
 // by the residual epilogues); ln_1 / ln_2 are applied inside the in-proj / c_fc GEMM epilogues.
-// folded == false: separate LayerNorm kernels.
-int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
-              hipStream_t s, bool f16res = false) {
+// folded == false: separate LayerNorm kernels (launched with steps 0 and 3).
+int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded,
+                   int* parts, hipStream_t s, bool f16res) {
   const int M = n_seq * L, H = D / 64;
   int rc;
   GemmArgs a{};
-  if (!folded) {
-    if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
-    a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
-  } else {
-    a.W = (const half_t*)b.w_qkv_f; a.bias = b.c_qkv; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_qkv; a.ln_dim = D;
-    a.ln_eps = 1e-5f;
+  switch (step) {
+    case 0:
+      if (!folded) {
+        if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+        a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
+      } else {
+        a.W = (const half_t*)b.w_qkv_f; a.bias = b.c_qkv; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_qkv; a.ln_dim = D;
+        a.ln_eps = 1e-5f;
+      }
+      a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
+      a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
+      return launch_gemm(a, s);
+    case 1:
+      return launch_attention(w.qkv, w.att, n_seq, L, H, causal, s);
+    case 2:
+      a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
+      a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+      if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
+      return launch_gemm(a, s);
+    case 3:
+      if (!folded) {
+        if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+        a.W = (const half_t*)b.w_fc; a.bias = b.b_fc;
+      } else {
+        a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_fc; a.ln_dim = D;
+        a.ln_eps = 1e-5f;
+      }
+      a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
+      a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
+      return launch_gemm(a, s);
+    default:
+      a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
+      a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+      if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
+      return launch_gemm(a, s);
   }
-  a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
-  a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
-  if ((rc = launch_gemm(a, s))) return rc;
-  if ((rc = launch_attention(w.qkv, w.att, n_seq, L, H, causal, s))) return rc;
-  a = GemmArgs{};
-  a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
-  a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
-  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
-  if ((rc = launch_gemm(a, s))) return rc;
-  a = GemmArgs{};
-  if (!folded) {
-    if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
-    a.W = (const half_t*)b.w_fc; a.bias = b.b_fc;
-  } else {
-    a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_fc; a.ln_dim = D;
-    a.ln_eps = 1e-5f;
+}
+
+int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
+              hipStream_t s, bool f16res = false) {
+  for (int step = 0; step < 5; ++step) {
+    const int rc = run_block_step(step, b, w, n_seq, L, D, causal, folded, parts, s, f16res);
+    if (rc) return rc;
   }
-  a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
-  a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
-  if ((rc = launch_gemm(a, s))) return rc;
-  a = GemmArgs{};
-  a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
-  a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
-  if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
-  return launch_gemm(a, s);
+  return CLIPMI_OK;
 }
 
 // ln_1 / ln_2 are applied inside the GEMM epilogues whenever the folded operands are bound (CLIPMI_LN_FOLD=0 switches
@@ -146,8 +235,7 @@ int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L,
 // prologue) and the residual producers +13 us each (the fp16 shadow of the stream is another 77 MB in their store
 // burst): net -41 us per block, +3 % end to end.
 bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
-  const char* e = getenv("CLIPMI_LN_FOLD");
-  if (e && e[0] == '0') return false;
+  if (options().ln_fold.load(std::memory_order_relaxed) == 0) return false;
   for (const auto& b : blocks)
     if (!b.w_qkv_f) return false;
   return !blocks.empty();
@@ -159,12 +247,11 @@ bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
 //                GEMMs of a block move 154 MB each instead of 387 MB (+10 % end to end at B = 256); against the fp32
 //                stream the image-side cosine error goes 3.1e-5 -> 8.7e-5 (tests/precision_modes.py), tolerance 1e-3;
 //   text tower:  fp32 with an fp16 shadow -- its features are computed once per class list and reused for every image.
-// CLIPMI_RESIDUAL_F16 = 0 (fp32 everywhere) | v (default) | t | 1 (both towers fp16).
+// option residual_f16 (env CLIPMI_RESIDUAL_F16) = 0 (fp32 everywhere) | 2 / v (default) | 3 / t | 1 (both towers fp16).
 bool residual_f16_enabled(bool folded, bool vision) {
   if (!folded) return false;
-  const char* e = getenv("CLIPMI_RESIDUAL_F16");
-  const char mode = e ? e[0] : 'v';
-  return mode == '1' || (vision ? mode == 'v' : mode == 't');
+  const int mode = options().residual_f16.load(std::memory_order_relaxed);
+  return mode == 1 || (vision ? mode == 2 : mode == 3);
 }
 
 int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
@@ -243,6 +330,35 @@ const char* clipmi_strerror(int code) {
 
 const char* clipmi_last_error(void) { return g_err; }
 
+int clipmi_set_option(const char* name, int value) {
+  CLIPMI_REQUIRE(name, CLIPMI_ERR_ARG, "set_option: null name");
+  for (const OptionDesc& d : kOptions)
+    if (!strcmp(d.name, name)) {
+      (options().*(d.field)).store(value, std::memory_order_relaxed);
+      return CLIPMI_OK;
+    }
+  set_error("set_option: unknown option '%s'", name);
+  return CLIPMI_ERR_ARG;
+}
+
+#ifdef CLIPMI_TUNING
+int clipmi_tuning_set_stamps(void* device_buffer) {   // tuning build only; not part of include/clipmi.h
+  g_tuning_stamps.store(static_cast<long long*>(device_buffer), std::memory_order_relaxed);
+  return CLIPMI_OK;
+}
+#endif
+
+int clipmi_get_option(const char* name, int* value) {
+  CLIPMI_REQUIRE(name && value, CLIPMI_ERR_ARG, "get_option: null pointer");
+  for (const OptionDesc& d : kOptions)
+    if (!strcmp(d.name, name)) {
+      *value = (options().*(d.field)).load(std::memory_order_relaxed);
+      return CLIPMI_OK;
+    }
+  set_error("get_option: unknown option '%s'", name);
+  return CLIPMI_ERR_ARG;
+}
+
 // ---------------------------------------------------------------- operator level
 int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
                     void* out, int64_t ldo, int out_dtype, int M, int N, int K, int epilogue, clipmi_stream_t stream) {
@@ -272,9 +388,22 @@ int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int 
   return launch_l2_normalize(in, in_dtype, out, rows, E, (hipStream_t)stream);
 }
 
+int clipmi_l2_normalize_to(const void* in, int in_dtype, void* out, int out_dtype, int rows, int E, clipmi_stream_t stream) {
+  return launch_l2_normalize_to(in, in_dtype, out, out_dtype, rows, E, (hipStream_t)stream);
+}
+
 int clipmi_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits, float* conf,
                   int32_t* pred, int B, int C, int E, clipmi_stream_t stream) {
   return launch_logits(img_n, txt_n, scale, dac_conf, logits, conf, pred, B, C, E, (hipStream_t)stream);
+}
+
+size_t clipmi_fused_tail_workspace_bytes(int B) { return B < 0 ? 0 : fused_tail_workspace_bytes(B); }
+
+int clipmi_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
+                      float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins,
+                      void* workspace, size_t workspace_bytes, int B, int C, int E, clipmi_stream_t stream) {
+  return launch_fused_tail(img, img_dtype, normalize, txt_n, scale, dac_conf, logits, img_n_out, conf, pred, labels, bins, n_bins, workspace,
+                           workspace_bytes, B, C, E, (hipStream_t)stream);
 }
 
 int clipmi_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, clipmi_stream_t stream) {
@@ -499,48 +628,47 @@ int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float
   return run_text_tail(m, w, n_prompts, out, s);
 }
 
-int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspace, size_t workspace_bytes, float* ms_out,
-                            clipmi_stream_t stream) {
+int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* workspace, size_t workspace_bytes, float* ms_out,
+                         clipmi_stream_t stream) {
   CLIPMI_REQUIRE(m && ms_out && workspace, CLIPMI_ERR_ARG, "profile: null pointer");
   CLIPMI_REQUIRE(m->has_vision, CLIPMI_ERR_STATE, "vision weights not bound");
-  CLIPMI_REQUIRE(batch > 0 && iters > 0, CLIPMI_ERR_SHAPE, "profile: batch/iters must be positive");
+  CLIPMI_REQUIRE(batch > 0 && iters > 0 && only >= -1 && only < 5, CLIPMI_ERR_SHAPE, "profile: batch/iters must be positive, only in -1..4");
   hipStream_t s = (hipStream_t)stream;
   const int L = m->tokens0(), D = m->g.vision_width;
   const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch, m->col_bytes(batch));
   CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "profile: workspace too small");
   const clipmi_block_weights& b = m->vblocks[0];
-  GemmArgs a{};
-  a.A = w.xn; a.lda = D; a.W = (const half_t*)b.w_fc; a.ldw = D; a.bias = b.b_fc; a.out = w.hid; a.ldo = 4 * D;
-  a.out_dtype = CLIPMI_F16; a.M = batch * L; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
-  if (fold_enabled(m->vblocks)) {   // time the kernel exactly as the tower launches it (LayerNorm folded into the epilogue)
-    a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = (D + 255) / 256; a.ln_g = b.g_fc; a.ln_dim = D;
-    a.ln_eps = 1e-5f;
-    if (a.ln_parts > LN_MAX_PARTS) a.ln_parts = LN_MAX_PARTS;
-    (void)hipMemsetAsync(w.stats, 0, (size_t)2 * a.ln_parts * a.M * sizeof(float), s);   // defined row statistics for the timing runs
-  }
+  const bool folded = fold_enabled(m->vblocks);
+  const bool f16res = residual_f16_enabled(folded, true);
+  // the row partials a residual GEMM of this shape leaves behind (what the consumers read in the tower)
+  int parts = (D + 255) / 256 > LN_MAX_PARTS ? LN_MAX_PARTS : (D + 255) / 256;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     set_error("profile: hipEventCreate failed");
     return CLIPMI_ERR_HIP;
   }
-  double total = 0.0;
   int rc = CLIPMI_OK;
-  for (int i = 0; i < iters && rc == CLIPMI_OK; ++i) {
-    (void)hipEventRecord(e0, s);
-    rc = launch_gemm(a, s);
-    (void)hipEventRecord(e1, s);
-    if (hipEventSynchronize(e1) != hipSuccess) {
-      set_error("profile: hipEventSynchronize failed");
-      rc = CLIPMI_ERR_HIP;
-      break;
+  for (int step = 0; step < 5 && rc == CLIPMI_OK; ++step) {
+    ms_out[step] = 0.f;
+    if (only >= 0 && only != step) continue;
+    double total = 0.0;
+    for (int i = -1; i < iters && rc == CLIPMI_OK; ++i) {   // i = -1: untimed warm-up launch
+      (void)hipEventRecord(e0, s);
+      rc = run_block_step(step, b, w, batch, L, D, 0, folded, &parts, s, f16res);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) {
+        set_error("profile: hipEventSynchronize failed");
+        rc = CLIPMI_ERR_HIP;
+        break;
+      }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (i >= 0) total += ms;
     }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    total += ms;
+    ms_out[step] = (float)(total / iters);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (rc == CLIPMI_OK) *ms_out = (float)(total / iters);
   return rc;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/clipmi.h"
 
 namespace clipmi {
@@ -37,6 +38,44 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
+
+// Runtime switches (clipmi_set_option / clipmi_get_option).  The CLIPMI_* environment variables of the same meaning are
+// read ONCE, the first time any option is looked at; nothing on a launch path calls getenv.  Plain atomics: a switch
+// may be flipped between launches from any thread.
+struct Options {
+  std::atomic<int> gemm_variant{-1};   // CLIPMI_GEMM_VARIANT: -1 = cost model, else the forced tile configuration (test / tuning aid)
+  std::atomic<int> gemm_band{0};       // CLIPMI_GEMM_BAND: 0 = default traversal band
+  std::atomic<int> gemm_persist{0};    // CLIPMI_GEMM_PERSIST
+  std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
+  std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
+  std::atomic<int> attn_no_tr{0}, attn_no_persist{0}, attn_no_stream{0}, attn_stagger{0};
+  std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
+};
+Options& options();
+
+#ifdef CLIPMI_TUNING
+// Diagnostic build only (make TUNING=1): device buffer of 8 int64 per workgroup that the GEMM kernels stamp with
+// s_memrealtime at their phase boundaries (clipmi_tuning_set_stamps, tools/gemm_stamps.py).  Absent from the product build.
+extern std::atomic<long long*> g_tuning_stamps;
+#endif
+
+// Per-device state.  One process may drive several GPUs: kernel attributes (dynamic LDS size) are set once per
+// (kernel, device) and the CU count is cached per device.  Thread-safe (idempotent HIP calls guarded by atomics).
+int current_device();                  // hipGetDevice, -1 on failure
+int device_cus();                      // multiProcessorCount of the current device (256 when it cannot be read)
+struct DeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  // true exactly until `mark()` has been called for the current device (devices >= 64 are never cached)
+  bool needed(int dev) const { return dev < 0 || dev >= 64 || !((mask.load(std::memory_order_acquire) >> dev) & 1); }
+  void mark(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+template <typename Fn>
+inline void ensure_dynamic_lds(Fn fn, int bytes, DeviceOnce& once) {
+  const int dev = current_device();
+  if (!once.needed(dev)) return;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
+  once.mark(dev);
+}
 
 #define CLIPMI_REQUIRE(cond, code, ...)        \
   do {                                         \
@@ -96,8 +135,13 @@ int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream
 int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStream_t s);
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s);
+int launch_l2_normalize_to(const void* in, int in_dtype, void* out, int out_dtype, int rows, int E, hipStream_t s);
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,
                   float* conf, int32_t* pred, int B, int C, int E, hipStream_t s);
+size_t fused_tail_workspace_bytes(int B);
+int launch_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
+                      float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins, void* workspace,
+                      size_t workspace_bytes, int B, int C, int E, hipStream_t s);
 int launch_calibrate_rows(float* logits, const float* dac_conf, float* conf, int32_t* pred, int B, int C, hipStream_t s);
 int launch_softmax_rows(const float* logits, const float* dac_conf, float* probs, float* conf, int32_t* pred, int B, int C,
                         hipStream_t s);

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void cast16_kernel(const half_t* __restrict__ 
 }
 
 // out[r,:] = in[r,:] / ||in[r,:]||_2, one wave per row, fp32 math
-template <typename TI>
-__global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, float* __restrict__ out, int rows, int E) {
+template <typename TI, typename TO = float>
+__global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int E) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, 
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
   const float inv = 1.0f / sqrtf(ss);
-  for (int e = lane; e < E; e += 64) out[(int64_t)row * E + e] = (float)x[e] * inv;
+  for (int e = lane; e < E; e += 64) out[(int64_t)row * E + e] = (TO)((float)x[e] * inv);   // TO = fp16: the fp32 value, rounded once
 }
 
 // out[g,:] = mean_p in[(g*P + p),:]  -- ProDA's prompt-ensemble mean of the normalised text features (proda.py:328-332)
@@ -352,10 +352,28 @@ int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStrea
 }
 
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s) {
+  return launch_l2_normalize_to(in, in_dtype, out, CLIPMI_F32, rows, E, s);
+}
+
+int launch_l2_normalize_to(const void* in, int in_dtype, void* out_, int out_dtype, int rows, int E, hipStream_t s) {
   if (rows == 0) return CLIPMI_OK;
-  CLIPMI_REQUIRE(in && out, CLIPMI_ERR_ARG, "l2_normalize: null pointer");
+  CLIPMI_REQUIRE(in && out_, CLIPMI_ERR_ARG, "l2_normalize: null pointer");
   CLIPMI_REQUIRE(rows > 0 && E > 0, CLIPMI_ERR_SHAPE, "l2_normalize: bad shape");
   const dim3 grid((rows + 3) / 4);
+  if (out_dtype == CLIPMI_F16) {   // the exchange format of the multi-GPU path (fp16 embeddings over xGMI)
+    half_t* o16 = static_cast<half_t*>(out_);
+    if (in_dtype == CLIPMI_F32)
+      hipLaunchKernelGGL((l2norm_kernel<float, half_t>), grid, dim3(256), 0, s, (const float*)in, o16, rows, E);
+    else if (in_dtype == CLIPMI_F16)
+      hipLaunchKernelGGL((l2norm_kernel<half_t, half_t>), grid, dim3(256), 0, s, (const half_t*)in, o16, rows, E);
+    else {
+      set_error("l2_normalize: bad dtype %d", in_dtype);
+      return CLIPMI_ERR_ARG;
+    }
+    return check_launch("l2norm_kernel");
+  }
+  CLIPMI_REQUIRE(out_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "l2_normalize: bad output dtype %d", out_dtype);
+  float* out = static_cast<float*>(out_);
   if (in_dtype == CLIPMI_F32)
     hipLaunchKernelGGL(l2norm_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, rows, E);
   else if (in_dtype == CLIPMI_F16)

@@ -37,8 +37,13 @@ struct KArgs {
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   half_t* x16; float* stats_out;
-  long long* stamps;   // diagnostic only (tools/gemm_stamps.py): per-workgroup s_memrealtime stamps, NULL in every real run
+#ifdef CLIPMI_TUNING
+  long long* stamps;   // diagnostic build only (make TUNING=1, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps
+#endif
 };
+
+// Phase stamps exist only in the tuning build (make TUNING=1): the product kernels take no stamp pointer.
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm folded into the GEMMs (removes the two LayerNorm kernels of every residual block and their 232 MB pass).
@@ -279,13 +284,147 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
   }
 }
 
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// fp16-stream producer, second form (the default of gemm_f16_kernel): the residual operand comes in through LDS.
+// The register-direct form above reads x16 as 8-byte pieces, 16 rows x 32 B per wave-instruction, in dependent 32-row
+// chunks: phase stamps put that epilogue at 32 us per 320 x 256 tile (two tiles per CU: a quarter of the c_proj launch
+// and half of the out-proj launch).  Here every wave DMAs the rows of its own 64-column sub-tile (128 B per row, 8 rows
+// per buffer_load ... lds instruction: full lines) into a private region of the now idle stage buffers -- up to four
+// 32-row chunks in flight, XOR-swizzled on the source address exactly like the main loop's operands -- adds in place
+// (the lane that reads an element is the lane that writes it), and stores the rows back as 16 B per lane.  Counted
+// vmcnt waits: the DMA of later chunks and the stores of earlier ones stay in flight while a chunk is worked on.
+template <typename T>
+struct FoldDma {
+  static constexpr int NCH = T::TM / 2;                 // 32-row chunks per wave
+  static constexpr int RD = NCH < 4 ? NCH : 4;          // chunks in flight (ring of private 4 KiB regions)
+  static constexpr int CHB = 32 * 128;
+  static constexpr int RED_OFF = T::NW * RD * CHB;
+  static constexpr int LDS = RED_OFF + T::WGN * T::BM * (int)sizeof(float2);
+  // VMEM operations a wave issues after the last DMA instruction of chunk c and before it needs chunk c:
+  // the rest of the initial burst, then per chunk p worked on in between 4 stores (+ 4 DMA instructions if p re-arms the ring)
+  static constexpr int younger(int c) {
+    int n = c < RD ? (RD - 1 - c) * 4 : 0;
+    for (int p = (c < RD ? 0 : c - RD + 1); p < c; ++p) n += 4 + (p + RD < NCH ? 4 : 0);
+    return n;
+  }
+};
+
+template <typename F, int C = 0>
+__device__ __forceinline__ void wait_chunk(int c) {   // c is a constant after unrolling: exactly one counted wait survives
+  if constexpr (C < F::NCH) {
+    if (c == C) wait_vmcnt<F::younger(C)>();
+    else wait_chunk<F, C + 1>(c);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int tile_n,
+                                                             int wave_m, int wave_n, int lane, int wave, char* smem) {
+  using F = FoldDma<T>;
+  constexpr int TM = T::TM, TN = T::TN, NCH = F::NCH, RD = F::RD, CHB = F::CHB;
+  static_assert(T::WTN == 64 && TM % 2 == 0 && TN == 4, "fold epilogue assumes 64-column wave tiles");
+  const int r16 = lane & 15, g4 = lane >> 4;
+  char* region = smem + wave * (RD * CHB);
+  float2* red = reinterpret_cast<float2*>(smem + F::RED_OFF);   // [WGN][BM]
+  const int col0 = n0 + wave_n * 64, row0 = m0 + wave_m * T::WTM;   // wave-uniform
+  f32x4 bias[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = col0 + i * 16 + g4 * 4;
+    bias[i] = n < a.N ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads: nothing but this epilogue's own traffic is counted below
+  __syncthreads();                                    // every wave is done with the main-loop LDS image
+  // rows at or beyond M lie outside the descriptor and read as zero
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x16 + (int64_t)row0 * a.ldo + col0, ((int64_t)(a.M - row0) * a.ldo - col0) * 2);
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto dma_chunk = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = c * 32 + q * 8 + drow;
+      const int voff = (row * (int)a.ldo + ((dslot ^ ((row >> 1) & 7)) << 3)) * 2;
+      CLIPMI_BUFFER_LOAD_LDS16(rs, region + (c % RD) * CHB + q * 1024, voff, 0);
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < RD; ++c) dma_chunk(c);
+  // lane-constant LDS offsets inside a chunk: element (row jj*16 + r16, columns i*16 + g4*4 .. +3) = data chunk 2i + (g4>>1),
+  // stored at slot (chunk ^ ((row>>1)&7)); the coalesced read-back takes slot (lane&7) of row t*8 + (lane>>3) as it lies
+  int eoff[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) eoff[jj] = (jj * 16 + r16) * 128 + (g4 & 1) * 8;
+  const int esw = (r16 >> 1) & 7;   // ((jj*16 + r16) >> 1) & 7
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    char* reg = region + (c % RD) * CHB;
+    __builtin_amdgcn_sched_barrier(0);
+    wait_chunk<F>(c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int ml = wave_m * T::WTM + (c * 2 + jj) * 16 + r16;
+      const int m = m0 + ml;
+      float rsum = 0.f, rsq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = col0 + i * 16 + g4 * 4;
+        char* p = reg + eoff[jj] + (((2 * i + (g4 >> 1)) ^ esw) << 4);
+        const f16x4 r = *reinterpret_cast<const f16x4*>(p);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < a.M && n < a.N) {
+          v = acc[i][c * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
+          rsum += (v[0] + v[1]) + (v[2] + v[3]);
+          rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      }
+      rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
+      rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+      if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
+    }
+    // same wave, LDS in order: the reads below see the writes above
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rl = t * 8 + drow;
+      const f16x8 val = *reinterpret_cast<const f16x8*>(reg + rl * 128 + dslot * 16);
+      const int m = row0 + c * 32 + rl;
+      const int n_st = col0 + ((dslot ^ ((rl >> 1) & 7)) << 3);
+      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + RD < NCH) dma_chunk(c + RD);   // its region was read (lgkmcnt drained for the stores above) a moment ago
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T::BM; t += T::NT) {
+    const int m = m0 + t;
+    if (m < a.M) {
+      float sx = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < T::WGN; ++w) {
+        const float2 pr = red[w * T::BM + t];
+        sx += pr.x;
+        sq += pr.y;
+      }
+      *reinterpret_cast<float2*>(a.stats_out + 2 * ((int64_t)tile_n * a.M + m)) = make_float2(sx, sq);
+    }
+  }
+}
+
 template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
                                                 int wave_n, int lane);
 
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, bool DMA_RES = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
                                          int lane, int wave, char* smem, const float2* lnp = nullptr) {
+  if constexpr (EPI == EPI_RESIDUAL_FOLD16 && DMA_RES) {
+    epilogue_residual_fold16_dma<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
+    return;
+  }
   if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) {
     epilogue_residual_fold<T, EPI == EPI_RESIDUAL_FOLD16>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
     return;
@@ -438,11 +577,15 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K / BK;
+#ifdef CLIPMI_TUNING
+#ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
+#endif
   if (stamp) {
     a.stamps[blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
     a.stamps[blockIdx.x * 8 + 5] = (long long)__smid();
   }
+#endif
   stage(0, 0);
   // LayerNorm-fold consumer: the (rstd, mean*rstd) pair of each of the tile's rows, computed once here (behind the first
   // stage's DMA latency) instead of per lane per row in the epilogue; visible after the loop's first barrier
@@ -460,7 +603,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
+#ifdef CLIPMI_TUNING
     if (stamp && kt == 0) a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* st = smem + (kt & 1) * T::STAGE;
 #pragma unroll
@@ -505,20 +650,24 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     }
   }
 
+#ifdef CLIPMI_TUNING
   if (stamp) a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
+#endif
+  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
+#ifdef CLIPMI_TUNING
   if (a.stamps != nullptr) {
     if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamp) a.stamps[blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
   }
+#endif
 }
 
 // n-tiles per traversal band.  Measured (profiles/r01_gemm_band_sweep.txt): 4 is best or tied on every tower
 // shape (fc: 298 -> 275 us against the unbanded order); up to 6 n-tiles are kept as one band.
 int pick_band(int tiles_n, int /*bn*/, int /*K*/) {
-  const char* e = getenv("CLIPMI_GEMM_BAND");
-  int g = e ? atoi(e) : (tiles_n <= 6 ? tiles_n : 4);
+  const int forced = options().gemm_band.load(std::memory_order_relaxed);
+  int g = forced > 0 ? forced : (tiles_n <= 6 ? tiles_n : 4);
   if (g < 1) g = 1;
   if (g > tiles_n) g = tiles_n;
   const int nb = (tiles_n + g - 1) / g;   // even out the bands (9 n-tiles, g = 4 -> 3 bands of 3)
@@ -527,15 +676,13 @@ int pick_band(int tiles_n, int /*bn*/, int /*K*/) {
 
 template <typename T, int EPI, bool OUT_F32>
 int launch_tile(KArgs k, hipStream_t s) {
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = gemm_f16_kernel<T, EPI, OUT_F32>;
-  constexpr int SMEM = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_set = true;
-  }
+  constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
+  constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;   // the residual tile passes through LDS
+  constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  static_assert(SMEM <= 160 * 1024, "tile does not fit the CU's LDS");
+  ensure_dynamic_lds(fn, SMEM, attr_once);
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -561,8 +708,6 @@ struct Ring {
 };
 
 __device__ __forceinline__ int ring_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int NS, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_ring_kernel(const KArgs a) {
@@ -642,14 +787,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_ring_kernel(const KArgs a)
 template <typename T, int NS, int EPI, bool OUT_F32>
 int launch_ring(KArgs k, hipStream_t s) {
   using R = Ring<T, NS>;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = gemm_ring_kernel<T, NS, EPI, OUT_F32>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, R::SMEM, attr_once);
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -765,17 +905,21 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
   };
   row_params(m0, n0, 0);
 
+#ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
+#endif
   while (true) {
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
     }
+#endif
 
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = (first_buf + kt) & 1;
@@ -783,7 +927,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       // epilogue stores; vmcnt(0) also drains those -- they were issued a full prefetch latency ago
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#ifdef CLIPMI_TUNING
       if (stamp && kt == 0) a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
       if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
       const char* st = smem + buf * T::STAGE;
 #pragma unroll
@@ -808,8 +954,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     }
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cn0 = n0;
-    const int cvb = vb;
+    [[maybe_unused]] const int cvb = vb;
+#ifdef CLIPMI_TUNING
     if (stamp) a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < a.nwg;
     if (has_next) {
@@ -847,7 +995,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     } else {
       epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane_e);
     }
+#ifdef CLIPMI_TUNING
     if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (!has_next) break;
   }
 }
@@ -856,20 +1006,11 @@ template <typename T, int EPI, bool OUT_F32>
 int launch_persist(KArgs k, hipStream_t s) {
   constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
   constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2) + 4 * T::BN * (int)sizeof(float);   // + row / column parameters
-  static bool attr_set = false;
-  static int n_cu = 0;
+  static DeviceOnce attr_once;
   auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, SMEM, attr_once);
+  int n_cu = device_cus();
+  n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -1096,20 +1237,11 @@ __global__ __launch_bounds__(768, 3) void gemm_defer_kernel(const KArgs a) {
 template <int EPI>
 int launch_defer(KArgs k, hipStream_t s) {
   constexpr int SMEM = 2 * (256 + 192) * 128 + 12 * 16 * 144 + 2 * 256 * 8 + 2 * 2 * 192 * 4;
-  static bool attr_set = false;
-  static int n_cu = 0;
+  static DeviceOnce attr_once;
   auto fn = gemm_defer_kernel<EPI>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-    n_cu &= ~7;
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, SMEM, attr_once);
+  int n_cu = device_cus();
+  n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
   const int tiles_m = (k.M + 255) / 256;
   k.tiles_n = (k.N + 191) / 192;
   k.band = pick_band(k.tiles_n, 192, k.K);
@@ -1245,14 +1377,9 @@ template <int EPI, bool OUT_F32>
 int launch_pipe(KArgs k, hipStream_t s) {
   using T = TPipe;
   using R = Ring<T, 4>;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = gemm_pipe_kernel<EPI, OUT_F32>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, R::SMEM, attr_once);
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -1389,14 +1516,9 @@ __global__ __launch_bounds__(T::NT, 1) void gemm_wide_kernel(const KArgs a) {
 template <typename T, int EPI, bool OUT_F32>
 int launch_wide(KArgs k, hipStream_t s) {
   using R = Ring<T, 4>;
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = gemm_wide_kernel<T, EPI, OUT_F32>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, R::SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, R::SMEM, attr_once);
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -1425,24 +1547,9 @@ using T256w4 = Tile<256, 256, 2, 2, 1>;    // 4 waves of 128x128 (gemm_wide_kern
 //                                        591 tiles = 2.31 rounds with (1) but 474 = 1.85 rounds here (proj 917 vs 760 TF)
 //   0  128 x 128,  4 waves, 2 WG / CU   small problems (final projections, tiny batches)
 // rounds = ceil(tiles / (CUs x workgroups per CU)); penalties are the measured per-flop slowdowns relative to (1).
-int device_cus() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  return n_cu;
-}
-
 int pick_variant(const KArgs& k) {
-  const char* e = getenv("CLIPMI_GEMM_VARIANT");
-  if (e && e[0] >= '0' && e[0] <= '9') return e[0] - '0';
-  if (e && e[0] == 'a') return 10;
-  if (e && e[0] == 'b') return 11;
-  if (e && e[0] == 'c') return 12;
-  if (e && e[0] == 'f') return 15;
+  const int forced = options().gemm_variant.load(std::memory_order_relaxed);   // -1 unless a test / tuning run forces one
+  if (forced >= 0) return forced;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
@@ -1461,8 +1568,7 @@ int pick_variant(const KArgs& k) {
   // CLIPMI_GEMM_PERSIST=1: use the persistent form of (1) (variant b: next tile's first stage prefetched before the
   // epilogue, no workgroup relaunch gap) for multi-round problems.  Isolated A/B: +4.5 % on qkv, neutral on fc; inside the
   // tower it measures 1 % slower (20.33 vs 20.55 k img/s, three alternating runs), so it stays opt-in.
-  const char* ps = getenv("CLIPMI_GEMM_PERSIST");
-  if (best == 1 && ps && ps[0] == '1' && (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)cus) best = 11;
+  if (best == 1 && options().gemm_persist.load(std::memory_order_relaxed) == 1 && (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)cus) best = 11;
   return best;
 }
 
@@ -1572,14 +1678,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_conv3x3_kernel(const KArgs
 
 template <typename T, int EPI>
 int launch_conv_tile(KArgs k, const ConvArgs& cv, hipStream_t s) {
-  static bool attr_set = false;
+  static DeviceOnce attr_once;
   auto fn = gemm_conv3x3_kernel<T, EPI>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_set = true;
-  }
+  ensure_dynamic_lds(fn, T::SMEM, attr_once);
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
@@ -1659,10 +1760,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
   k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
-  {
-    const char* e = getenv("CLIPMI_GEMM_STAMPS_PTR");   // tuning aid: device buffer of 8 int64 per workgroup
-    k.stamps = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 0)) : nullptr;
-  }
+#ifdef CLIPMI_TUNING
+  k.stamps = g_tuning_stamps.load(std::memory_order_relaxed);   // clipmi_tuning_set_stamps (tools/gemm_stamps.py), tuning build only
+#endif
   CLIPMI_REQUIRE(!a.ln_stats || (a.ln_g && a.ln_dim > 0 && a.ln_parts >= 1 && a.ln_parts <= LN_MAX_PARTS &&
                                  (a.epilogue == CLIPMI_EPI_BIAS || a.epilogue == CLIPMI_EPI_BIAS_QUICKGELU)),
                  CLIPMI_ERR_ARG, "gemm: LayerNorm fold needs ln_g, ln_dim, 1..%d partials and a BIAS / BIAS_QUICKGELU epilogue", LN_MAX_PARTS);

@@ -40,6 +40,14 @@ class DeviceCalibrationEvaluator:
             self._pred.append(pred)
             self._gt.append(gt)
 
+    def note_processed(self, conf: torch.Tensor, pred: torch.Tensor, gt: torch.Tensor):
+        """The fused tail (ops.fused_tail with ``bins=self.bins``) has already added this batch to the bin accumulators;
+        only the optional per-sample vectors are kept here."""
+        if self.keep_samples:
+            self._conf.append(conf)
+            self._pred.append(pred)
+            self._gt.append(gt.to(conf.device, torch.int64))
+
     def merge_from(self, other_bins: torch.Tensor):
         self.bins += other_bins.to(self.bins.device)
 

@@ -425,13 +425,18 @@ class CLIP(nn.Module):
         lpt, _, _ = ops.logits_fused(txt_n, img_n, scale, None, want_conf_pred=False)
         return lpi.to(self.dtype), lpt.to(self.dtype)
 
-    def profile_mlp_gemm_ms(self, batch: int, iters: int = 20) -> float:
+    BLOCK_KERNELS = ("in_proj", "attention", "out_proj", "c_fc", "c_proj")
+
+    def profile_block_ms(self, batch: int, iters: int = 20, only: int = -1) -> Dict[str, float]:
+        """Mean launch time (ms, hipEvents on the launch stream) of the five per-layer kernels of the image tower as
+        the tower launches them (clipmi_profile_block).  Call ``image_features_f32`` on ``batch`` images first so that
+        the workspace holds real activations."""
         self._ensure_bound()
         ws = self._workspace("vision", lib.clipmi_vision_workspace_bytes(self._handle, batch, 0))
-        ms = C.c_float()
-        check(lib.clipmi_profile_mlp_gemm(self._handle, batch, iters, ws.data_ptr(), ws.numel(), C.byref(ms), ops._stream()),
-              "clipmi_profile_mlp_gemm")
-        return float(ms.value)
+        ms = (C.c_float * 5)()
+        check(lib.clipmi_profile_block(self._handle, batch, iters, only, ws.data_ptr(), ws.numel(), ms, ops._stream()),
+              "clipmi_profile_block")
+        return {name: float(ms[i]) for i, name in enumerate(self.BLOCK_KERNELS)}
 
 
 def convert_weights(model: nn.Module) -> None:

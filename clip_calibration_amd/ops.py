@@ -25,6 +25,11 @@ def _dev(t: torch.Tensor, name: str, dtypes=None) -> torch.Tensor:
                            "the HIP path has no CPU fallback")
     if dtypes is not None and t.dtype not in dtypes:
         raise TypeError(f"clipmi: `{name}` has dtype {t.dtype}, expected one of {dtypes}")
+    # launches go to the CURRENT device's stream with raw pointers: a tensor that lives on another GPU would be handed to
+    # the wrong device.  One process drives one GPU here; anything else must say so with torch.cuda.device(...).
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"clipmi: `{name}` is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           f"run the call under `with torch.cuda.device({t.device.index}):`")
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -104,37 +109,75 @@ def patchify(image: torch.Tensor, patch: int, kpad: Optional[int] = None) -> tor
     return col
 
 
-def l2_normalize(f: torch.Tensor) -> torch.Tensor:
-    """``f / f.norm(dim=-1, keepdim=True)`` in fp32 (reference zsclip.py:99)."""
+def l2_normalize(f: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """``f / f.norm(dim=-1, keepdim=True)`` in fp32 (reference zsclip.py:99); ``out_dtype=torch.float16`` rounds the
+    quotient once (the exchange format of the multi-GPU path)."""
     f = _dev(f, "features", (torch.float16, torch.float32))
     rows, E = f.shape
-    out = torch.empty(rows, E, dtype=torch.float32, device=f.device)
-    check(lib.clipmi_l2_normalize(f.data_ptr(), _DT[f.dtype], out.data_ptr(), rows, E, _stream()), "clipmi_l2_normalize")
+    out = torch.empty(rows, E, dtype=out_dtype, device=f.device)
+    with torch.cuda.device(f.device):
+        check(lib.clipmi_l2_normalize_to(f.data_ptr(), _DT[f.dtype], out.data_ptr(), _DT[out_dtype], rows, E, _stream()),
+              "clipmi_l2_normalize_to")
     return out
 
 
 def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: Optional[torch.Tensor] = None,
                  want_conf_pred: bool = True):
-    """(scale*img_n) @ txt_n^T  [+ DAC row scale]  [+ softmax top-1 conf / pred]; see include/clipmi.h."""
-    img_n = _dev(img_n, "img_n", (torch.float32,))
+    """(scale*img_n) @ txt_n^T  [+ DAC row scale]  [+ softmax top-1 conf / pred] on features that are ALREADY normalised
+    (the gathered embeddings of the multi-GPU path, CoCoOp's shared image features): one launch of the fused tail."""
+    logits, _, conf, pred = fused_tail(img_n, txt_n, scale, dac_conf, want_conf_pred, normalize=False)
+    return logits, conf, pred
+
+
+_TAIL_WS = {}   # device index -> zeroed int32 ticket counters (the kernel leaves them zero)
+
+
+def _tail_workspace(device: torch.device, batch: int) -> torch.Tensor:
+    need = lib.clipmi_fused_tail_workspace_bytes(batch)
+    ws = _TAIL_WS.get(device.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=device)
+        _TAIL_WS[device.index] = ws
+    return ws
+
+
+def fused_tail(img: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: Optional[torch.Tensor] = None,
+               want_conf_pred: bool = True, normalize: bool = True, labels: Optional[torch.Tensor] = None,
+               bins: Optional[torch.Tensor] = None, n_bins: int = 0):
+    """The tail of the path in ONE launch (include/clipmi.h, clipmi_fused_tail): L2-normalise the image features,
+    ``scale * img_n @ txt_n^T``, DAC row scale, softmax top-1 and -- when ``labels`` and ``bins`` are given -- the ECE bin
+    accumulation.  Returns (logits, img_n, conf, pred); img_n is ``img`` itself when ``normalize`` is False."""
+    img = _dev(img, "img", (torch.float32, torch.float16))
     txt_n = _dev(txt_n, "txt_n", (torch.float32,))
-    B, E = img_n.shape
+    if txt_n.device != img.device:
+        raise RuntimeError(f"fused_tail: img on {img.device}, txt_n on {txt_n.device}")
+    B, E = img.shape
     Cn = txt_n.shape[0]
     if txt_n.shape[1] != E:
-        raise ValueError("logits: feature widths differ")
+        raise ValueError("fused_tail: feature widths differ")
     dac_conf, pd = _opt(dac_conf, "dac_conf", (torch.float32,))
     if dac_conf is not None and dac_conf.numel() != Cn:
-        raise ValueError("logits: dac_conf must have one entry per class")
-    logits = torch.empty(B, Cn, dtype=torch.float32, device=img_n.device)
+        raise ValueError("fused_tail: dac_conf must have one entry per class")
+    labels, pl = _opt(labels, "labels", (torch.int64,))
+    bins, pb = _opt(bins, "bins", (torch.float64,))
+    if (pb is None) != (pl is None):
+        raise ValueError("fused_tail: labels and bins come together")
+    if bins is not None and (bins.numel() != 3 * (n_bins + 1) or labels.numel() != B):
+        raise ValueError("fused_tail: bins must hold 3*(n_bins+1) float64 and labels one entry per image")
+    logits = torch.empty(B, Cn, dtype=torch.float32, device=img.device)
+    img_n = torch.empty(B, E, dtype=torch.float32, device=img.device) if normalize else img
     conf = pred = None
     pc = pp = None
-    if want_conf_pred:
-        conf = torch.empty(B, dtype=torch.float32, device=img_n.device)
-        pred = torch.empty(B, dtype=torch.int32, device=img_n.device)
+    if want_conf_pred or bins is not None:
+        conf = torch.empty(B, dtype=torch.float32, device=img.device)
+        pred = torch.empty(B, dtype=torch.int32, device=img.device)
         pc, pp = conf.data_ptr(), pred.data_ptr()
-    check(lib.clipmi_logits(img_n.data_ptr(), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(), pc, pp, B, Cn, E,
-                            _stream()), "clipmi_logits")
-    return logits, conf, pred
+    ws = _tail_workspace(img.device, B)
+    with torch.cuda.device(img.device):
+        check(lib.clipmi_fused_tail(img.data_ptr(), _DT[img.dtype], int(normalize), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(),
+                                    img_n.data_ptr() if normalize else None, pc, pp, pl, pb, int(n_bins), ws.data_ptr(), ws.numel(),
+                                    B, Cn, E, _stream()), "clipmi_fused_tail")
+    return logits, img_n, conf, pred
 
 
 def softmax_rows(logits: torch.Tensor, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):

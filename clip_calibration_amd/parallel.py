@@ -8,7 +8,8 @@ The reference has no counterpart (single process + nn.DataParallel re-broadcasti
 coop.py:268-272, tempscaling.py:117-120)."""
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes as C
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -21,6 +22,72 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+class EmbeddingExchange:
+    """The exchange step of the path as the library owns it: ``clipmi_allgather`` = RCCL ``ncclAllGather`` on the caller's
+    stream (include/clipmi.h, "Multi-GPU exchange"), communicator built from a unique id that rank 0 creates and
+    ``torch.distributed`` only carries to the other ranks.  ``backend``:
+
+    * ``"rccl"``  -- the C-ABI communicator (default whenever every rank has its own GPU);
+    * ``"torch"`` -- ``torch.distributed.all_gather_into_tensor`` on the process group (gloo in the CPU tests and in
+      same-GPU debug runs: RCCL refuses two ranks on one device);
+    * ``"auto"``  -- rccl, falling back to torch with a printed reason if the communicator cannot be built.
+
+    Gather, not reduce: the result is bitwise independent of the number of ranks."""
+
+    def __init__(self, device: torch.device, group=None, backend: str = "auto"):
+        from . import _lib
+        self.group, self.device = group, torch.device(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._comm = None
+        self.backend = "torch"
+        if backend in ("rccl", "auto") and self.device.type == "cuda":
+            try:
+                uid = [bytes(_lib.COMM_ID_BYTES)]
+                if self.rank == 0:
+                    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+                    _lib.check(_lib.lib.clipmi_comm_unique_id(buf), "clipmi_comm_unique_id")
+                    uid = [buf.raw]
+                if self.world > 1:
+                    dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                handle = C.c_void_p()
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib.clipmi_comm_create(uid[0], self.world, self.rank, C.byref(handle)), "clipmi_comm_create")
+                self._comm, self.backend = handle, "rccl"
+            except (_lib.ClipmiError, RuntimeError) as e:
+                if backend == "rccl":
+                    raise
+                print(f"[clip_calibration_amd] RCCL communicator unavailable ({e}); using torch.distributed", flush=True)
+
+    @property
+    def rccl_ranks(self) -> Optional[int]:
+        """World size as the RCCL communicator reports it (None on the torch backend)."""
+        if self._comm is None:
+            return None
+        from . import _lib
+        w, r = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib.clipmi_comm_ranks(self._comm, C.byref(w), C.byref(r)), "clipmi_comm_ranks")
+        return int(w.value)
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        """[b, E] per rank -> [world*b, E] on every rank, rank-major (equal b on every rank)."""
+        local = local.contiguous()
+        if self._comm is None:
+            return all_gather_embeddings(local, self.group)
+        from . import _lib
+        out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        with torch.cuda.device(local.device):
+            _lib.check(_lib.lib.clipmi_allgather(self._comm, local.data_ptr(), out.data_ptr(), local.numel() * local.element_size(),
+                                                 torch.cuda.current_stream().cuda_stream), "clipmi_allgather")
+        return out
+
+    def close(self):
+        if self._comm is not None:
+            from . import _lib
+            _lib.lib.clipmi_comm_destroy(self._comm)
+            self._comm = None
 
 
 def all_gather_embeddings(local: torch.Tensor, group=None) -> torch.Tensor:
@@ -76,13 +143,26 @@ def all_gather_varlen(local: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([gathered[r * width: r * width + lens[r]] for r in range(world)], dim=0)
 
 
-def gather_samples(evaluator, proximity=None, group=None):
+def gather_samples(evaluator, proximity=None, group=None, has_proximity: Optional[bool] = None):
     """End-of-evaluation merge for a sharded test split: sums the bin accumulators and replaces the evaluator's kept
     (conf, pred, gt) vectors by the all-rank concatenation, so that ``evaluate`` returns identical numbers on every rank.
-    Returns the gathered proximity vector (or None)."""
+    Returns the gathered proximity vector (or None).
+
+    Every rank enters every collective, also a rank whose shard was EMPTY (more ranks than batches): the decision to
+    gather samples hangs on ``keep_samples`` and the one for proximity on ``has_proximity`` (rank-uniform configuration,
+    default: ``proximity is not None`` -- pass it explicitly when a rank may hold an empty shard), never on local data."""
     merge_ece_bins(evaluator.bins, group)
-    if evaluator.keep_samples and evaluator._conf:
-        evaluator._conf = [all_gather_varlen(torch.cat(evaluator._conf), group)]
-        evaluator._pred = [all_gather_varlen(torch.cat(evaluator._pred), group)]
-        evaluator._gt = [all_gather_varlen(torch.cat(evaluator._gt), group)]
-    return None if proximity is None else all_gather_varlen(proximity, group)
+    dev = evaluator.bins.device
+    if evaluator.keep_samples:
+        def cat(parts, dtype):   # one dtype on every rank, whatever a rank happened to collect (or not collect)
+            return torch.cat(parts).to(dtype) if parts else torch.zeros(0, dtype=dtype, device=dev)
+        evaluator._conf = [all_gather_varlen(cat(evaluator._conf, torch.float32), group)]
+        evaluator._pred = [all_gather_varlen(cat(evaluator._pred, torch.int64), group)]
+        evaluator._gt = [all_gather_varlen(cat(evaluator._gt, torch.int64), group)]
+    if has_proximity is None:
+        has_proximity = proximity is not None
+    if not has_proximity:
+        return None
+    if proximity is None:
+        proximity = torch.zeros(0, dtype=torch.float32, device=dev)
+    return all_gather_varlen(proximity.to(torch.float32), group)

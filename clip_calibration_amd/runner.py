@@ -89,5 +89,5 @@ def test(infer: Callable, loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], v
     if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                              and torch.distributed.get_world_size() > 1):
         from .parallel import gather_samples
-        proximity = gather_samples(ev, proximity, group)
+        proximity = gather_samples(ev, proximity, group, has_proximity=val_dict is not None)   # rank-uniform, not data-dependent
     return ev.evaluate(None if proximity is None else proximity.cpu().numpy())

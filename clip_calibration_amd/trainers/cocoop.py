@@ -34,7 +34,7 @@ class PromptLearner(nn.Module):
         with torch.no_grad():
             if ctx_init_ids is not None:      # CTX_INIT "a photo of a" (cocoop.py:85-93)
                 emb = clip_model.token_embedding(ctx_init_ids.to(dev)).type(dtype)
-                n_ctx = ctx_init_ids.shape[-1] - 2 if ctx_init_ids.dim() == 2 else n_ctx
+                n_ctx = n_ctx_from_init_ids(ctx_init_ids, tokenized_prompts.shape[-1])
                 ctx_vectors = emb[0, 1:1 + n_ctx, :].clone()
             else:
                 ctx_vectors = (0.02 * torch.randn(n_ctx, ctx_dim, generator=g)).to(dev, dtype)

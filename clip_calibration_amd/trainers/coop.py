@@ -25,6 +25,18 @@ class TextEncoder(nn.Module):
         return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx)
 
 
+def n_ctx_from_init_ids(ctx_init_ids: torch.Tensor, context_length: int) -> int:
+    """Number of context words of a CTX_INIT prompt from its token ids ``[1, L]`` = ``[SOT, w1..wn, EOT, 0...]``: the
+    reference counts ``len(ctx_init.split(" "))`` (coop.py:82-84); here it is the EOT position (the largest id, as in
+    ``clip.tokenize``) minus one, so both the zero-padded ``[1, 77]`` tensor ``tokenize`` returns and an unpadded
+    ``[1, n+2]`` slice give n.  (For the templates the configs ship -- "a photo of a" -- every word is one token.)"""
+    ids = ctx_init_ids.reshape(-1, ctx_init_ids.shape[-1])[0]
+    n_ctx = int(ids.argmax()) - 1
+    if not (1 <= n_ctx and 1 + n_ctx < context_length):
+        raise ValueError(f"CTX_INIT ids give n_ctx={n_ctx}: expected [SOT, words.., EOT, padding] with 1 <= n_ctx < {context_length - 1}")
+    return n_ctx
+
+
 class PromptLearner(nn.Module):
     """coop.py:70-144 with CLASS_TOKEN_POSITION == 'end' (the shipped configs): prompts = [SOS | ctx | class tokens, EOS, pad].
     ``tokenized_prompts`` are the ids of ``"X X ... X {classname}."`` (coop.py:107-112)."""
@@ -40,13 +52,15 @@ class PromptLearner(nn.Module):
         with torch.no_grad():
             if ctx_init_ids is not None:  # CTX_INIT: embedding of the given words (coop.py:82-90)
                 emb = clip_model.token_embedding(ctx_init_ids.to(dev)).type(dtype)
-                n_ctx = ctx_init_ids.shape[-1] - 2 if ctx_init_ids.dim() == 2 else n_ctx
+                n_ctx = n_ctx_from_init_ids(ctx_init_ids, tokenized_prompts.shape[-1])
                 ctx_vectors = emb[0, 1:1 + n_ctx, :].clone()
             else:
                 g = torch.Generator().manual_seed(seed)
                 shape = (n_cls, n_ctx, ctx_dim) if csc else (n_ctx, ctx_dim)
                 ctx_vectors = (0.02 * torch.randn(*shape, generator=g)).to(dev, dtype)
             embedding = clip_model.token_embedding(tokenized_prompts).type(dtype)
+        if not 1 + n_ctx < tokenized_prompts.shape[-1]:
+            raise ValueError(f"n_ctx={n_ctx} does not fit a context of {tokenized_prompts.shape[-1]} tokens")
         self.ctx = nn.Parameter(ctx_vectors)
         self.register_buffer("token_prefix", embedding[:, :1, :])            # SOS
         self.register_buffer("token_suffix", embedding[:, 1 + n_ctx:, :])    # class tokens, EOS, padding
@@ -111,8 +125,8 @@ class CustomCLIP(nn.Module):
     @torch.no_grad()
     def forward(self, image: torch.Tensor, label=None, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):
         text_features = self.text_features()
-        image_features = ops.l2_normalize(self._image_features(image))
-        logits, conf, pred = ops.logits_fused(image_features, text_features, self.scale, dac_conf, want_conf_pred)
+        logits, image_features, conf, pred = ops.fused_tail(self._image_features(image), text_features, self.scale, dac_conf,
+                                                            want_conf_pred)
         if want_conf_pred:
             return logits, image_features, text_features, conf, pred
         return logits, image_features, text_features

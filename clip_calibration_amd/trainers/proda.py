@@ -98,8 +98,8 @@ class CustomCLIP(nn.Module):
     def forward(self, image: torch.Tensor, label=None, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):
         if self.text_features is None:
             self.set_classifier()
-        image_features = ops.l2_normalize(self.clip_model.image_features_f32(image))
-        logits, conf, pred = ops.logits_fused(image_features, self.text_features, self.scale, dac_conf, want_conf_pred)
+        logits, image_features, conf, pred = ops.fused_tail(self.clip_model.image_features_f32(image), self.text_features, self.scale,
+                                                            dac_conf, want_conf_pred)
         if want_conf_pred:
             return logits, image_features, self.text_features, conf, pred
         return logits, image_features, self.text_features

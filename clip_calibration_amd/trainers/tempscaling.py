@@ -1,5 +1,7 @@
-"""TempScaling (reference trainers/calibration/tempscaling.py:31-59) -- the forward; the 1-parameter SGD fit stays in
-torch autograd on the caller's side."""
+"""TempScaling (reference trainers/calibration/tempscaling.py:31-59) -- the forward, and the hand-off to the 1-parameter
+SGD fit, which stays in torch autograd on the caller's side: ``forward_train`` returns
+``scale_learner() * cosine_logits`` with the cosine logits from the HIP path as a constant and the scalar as the only
+leaf, so ``F.cross_entropy(logits, label).backward()`` is exactly the reference's step (tempscaling.py:146-158)."""
 from __future__ import annotations
 
 import torch
@@ -28,6 +30,16 @@ class CustomCLIPCalibration(nn.Module):
         self.logits_encoder = base_model
         self.dtype = getattr(base_model, "dtype", torch.float32)
         self.scale_learner = ScaleLearner(torch.float32, init)
+
+    def forward_train(self, image, label=None):
+        """tempscaling.py:53-56 under autograd: ``logit_scale * image_features @ text_features.t()``.  The towers and the
+        [B, C] cosine matmul run on the HIP path (no graph: every tower weight is frozen there, tempscaling.py:93-106);
+        the product with the learnt scalar is the one differentiable operation, so d loss / d logit_scale is the
+        reference's.  Returns (logits, image_features, text_features) like ``forward``."""
+        with torch.no_grad():
+            _, image_features, text_features = self.logits_encoder(image)[:3]
+            cosine, _, _ = ops.logits_fused(image_features, text_features, 1.0, None, False)
+        return self.scale_learner() * cosine, image_features, text_features
 
     @torch.no_grad()
     def forward(self, image, label=None, dac_conf=None, want_conf_pred: bool = False):

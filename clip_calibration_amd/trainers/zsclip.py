@@ -27,9 +27,15 @@ class ZeroshotCLIP:
         return float(self._fixed_scale) if self._fixed_scale is not None else float(self.clip_model.logit_scale.detach().exp())
 
     @torch.no_grad()
-    def model_inference(self, image: torch.Tensor, dac_conf: torch.Tensor | None = None, want_conf_pred: bool = False):
-        image_features = ops.l2_normalize(self.clip_model.image_features_f32(image))
-        logits, conf, pred = ops.logits_fused(image_features, self.text_features, self.scale, dac_conf, want_conf_pred)
+    def model_inference(self, image: torch.Tensor, dac_conf: torch.Tensor | None = None, want_conf_pred: bool = False,
+                        labels: torch.Tensor | None = None, evaluator=None):
+        """zsclip.py:97-102 as image tower + ONE tail launch (normalise, logits, DAC, softmax top-1 and -- when a
+        DeviceCalibrationEvaluator and labels are passed -- its ECE bin accumulation)."""
+        bins, n_bins = (evaluator.bins, evaluator.n_bins) if evaluator is not None and labels is not None else (None, 0)
+        logits, image_features, conf, pred = ops.fused_tail(self.clip_model.image_features_f32(image), self.text_features, self.scale,
+                                                            dac_conf, want_conf_pred, True, labels if bins is not None else None, bins, n_bins)
+        if bins is not None:
+            evaluator.note_processed(conf, pred, labels)
         if want_conf_pred:
             return logits, image_features, self.text_features, conf, pred
         return logits, image_features, self.text_features

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 8
+#define CLIPMI_ABI_VERSION 10
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -57,6 +57,21 @@ enum {
 int clipmi_abi_version(void);
 const char* clipmi_strerror(int code);
 const char* clipmi_last_error(void);
+
+/* Runtime switches, process-wide.  The reference has none (its knobs are yacs config keys read by Dassl); these select
+ * between parity-tested implementations of the same operator and exist for tests, A/B measurements and the precision
+ * policy.  Each option also has an environment spelling that is read ONCE, at the first launch; after that only
+ * clipmi_set_option changes it (no launch path calls getenv).  Unknown names return CLIPMI_ERR_ARG.
+ *   gemm_variant     (CLIPMI_GEMM_VARIANT)    -1 = cost model (default); 0..12, 15 force one GEMM tile configuration
+ *   gemm_band        (CLIPMI_GEMM_BAND)       0 = default; n-tiles per traversal band
+ *   gemm_persist     (CLIPMI_GEMM_PERSIST)    1 = persistent form of the 16-wave tile for multi-round problems
+ *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
+ *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
+ *                                             (default; env 'v'), 3 = text tower only (env 't')
+ *   attn_no_tr / attn_no_persist / attn_no_stream / attn_stagger   (CLIPMI_ATTN_*)  attention kernel selection
+ *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits as three launches instead of the fused tail kernel */
+int clipmi_set_option(const char* name, int value);
+int clipmi_get_option(const char* name, int* value);
 
 /* ------------------------------------------------------------------------------------------------------
  * Operator level (stateless).  These are the kernels; the tower drivers below are sequences of them.
@@ -91,6 +106,10 @@ int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R,
 /* Row L2 normalisation  f / ||f||  (zsclip.py:99; coop.py:212-213): in (fp16|fp32) [rows,E] -> out fp32. */
 int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, clipmi_stream_t stream);
 
+/* The same with a choice of output type: out fp32 or fp16 [rows,E] (out_dtype).  fp16 is the exchange format of the
+ * multi-GPU path: the fp32 quotient rounded once (what the reference's fp16 GPU path holds after zsclip.py:99). */
+int clipmi_l2_normalize_to(const void* in, int in_dtype, void* out, int out_dtype, int rows, int E, clipmi_stream_t stream);
+
 /* Fused  logits = (scale * img_n) @ txt_n^T  (zsclip.py:100-101, coop.py:215-217, tempscaling.py:53-56)
  * + DistanseAwareCalibration.predict (distanse_aware_calibration.py:49-58: logits[i,:] *= conf[argmax_i])
  * + softmax top-1 (vl_calibrator.py:91, vl_evaluator.py:68,83): conf[i] = max_c softmax(logits[i,:]),
@@ -98,6 +117,25 @@ int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int 
  * logits fp32 [B,C] (required), conf fp32[B], pred int32[B] (either may be NULL).  E % 16 == 0. */
 int clipmi_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf,
                   float* logits, float* conf, int32_t* pred, int B, int C, int E, clipmi_stream_t stream);
+
+/* The tail of the path as ONE launch (the fused normalise + matmul + DAC-temperature kernel):
+ *   img_n = img / ||img||                      zsclip.py:99, coop.py:212-213            (normalize != 0; else img is used as given)
+ *   logits = scale * img_n @ txt_n^T           zsclip.py:100-101, coop.py:215-217, tempscaling.py:53-56
+ *   pred = argmax_c; logits[i,:] *= dac[pred]  distanse_aware_calibration.py:49-58      (dac_conf != NULL)
+ *   conf = max_c softmax(logits[i,:])          vl_calibrator.py:91, vl_evaluator.py:68,83
+ *   ECE bins += (1, conf, pred == label)       tools/metrics.py:90-130                  (bins != NULL; layout of clipmi_ece_accumulate)
+ * img fp32 or fp16 [B,E] (img_dtype; un-normalised tower output when normalize != 0, e.g. the fp16 embeddings gathered from
+ * all ranks when normalize == 0), txt_n fp32 [C,E] L2-normalised; logits fp32 [B,C] required;
+ * img_n_out fp32 [B,E] (the normalised image features of the reference's 3-tuple; NULL to skip; only with normalize), conf fp32 [B],
+ * pred int32 [B], labels int64 [B] + bins float64 [3*(n_bins+1)]: each may be NULL.  Results are bit-identical to
+ * clipmi_l2_normalize + clipmi_logits + clipmi_ece_accumulate.  E % 64 == 0 and E <= 2048 run fused; other shapes, and option
+ * tail_unfused = 1, run the separate launches (which need img_n_out or fp32 normalised input, and conf + pred when bins are given).
+ * workspace: clipmi_fused_tail_workspace_bytes(B) bytes of device memory that is ZERO before the first launch; every launch
+ * leaves it zero again (ticket counters, one per 16 image rows).  Re-zero it after a launch that failed. */
+size_t clipmi_fused_tail_workspace_bytes(int B);
+int clipmi_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
+                      float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins,
+                      void* workspace, size_t workspace_bytes, int B, int C, int E, clipmi_stream_t stream);
 
 /* The row pass of clipmi_logits alone, on logits that already exist -- DistanseAwareCalibration.predict
  * (distanse_aware_calibration.py:49-58) + softmax top-1: pred = argmax_c logits[i,:]; if dac_conf != NULL the row is
@@ -178,6 +216,25 @@ int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t*
  * fp32; E % 64 == 0; 1 <= K <= min(16, Nr).  (The "val image" variant asks for K+1 against itself and drops column 0.) */
 int clipmi_knn_dists(const float* queries, const float* refs, float* out, int Nq, int Nr, int E, int K,
                      clipmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange: one process per GPU, the image batch sharded over the ranks, weights and text
+ * features replicated and resident; per step ONE all-gather of the per-GPU L2-normalised image embeddings (fp16 [B/G,E])
+ * before the shared logits kernel.  Replaces the reference's nn.DataParallel wrapping, which re-broadcasts the weights on
+ * every call (trainers/classification/coop.py:266-272, trainers/calibration/tempscaling.py:117-120).  RCCL (librccl,
+ * opened on first use) over xGMI; gather, not reduce, so results do not depend on the rank count.
+ *   clipmi_comm_unique_id  rank 0: fills id_out (host, CLIPMI_COMM_ID_BYTES) -- hand it to every rank out of band
+ *   clipmi_comm_create     every rank, collectively, AFTER selecting its GPU (hipSetDevice / torch.cuda.set_device)
+ *   clipmi_comm_ranks      what the communicator itself reports (world size, this rank)
+ *   clipmi_allgather       out[r*bytes .. (r+1)*bytes) = rank r's `in`, on every rank; asynchronous on `stream`
+ * ---------------------------------------------------------------------------------------------------- */
+#define CLIPMI_COMM_ID_BYTES 128
+typedef struct clipmi_comm clipmi_comm;
+int clipmi_comm_unique_id(void* id_out);
+int clipmi_comm_create(const void* id, int world, int rank, clipmi_comm** out);
+int clipmi_comm_destroy(clipmi_comm* comm);
+int clipmi_comm_ranks(const clipmi_comm* comm, int* world, int* rank);
+int clipmi_allgather(clipmi_comm* comm, const void* in, void* out, size_t bytes_per_rank, clipmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Model level.  One handle per CLIP model per GPU.
@@ -272,11 +329,14 @@ int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const i
 int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace,
                        size_t workspace_bytes, clipmi_stream_t stream);
 
-/* Timing aid for bench.py: runs `iters` launches of the MLP up-projection GEMM of the vision tower
- * (M = batch*tokens, N = 4*Dv, K = Dv, bias+QuickGELU epilogue) on `stream`, each bracketed by hipEvents on that
- * stream, and returns the mean launch duration in milliseconds through *ms_out.  Synchronises the stream. */
-int clipmi_profile_mlp_gemm(clipmi_model* m, int batch, int iters, void* workspace, size_t workspace_bytes,
-                            float* ms_out, clipmi_stream_t stream);
+/* Timing aid for bench.py (the per-kernel roofline of its JSON line): the five launches of the vision tower's residual
+ * block 0 -- 0 in-proj, 1 attention, 2 out-proj + residual, 3 c_fc + QuickGELU, 4 c_proj + residual (clip/model.py:181-188)
+ * -- issued exactly as clipmi_encode_image issues them (LayerNorm fold, fp16 stream, tile selection) on the operands the
+ * workspace holds (call clipmi_encode_image on `batch` images first), each `iters` times after one untimed launch,
+ * every launch bracketed by hipEvents on `stream`.  ms_out: host float[5], mean milliseconds per launch.  only = -1 times
+ * all five, 0..4 just that one (the others report 0).  Synchronises the stream; overwrites the activations in the workspace. */
+int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* workspace, size_t workspace_bytes,
+                         float* ms_out, clipmi_stream_t stream);
 
 #ifdef __cplusplus
 }

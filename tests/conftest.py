@@ -16,6 +16,49 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- the N > 1 path on the hardware there is (tests/test_gpu_multirank.py) -------------------------------------------
+# Two fresh rank processes (torch.distributed.run) and one single-process reference run of bench.py are started HERE, at
+# session start, before this process has touched the GPU (torch.cuda.device_count() does not initialise it): a process
+# that has initialised the GPU must not be the one that execs other programs on these boxes.  The test only waits for
+# the children and compares their dumps.
+MULTIRANK = {}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    import tempfile
+    markexpr = session.config.getoption("-m") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr or torch.cuda.device_count() < 1:
+        return
+    if os.environ.get("CLIPMI_SKIP_MULTIRANK") == "1":
+        return
+    tmp = tempfile.mkdtemp(prefix="clipmi_multirank_")
+    common = ["--steps", "2", "--warmup", "1", "--batch", "24", "--classes", "200", "--no-roofline", "--no-cpu-baseline", "--images-seed", "40"]
+    env = dict(os.environ, BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    bench = os.path.join(ROOT, "bench.py")
+    two = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), bench, "--gpus", "2", "--dump", os.path.join(tmp, "two.npz")] + common,
+                           env=env, stdout=open(os.path.join(tmp, "two.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
+    one = subprocess.Popen([sys.executable, bench, "--gpus", "1", "--virtual-ranks", "2", "--exchange-f16", "--dump", os.path.join(tmp, "one.npz")] + common,
+                           env=dict(os.environ, OMP_NUM_THREADS="8"), stdout=open(os.path.join(tmp, "one.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
+    MULTIRANK.update(tmp=tmp, two=two, one=one)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for key in ("two", "one"):
+        p = MULTIRANK.get(key)
+        if p is not None and p.poll() is None:
+            p.kill()            # exactly the processes this session started
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
@@ -37,3 +80,19 @@ def tiny3():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+@pytest.fixture
+def clipmi_option():
+    """Set libclipmi runtime switches (include/clipmi.h, clipmi_set_option) for one test; restored afterwards."""
+    from clip_calibration_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -23,8 +23,9 @@ with torch.no_grad():
     rz = orc.l2_normalize(orc.encode_text(sd, ids_zs)).numpy()
     rc = orc.l2_normalize(orc.text_encoder(sd, orc.coop_prompts(sd, ids_cp, ctx), ids_cp)).numpy()
 n = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
-for mode in ("0", "v", "t", "1"):
-    os.environ["CLIPMI_RESIDUAL_F16"] = mode
+from clip_calibration_amd import _lib
+for mode, value in (("0", 0), ("v", 2), ("t", 3), ("1", 1)):
+    _lib.set_option("residual_f16", value)
     coop._cache = None; coop._cache_key = None
     with torch.no_grad():
         gi = n(model.image_features_f32(images.cuda()).cpu().numpy())

@@ -95,6 +95,23 @@ def test_boundary_state_dict_surface():
         build_model({k: v for k, v in sd.items() if k != "visual.proj"}, None)   # neither a ViT nor a ModifiedResNet checkpoint
 
 
+def test_ctx_init_n_ctx_from_padded_and_unpadded_ids():
+    """CTX_INIT (coop.py:82-90, kgcoop.py:102-112): n_ctx is the word count of the init prompt, whether the caller passes the
+    zero-padded [1, 77] tensor clip.tokenize returns or an unpadded [1, n+2] slice; anything else is refused."""
+    from clip_calibration_amd.trainers.coop import n_ctx_from_init_ids
+    padded = torch.zeros(1, 77, dtype=torch.long)
+    padded[0, :6] = torch.tensor([49406, 320, 1125, 539, 320, 49407])      # "a photo of a"
+    assert n_ctx_from_init_ids(padded, 77) == 4
+    assert n_ctx_from_init_ids(padded[:, :6], 77) == 4
+    sixteen = torch.zeros(1, 77, dtype=torch.long)
+    sixteen[0, :18] = torch.tensor([49406] + [343] * 16 + [49407])
+    assert n_ctx_from_init_ids(sixteen, 77) == 16
+    with pytest.raises(ValueError):
+        n_ctx_from_init_ids(torch.tensor([[49406, 320, 1125, 539, 320, 999]]), 77)   # no EOT: argmax lands on SOT
+    with pytest.raises(ValueError):
+        n_ctx_from_init_ids(torch.tensor([[49406, 49407]]), 77)                       # empty init
+
+
 def test_host_ece_matches_reference_goldens():
     g = load_golden("ece_cases.npz")
     for n in sorted({k.split(":")[0] for k in g}):

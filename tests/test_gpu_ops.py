@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from clip_calibration_amd import _lib
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -64,9 +65,9 @@ def test_gemm(ops, M, N, K, epi):
 @pytest.mark.parametrize("variant", [str(v) for v in range(10)] + ["a", "b", "c", "f"])
 @pytest.mark.parametrize("M,N,K,epi", [(200, 192, 128, "gelu"), (1000, 2304, 768, "bias"), (333, 512, 3072, "residual"),
                                         (50432, 768, 768, "residual"), (513, 260, 64, "none"), (5000, 3072, 768, "gelu")])
-def test_gemm_tile_variants(ops, monkeypatch, variant, M, N, K, epi):
-    """Every tile/pipeline variant the dispatcher can pick (CLIPMI_GEMM_VARIANT) computes the same thing."""
-    monkeypatch.setenv("CLIPMI_GEMM_VARIANT", variant)
+def test_gemm_tile_variants(ops, clipmi_option, variant, M, N, K, epi):
+    """Every tile/pipeline variant the dispatcher can pick (option gemm_variant) computes the same thing."""
+    clipmi_option("gemm_variant", _lib.gemm_variant_id(variant))
     test_gemm(ops, M, N, K, epi)
 
 
@@ -120,8 +121,8 @@ def _attn_ref(qkv, n, l, h, causal):
                                           (2, 199, 12, False), (1, 257, 16, False), (1, 577, 4, False), (2, 77, 1, True),
                                           (1, 32, 1, True), (1, 1, 1, False), (1, 225, 2, True)])
 @pytest.mark.parametrize("tr", ["1", "0"])
-def test_attention(ops, n, l, h, causal, tr, monkeypatch):
-    monkeypatch.setenv("CLIPMI_ATTN_NO_TR", "0" if tr == "1" else "1")   # both V staging paths
+def test_attention(ops, n, l, h, causal, tr, clipmi_option):
+    clipmi_option("attn_no_tr", 0 if tr == "1" else 1)   # both V staging paths
     g = torch.Generator().manual_seed(n * 1000 + l + h)
     qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
     ref = _attn_ref(qkv, n, l, h, causal)
@@ -194,6 +195,67 @@ def test_l2_and_logits_dac_conf_pred(ops):
         out = cal.predict(g[f"{n}:logits"])
         assert out.dtype == np.float32
         np.testing.assert_allclose(out, g[f"{n}:scaled_logits"], rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("B,C,E", [(256, 1000, 512), (1, 1, 64), (16, 64, 64), (37, 1003, 512), (300, 50, 768), (2048, 1000, 512),
+                                   (128, 397, 1024), (5, 3, 16)])
+@pytest.mark.parametrize("dac", [False, True])
+def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
+    """clipmi_fused_tail (one launch: normalise + logits + DAC + softmax top-1 + ECE bins; zsclip.py:99-101,
+    distanse_aware_calibration.py:49-58) against the same arithmetic as separate launches: bit-identical outputs, and the
+    ticket counters are left zero.  (5, 3, 16) is a shape the fused kernel does not take: both sides run the launches.)"""
+    rng = np.random.default_rng(B * 31 + C + E)
+    img = _cuda(torch.from_numpy(rng.normal(size=(B, E)).astype(np.float32)) * 3.0)
+    txt_n = ops.l2_normalize(_cuda(torch.from_numpy(rng.normal(size=(C, E)).astype(np.float32))))
+    dacc = _cuda(torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32))) if dac else None
+    labels = _cuda(torch.from_numpy(rng.integers(0, C, size=B)))
+    outs = []
+    for unfused in (1, 0):
+        clipmi_option("tail_unfused", unfused)
+        bins = torch.zeros(3 * 11, dtype=torch.float64, device="cuda")
+        lg, img_n, conf, pred = ops.fused_tail(img, txt_n, 100.0, dacc, True, True, labels, bins, 10)
+        outs.append((lg, img_n, conf, pred, bins))
+    (lg_u, in_u, cf_u, pr_u, bins_u), (lg_f, in_f, cf_f, pr_f, bins_f) = outs
+    assert torch.equal(in_u, ops.l2_normalize(img)) and torch.equal(in_f, in_u)
+    assert torch.equal(lg_f, lg_u) and torch.equal(pr_f, pr_u) and torch.equal(cf_f, cf_u)
+    assert torch.equal(bins_f[:11], bins_u[:11]) and torch.equal(bins_f[22:], bins_u[22:])      # counts, correct: exact
+    np.testing.assert_allclose(bins_f[11:22].cpu().numpy(), bins_u[11:22].cpu().numpy(), rtol=1e-14)   # sums of conf: atomics order
+    assert int(ops._TAIL_WS[torch.cuda.current_device()].view(torch.int32).abs().sum()) == 0
+    # against the oracle (fp32 dot products of E terms, |logit| <= 100)
+    ref, _, _ = orc.clip_logits(img.cpu(), txt_n.cpu(), 100.0)
+    ref = ref.numpy()
+    if dac:
+        ref = orc.dac_predict(ref, dacc.cpu().numpy())
+    np.testing.assert_allclose(lg_f.cpu().numpy(), ref, atol=3e-4, rtol=2e-6)
+    # pre-normalised entry (the multi-GPU path after the all-gather): same logits from the normalised features
+    lg_p, cf_p, pr_p = ops.logits_fused(in_f, txt_n, 100.0, dacc)
+    assert torch.equal(lg_p, lg_f) and torch.equal(cf_p, cf_f) and torch.equal(pr_p, pr_f)
+
+
+def test_fused_tail_handoff_under_load(ops):
+    """The row pass runs in whichever workgroup of a 16-row block draws the last ticket and reads logits that workgroups
+    on other CUs / XCDs stored a moment ago (agent-scope release / acquire).  Hammer it: 300 back-to-back launches on
+    changing inputs with the consumer's lines warm (the previous launch's logits sit in the caches), each checked in
+    full against the separate-launch path."""
+    from clip_calibration_amd import _lib as L
+    rng = np.random.default_rng(7)
+    B, C, E = 2048, 1000, 512
+    txt_n = ops.l2_normalize(_cuda(torch.from_numpy(rng.normal(size=(C, E)).astype(np.float32))))
+    dacc = _cuda(torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32)))
+    base = _cuda(torch.from_numpy(rng.normal(size=(B, E)).astype(np.float32)))
+    filler = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    bad = 0
+    for it in range(300):
+        img = torch.roll(base, shifts=it, dims=0) * (1.0 + 0.01 * it)
+        L.set_option("tail_unfused", 0)
+        if it % 3 == 0:
+            filler.add_(1)                      # uneven load: an HBM-bound stream ahead of the launch
+        lg, _, conf, pred = ops.fused_tail(img, txt_n, 100.0, dacc if it % 2 else None)
+        L.set_option("tail_unfused", 1)
+        lg_u, _, conf_u, pred_u = ops.fused_tail(img, txt_n, 100.0, dacc if it % 2 else None)
+        L.set_option("tail_unfused", 0)
+        bad += int(not (torch.equal(lg, lg_u) and torch.equal(conf, conf_u) and torch.equal(pred, pred_u)))
+    assert bad == 0, f"{bad} of 300 launches differ from the separate-launch path"
 
 
 def test_ece_device_accumulation(ops):

@@ -112,6 +112,36 @@ def _sample_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _empty_shard_worker(rank, world, port, out_dir):
+    """world 2, every sample on rank 0 (fewer batches than ranks): rank 1 must still enter the collectives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        rng = np.random.default_rng(9)
+        n = 40
+        conf = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        pred = rng.integers(0, 5, n)
+        gt = np.where(rng.uniform(size=n) < conf, pred, rng.integers(0, 5, n))
+        prox = rng.uniform(0.2, 0.9, n).astype(np.float32)
+        lo, hi = (0, n) if rank == 0 else (n, n)
+        ev = _HostEvaluator(conf[lo:hi], pred[lo:hi], gt[lo:hi])
+        if rank == 1:
+            ev._conf, ev._pred, ev._gt = [], [], []      # what process() leaves behind when it was never called
+        got = parallel.gather_samples(ev, torch.from_numpy(prox[lo:hi]) if rank == 0 else None, has_proximity=True)
+        assert np.array_equal(got.numpy(), prox)
+        assert np.array_equal(torch.cat(ev._conf).numpy(), conf) and np.array_equal(torch.cat(ev._pred).numpy(), pred)
+        assert abs(metrics.ece_from_bins(ev.bins.numpy(), 10) - orc.ece(conf.astype(np.float64), pred, gt, 10)) < 1e-12
+        np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.ones(1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_samples_with_an_empty_shard_world2(tmp_path):
+    mp.spawn(_empty_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0.npy").exists() and (tmp_path / "ok1.npy").exists()
+
+
 def test_sample_level_metrics_world2(tmp_path):
     mp.spawn(_sample_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.array_equal(np.load(tmp_path / "res0.npy"), np.load(tmp_path / "res1.npy"))

@@ -3,16 +3,16 @@
 faster per image than batch 256 streaming through HBM?)."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from clip_calibration_amd import synthetic as syn
+from clip_calibration_amd import _lib, synthetic as syn
 from clip_calibration_amd.model import build_model
 
 sd = syn.synthetic_state_dict("ViT-B/16")
 model = build_model(dict(sd), None).cuda()
 for v in os.environ.get("VARIANTS", "auto,0,1").split(","):
     if v == "auto":
-        os.environ.pop("CLIPMI_GEMM_VARIANT", None)
+        _lib.set_option("gemm_variant", -1)
     else:
-        os.environ["CLIPMI_GEMM_VARIANT"] = v
+        _lib.set_option("gemm_variant", _lib.gemm_variant_id(v))
     row = [f"variant {v:4s}:"]
     for B in (16, 32, 48, 64, 96, 128, 256):
         img = syn.synthetic_images(B, "ViT-B/16", device="cuda")

@@ -20,7 +20,7 @@ for name, m, n, k, epi, odt in SHAPES:
     times = {v: [] for v in VARIANTS}
     for r in range(ROUNDS + 1):
         for v in VARIANTS:
-            os.environ["CLIPMI_GEMM_VARIANT"] = v
+            _lib.set_option("gemm_variant", _lib.gemm_variant_id(v))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):

@@ -56,7 +56,7 @@ def main():
         line = [f"{name:5s} M={m} N={n} K={k}  hipBLASLt(no epilogue) {t_blas*1e3:7.1f} us {flop/t_blas/1e9:7.1f} TF |"]
         ref = (a[:512].float() @ w.float().t()) + bias
         for v in VARIANTS:
-            os.environ["CLIPMI_GEMM_VARIANT"] = v
+            _lib.set_option("gemm_variant", _lib.gemm_variant_id(v))
             out = torch.empty(m, n, dtype=odt, device="cuda")
             r = res.clone() if res is not None else None
             got = ops.gemm_f16(a, w, bias, r, epi, odt, out=out if r is None else r)

@@ -10,7 +10,7 @@ g = torch.Generator(device="cuda").manual_seed(0)
 for name, n, epi, odt in [("fc/gelu f16out", 3072, _lib.EPI_BIAS_QUICKGELU, torch.float16), ("qkv/bias f16out", 2304, _lib.EPI_BIAS, torch.float16),
                           ("none f16out", 3072, _lib.EPI_NONE, torch.float16), ("res f32", 768, _lib.EPI_BIAS_RESIDUAL, torch.float32)]:
     for v in os.environ.get("VARIANTS", "1,8").split(","):
-        os.environ["CLIPMI_GEMM_VARIANT"] = v
+        _lib.set_option("gemm_variant", _lib.gemm_variant_id(v))
         row = [f"{name:16s} N={n} v{v}:"]
         for k in (64, 128, 256, 768, 1536, 3072):
             a = torch.randn(M, k, device="cuda", generator=g).half()

@@ -1,51 +1,74 @@
 #!/usr/bin/env python3
-"""Diagnostic (never a benchmark): per-workgroup s_memrealtime stamps of the 2-stage GEMM kernel -> how long prologue,
-main loop, epilogue issue and store drain take, and how synchronised the CUs are."""
-import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from clip_calibration_amd import _lib, ops
+"""Diagnostic (never a benchmark): per-workgroup s_memrealtime stamps of the GEMM kernels AS THE IMAGE TOWER LAUNCHES THEM
+(LayerNorm fold, fp16 stream; clipmi_profile_block) -> how long prologue, main loop, epilogue issue and store drain take,
+and how synchronised the CUs are.  Needs the tuning build of the library:
 
-M = 256 * 197
-CASES = [("qkv", 2304, 768, _lib.EPI_BIAS, torch.float16, "1"), ("fc", 3072, 768, _lib.EPI_BIAS_QUICKGELU, torch.float16, "1"),
-         ("proj", 768, 3072, _lib.EPI_BIAS_RESIDUAL, torch.float32, "a"),
-         ("qkv persistent", 2304, 768, _lib.EPI_BIAS, torch.float16, "b"), ("fc persistent", 3072, 768, _lib.EPI_BIAS_QUICKGELU, torch.float16, "b")]
-for name, n, k, epi, odt, var in CASES:
-    os.environ["CLIPMI_GEMM_VARIANT"] = var
-    a = torch.randn(M, k, device="cuda").half(); w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
-    bias = torch.randn(n, device="cuda"); out = torch.empty(M, n, dtype=odt, device="cuda")
-    res = out if epi == _lib.EPI_BIAS_RESIDUAL else None
+    make -C clip_calibration_amd/csrc tuning
+    CLIPMI_LIBRARY=clip_calibration_amd/csrc/libclipmi_tuning.so python tools/gemm_stamps.py
+
+The product build has no stamp code in its kernels and does not export clipmi_tuning_set_stamps."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clip_calibration_amd import _lib, synthetic as syn  # noqa: E402
+from clip_calibration_amd.model import build_model  # noqa: E402
+
+if not hasattr(_lib.lib, "clipmi_tuning_set_stamps"):
+    raise SystemExit("libclipmi.so is the product build: `make -C clip_calibration_amd/csrc tuning` and set CLIPMI_LIBRARY")
+_lib.lib.clipmi_tuning_set_stamps.argtypes = [ctypes.c_void_p]
+
+B = int(os.environ.get("B", "256"))
+model = build_model(dict(syn.synthetic_state_dict("ViT-B/16", seed=0)), None).cuda()
+images = syn.synthetic_images(B, "ViT-B/16", seed=0, device="cuda")
+with torch.no_grad():
+    model.image_features_f32(images)          # real activations in the workspace
+torch.cuda.synchronize()
+
+CASES = [("in_proj", 0, None), ("out_proj", 2, None), ("c_fc", 3, None), ("c_proj", 4, None),
+         ("in_proj persistent", 0, 11), ("c_fc persistent", 3, 11)]
+if os.environ.get("CASES"):
+    CASES = [c for c in CASES if c[0] in os.environ["CASES"].split(",")]
+for name, step, variant in CASES:
+    _lib.set_option("gemm_variant", -1 if variant is None else variant)
     stamps = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
-    for _ in range(3):
-        ops.gemm_f16(a, w, bias, res, epi, odt, out=out)
-    os.environ["CLIPMI_GEMM_STAMPS_PTR"] = hex(stamps.data_ptr())
-    ops.gemm_f16(a, w, bias, res, epi, odt, out=out)
+    model.profile_block_ms(B, iters=2, only=step)
+    _lib.lib.clipmi_tuning_set_stamps(stamps.data_ptr())
+    ms = model.profile_block_ms(B, iters=1, only=step)[model.BLOCK_KERNELS[step]]   # warm-up launch + timed launch: the last one's stamps stay
     torch.cuda.synchronize()
-    del os.environ["CLIPMI_GEMM_STAMPS_PTR"]
+    _lib.lib.clipmi_tuning_set_stamps(None)
     s = stamps.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] > 0]
     t = (s[:, :5] - s[:, 0].min()) / 100.0      # 100 MHz -> microseconds
     order = np.argsort(t[:, 0])
     t = t[order]
-    if var == "b":   # persistent: stamps are per tile (virtual block id); column 5 = physical workgroup
+    if variant == 11:   # persistent: stamps are per tile (virtual block id); column 5 = physical workgroup
         wg = s[order][:, 5]
         pro, main, epi_i = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
         per_wg = {}
         for row, g in zip(t, wg):
             per_wg.setdefault(int(g), []).append(row)
         gaps = [b[0] - a[3] for rows in per_wg.values() for a, b in zip(sorted(rows, key=lambda r: r[0])[:-1], sorted(rows, key=lambda r: r[0])[1:])]
-        print(f"{name}: {len(t)} tiles on {len(per_wg)} workgroups, span {t[:,3].max():.1f} us")
+        print(f"{name}: {len(t)} tiles on {len(per_wg)} workgroups, span {t[:,3].max():.1f} us (hipEvents {ms*1e3:.1f} us)")
         print(f"   tile start -> first stage ready med {np.median(pro):5.2f} us  p90 {np.percentile(pro,90):5.2f}")
         print(f"   main loop med {np.median(main):5.2f} us  p90 {np.percentile(main,90):5.2f}")
         print(f"   prefetch + epilogue issue med {np.median(epi_i):5.2f} us  p90 {np.percentile(epi_i,90):5.2f}")
         print(f"   epilogue end -> next tile start med {np.median(gaps):5.2f} us")
         continue
     pro, main, epi_i, drain = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3]
-    print(f"{name}: {len(t)} workgroups, kernel span {t[:,4].max():.1f} us")
+    print(f"{name}: {len(t)} workgroups, kernel span {t[:,4].max():.1f} us (hipEvents {ms*1e3:.1f} us)")
     print(f"   prologue  med {np.median(pro):5.2f} us  p90 {np.percentile(pro,90):5.2f}")
     print(f"   main loop med {np.median(main):5.2f} us  p90 {np.percentile(main,90):5.2f}")
     print(f"   epi issue med {np.median(epi_i):5.2f} us  p90 {np.percentile(epi_i,90):5.2f}")
     print(f"   drain     med {np.median(drain):5.2f} us  p90 {np.percentile(drain,90):5.2f}")
-    first = t[:256]
-    print(f"   first 256 WGs start spread {first[:,0].max()-first[:,0].min():.2f} us; their end spread {first[:,4].max()-first[:,4].min():.2f} us")
+    n1 = min(256, len(t))
+    first = t[:n1]
+    print(f"   first {n1} WGs start spread {first[:,0].max()-first[:,0].min():.2f} us; their end spread {first[:,4].max()-first[:,4].min():.2f} us")
     starts = np.sort(t[:, 0])
-    print("   start times of WG #256..#263 (second round):", np.round(starts[256:264], 1))
+    if len(starts) > 264:
+        print("   start times of WG #256..#263 (second round):", np.round(starts[256:264], 1))
+_lib.set_option("gemm_variant", -1)
