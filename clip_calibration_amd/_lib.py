@@ -162,7 +162,7 @@ class option:
         return False
 
 
-_VARIANT_LETTERS = {"a": 10, "b": 11, "c": 12, "f": 15}
+_VARIANT_LETTERS = {"a": 10, "b": 11, "c": 12, "s": 13, "f": 15}
 
 
 def gemm_variant_id(v) -> int:

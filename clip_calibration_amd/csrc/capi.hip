@@ -38,6 +38,7 @@ const OptionDesc kOptions[] = {
     {"gemm_variant", "CLIPMI_GEMM_VARIANT", &Options::gemm_variant},
     {"gemm_band", "CLIPMI_GEMM_BAND", &Options::gemm_band},
     {"gemm_persist", "CLIPMI_GEMM_PERSIST", &Options::gemm_persist},
+    {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_no_tr", "CLIPMI_ATTN_NO_TR", &Options::attn_no_tr},
@@ -51,7 +52,7 @@ const OptionDesc kOptions[] = {
 // (CLIPMI_GEMM_VARIANT a/b/c/f = 10/11/12/15, CLIPMI_RESIDUAL_F16 v/t = 2/3)
 int parse_option(const char* name, const char* text) {
   if (!strcmp(name, "gemm_variant")) {
-    switch (text[0]) { case 'a': return 10; case 'b': return 11; case 'c': return 12; case 'f': return 15; default: break; }
+    switch (text[0]) { case 'a': return 10; case 'b': return 11; case 'c': return 12; case 's': return 13; case 'f': return 15; default: break; }
   }
   if (!strcmp(name, "residual_f16")) {
     switch (text[0]) { case 'v': return 2; case 't': return 3; default: break; }
@@ -68,6 +69,7 @@ std::atomic<int> g_cus[64];
 
 #ifdef CLIPMI_TUNING
 std::atomic<long long*> g_tuning_stamps{nullptr};
+std::atomic<int> g_tuning_knob{0};
 #endif
 
 Options& options() {
@@ -190,6 +192,7 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       } else {
         a.W = (const half_t*)b.w_qkv_f; a.bias = b.c_qkv; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_qkv; a.ln_dim = D;
         a.ln_eps = 1e-5f;
+        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * M;   // the last partial slot is free
       }
       a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
@@ -208,6 +211,7 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       } else {
         a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_fc; a.ln_dim = D;
         a.ln_eps = 1e-5f;
+        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * M;
       }
       a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
@@ -344,6 +348,13 @@ int clipmi_set_option(const char* name, int value) {
 #ifdef CLIPMI_TUNING
 int clipmi_tuning_set_stamps(void* device_buffer) {   // tuning build only; not part of include/clipmi.h
   g_tuning_stamps.store(static_cast<long long*>(device_buffer), std::memory_order_relaxed);
+  return CLIPMI_OK;
+}
+#endif
+
+#ifdef CLIPMI_TUNING
+int clipmi_tuning_set_knob(int bits) {   // tuning build only
+  g_tuning_knob.store(bits, std::memory_order_relaxed);
   return CLIPMI_OK;
 }
 #endif

@@ -45,7 +45,9 @@ int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
 struct Options {
   std::atomic<int> gemm_variant{-1};   // CLIPMI_GEMM_VARIANT: -1 = cost model, else the forced tile configuration (test / tuning aid)
   std::atomic<int> gemm_band{0};       // CLIPMI_GEMM_BAND: 0 = default traversal band
-  std::atomic<int> gemm_persist{0};    // CLIPMI_GEMM_PERSIST
+  std::atomic<int> gemm_persist{0};    // CLIPMI_GEMM_PERSIST: 1 = persistent 16-wave tile (parameters computed per tile), 2 / 3 = persistent
+                                       // 16- / 8-wave tile with DMA'd parameters (ln_finalize_kernel); measured equal to the default (power cap)
+  std::atomic<int> gemm_stream{0};     // CLIPMI_GEMM_STREAM: 1 = streamed-epilogue persistent kernel for large fp16-out GEMMs (measured slower)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
   std::atomic<int> attn_no_tr{0}, attn_no_persist{0}, attn_no_stream{0}, attn_stagger{0};
@@ -57,6 +59,7 @@ Options& options();
 // Diagnostic build only (make TUNING=1): device buffer of 8 int64 per workgroup that the GEMM kernels stamp with
 // s_memrealtime at their phase boundaries (clipmi_tuning_set_stamps, tools/gemm_stamps.py).  Absent from the product build.
 extern std::atomic<long long*> g_tuning_stamps;
+extern std::atomic<int> g_tuning_knob;   // ablation bits (clipmi_tuning_set_knob)
 #endif
 
 // Per-device state.  One process may drive several GPUs: kernel attributes (dynamic LDS size) are set once per
@@ -106,6 +109,7 @@ struct GemmArgs {
   //   producer (BIAS_RESIDUAL): x16 != NULL -> also store fp16(out) to x16 (ld = ldo), write this tile's row partials to
   //   stats_out and report the number of partials per row (= its n-tile count) through *parts_out (host pointer)
   const float* ln_stats; int ln_parts; const float* ln_g; int ln_dim; float ln_eps;
+  float* ln_rows = nullptr;   // consumer, optional scratch [M][2] fp32: lets the streamed-epilogue kernel reduce the partials once per GEMM
   half_t* x16; float* stats_out; int* parts_out;
   bool residual_f16 = false;   // producer: the residual operand is x16 itself (fp16 stream, updated in place); `residual`/`out` unused
 };

@@ -38,7 +38,8 @@ struct KArgs {
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   half_t* x16; float* stats_out;
 #ifdef CLIPMI_TUNING
-  long long* stamps;   // diagnostic build only (make TUNING=1, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps
+  long long* stamps;   // diagnostic build only (make tuning, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps
+  int knob;            // diagnostic build only: ablation bits of the streamed-epilogue kernel (timing only, results wrong)
 #endif
 };
 
@@ -800,6 +801,15 @@ int launch_ring(KArgs k, hipStream_t s) {
   return check_launch("gemm_ring_kernel");
 }
 
+// (rstd, mean * rstd) of every row from the producer's row partials: ln_row_params once per row and GEMM
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2* __restrict__ rows) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  float rs, mrs;
+  ln_row_params(a, m, rs, mrs);
+  rows[m] = make_float2(rs, mrs);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent variant of the 2-stage kernel: one workgroup per CU walks its tiles (same XCD-aware order, virtual block
 // id = blockIdx + k * gridDim).  After the last K-step of a tile the first stage of the NEXT tile is DMA'd into the
@@ -808,7 +818,7 @@ int launch_ring(KArgs k, hipStream_t s) {
 // epilogue patch lives behind the two stage buffers (16-row chunks keep it at 2.25 KiB per wave).
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs a) {
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
   constexpr int ROWB = T::WTN * 2 + 16;
   constexpr bool PATCH_ALIASED = T::SMEM + T::NW * 16 * ROWB > 160 * 1024;
@@ -884,6 +894,28 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
   constexpr bool COLP = EPI != CLIPMI_EPI_NONE && !OUT_F32 && EPI != EPI_PATCH_POS;
   int par = 0;
   auto row_params = [&](int row0, int col0, int which) {
+    if constexpr (CONSUMER && COLP) {
+      if (ln_rows) {   // kernel argument: uniform
+        // Row parameters finalised once per GEMM (ln_finalize_kernel) + the column parameters: straight into LDS by DMA, one
+        // 1 KiB piece per wave.  Computing them here with ordinary loads put a vmcnt(0) -- i.e. the whole 64 KB prefetch of
+        // the next tile's first stage -- and 256 chains of fp64 arithmetic between two tiles (phase stamps: 3.8 us per c_fc tile).
+        constexpr int PL = BM * 8 / 1024, PC = BN * 4 / 1024;
+        static_assert(PL + 2 * PC <= T::NW && (BM * 8) % 1024 == 0 && (BN * 4) % 1024 == 0, "one DMA piece per wave");
+        char* lnp = smem + LNP_OFF + which * (BM * 8);
+        char* colp = smem + COLP_OFF + which * (2 * BN * 4);
+        if (wave < PL) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows + row0, (int64_t)(a.M - row0) * 8);
+          CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, (wave * 64 + lane) * 16, 0);
+        } else if (wave < PL + PC) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bias + col0, (int64_t)(a.N - col0) * 4);
+          CLIPMI_BUFFER_LOAD_LDS16(rs, colp + (wave - PL) * 1024, ((wave - PL) * 64 + lane) * 16, 0);
+        } else if (wave < PL + 2 * PC) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_g + col0, (int64_t)(a.N - col0) * 4);
+          CLIPMI_BUFFER_LOAD_LDS16(rs, colp + BN * 4 + (wave - PL - PC) * 1024, ((wave - PL - PC) * 64 + lane) * 16, 0);
+        }
+        return;
+      }
+    }
     if constexpr (CONSUMER) {
       if (a.ln_stats) {   // block-uniform
         float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
@@ -1003,7 +1035,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
 }
 
 template <typename T, int EPI, bool OUT_F32>
-int launch_persist(KArgs k, hipStream_t s) {
+int launch_persist(KArgs k, hipStream_t s, float2* ln_rows = nullptr) {
   constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
   constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2) + 4 * T::BN * (int)sizeof(float);   // + row / column parameters
   static DeviceOnce attr_once;
@@ -1019,7 +1051,15 @@ int launch_persist(KArgs k, hipStream_t s) {
   k.nwg = (int)nwg;
   const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
   const int grid = k.nwg < n_cu * per_cu ? k.nwg : n_cu * per_cu;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k);
+  constexpr bool DMA_OK = (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) && !OUT_F32;
+  const float2* rows = nullptr;
+  if (DMA_OK && k.ln_stats && ln_rows) {   // the row partials -> (rstd, mean * rstd), once per GEMM
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((k.M + 255) / 256), dim3(256), 0, s, k, ln_rows);
+    const int rc = check_launch("ln_finalize_kernel");
+    if (rc) return rc;
+    rows = ln_rows;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k, rows);
   return check_launch("gemm_persist_kernel");
 }
 
@@ -1251,6 +1291,315 @@ int launch_defer(KArgs k, hipStream_t s) {
   const int grid = k.nwg < n_cu ? k.nwg : n_cu;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(768), SMEM, s, k);
   return check_launch("gemm_defer_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streamed-epilogue persistent kernel (fp16-out epilogues: in-proj, c_fc): 256 x 256 tile, EIGHT waves of 128(m) x 64(n)
+// (two per SIMD, 256 registers each), one workgroup per CU walking its tiles.
+//
+// Why: phase stamps of the 16-wave kernel (tools/gemm_stamps.py, round 2) put a 256 x 256 x 768 tile at 17.1 us of main
+// loop (1.5 PFLOP/s) + 1.5 us of prologue + 2.6-3.6 us of epilogue + 1-4 us until the CU's next workgroup starts: a third
+// of every tile is spent with the matrix pipe idle, and because every CU reaches its epilogue at the same moment the
+// 32 MB of stores of one round of tiles hit HBM as one burst.  Here the epilogue leaves the critical path:
+//   * after the K loop a wave only CONVERTS its 128 x 64 outputs (bias / LayerNorm fold / QuickGELU) to fp16 and keeps
+//     them in 64 registers (the accumulators themselves are needed for the next tile at once);
+//   * they are stored in eight 16-row slices, one per K-step, inside the NEXT tile's K loop, straight from the
+//     registers (four 8-byte buffer stores per lane and slice; the four stores of a slice fill whole 128-byte lines of
+//     16 rows, which L2 merges) -- no LDS round trip, no wait: the HBM write stream is continuous instead of bursty;
+//   * the next tile's first stage AND its row / column parameters are DMA'd (buffer_load ... lds) before the conversion
+//     starts; the row parameters (rstd, mean * rstd) come from ln_finalize_kernel, which reduces the row partials once
+//     per GEMM instead of once per tile.
+// Ablations on MI355X (tools/stream_ablate.py): a first version that sent each slice through a wave-private LDS patch at
+// the top of its K-step paid 0.9 us per slice (nothing else runs on the SIMD while both of its waves wait for that
+// round trip), computed the parameters of the next tile with ordinary loads (their vmcnt wait also waits for the 64 KB
+// stage) and ended 10 % SLOWER than the one-tile-per-workgroup kernel; without those three costs the loop runs at
+// 19 us per tile at 100 % duty.
+// With 8 waves a wave has 256 registers: 128 accumulators + 64 held outputs + 48 operand fragments fit (the 16-wave
+// geometry has 128 per wave: 64 + 32 held + 24 fragments + addresses do not).  The K-steps that carry a store slice are
+// unrolled (straight-line code: hipcc's waitcnt pass keeps counted lgkmcnt waits), the remaining ones run in a loop.
+// Needs K >= 10 * 64, an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
+// ---------------------------------------------------------------------------------------------------------------
+using TStream = Tile<256, 256, 2, 4, 2>;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
+  using T = TStream;
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;   // TM = 8, TN = 4
+  constexpr int LNP_OFF = T::SMEM, COLP_OFF = LNP_OFF + 2 * BM * 8;             // 2 x [BM] (rstd, mean*rstd) | 2 x ([BN] bias | [BN] g)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const bool fold = ln_rows != nullptr;   // kernel argument: uniform
+
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
+  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
+  const int lds_wave_off = wave * 1024;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * T::WTM * 128;
+  const int wbase = T::XBYTES + wave_n * T::WTN * 128;
+  const int nk = a.K / BK;
+
+  auto coords = [&](int vb, int& m0, int& n0) {
+    const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int per_band = tiles_m * a.band;
+    const int b = wg / per_band;
+    const int within = wg - b * per_band;
+    const int rem = a.tiles_n - b * a.band;
+    const int gw = rem < a.band ? rem : a.band;
+    const int tm = within / gw;
+    m0 = tm * BM;
+    n0 = (b * a.band + (within - tm * gw)) * BN;
+  };
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
+    char* xs = smem + buf * T::STAGE + lds_wave_off;
+    char* ws = xs + T::XBYTES;
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff0, i * xstep), k0);
+#pragma unroll
+    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff0, i * wstep), k0);
+  };
+  // row / column parameters of a tile -> LDS by DMA, one 1 KiB piece per wave (waves 0-3); rows / columns outside the
+  // matrix lie outside the descriptors and read as zero.  They ride on the same vmcnt wait as the tile's first stage.
+  auto params = [&](int row0, int col0, int which) {
+    char* lnp = smem + LNP_OFF + which * (BM * 8);
+    char* colp = smem + COLP_OFF + which * (2 * BN * 4);
+    if (wave < 2) {
+      if (fold) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows + row0, (int64_t)(a.M - row0) * 8);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, (wave * 64 + lane) * 16, 0);
+      }
+    } else if (wave == 2) {
+      if constexpr (EPI != CLIPMI_EPI_NONE) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bias + col0, (int64_t)(a.N - col0) * 4);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, colp, lane * 16, 0);
+      }
+    } else if (wave == 3) {
+      if (fold) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_g + col0, (int64_t)(a.N - col0) * 4);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, colp + BN * 4, lane * 16, 0);
+      }
+    }
+  };
+  // constant parts of the parameter tables (no fold: rstd = 1, mean * rstd = 0, g = 0; no bias: 0), both parities
+  for (int t = tid; t < 2 * BM; t += NT)
+    if (!fold) reinterpret_cast<float2*>(smem + LNP_OFF)[t] = make_float2(1.f, 0.f);
+  for (int t = tid; t < 2 * 2 * BN; t += NT) {
+    const bool is_g = (t / BN) & 1;
+    if (is_g ? !fold : EPI == CLIPMI_EPI_NONE) reinterpret_cast<float*>(smem + COLP_OFF)[t] = 0.f;
+  }
+
+  int vb = blockIdx.x;
+  int m0, n0;
+  coords(vb, m0, n0);
+  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int first_buf = 0, par = 0;
+  stage(xrs, wrs, first_buf, 0);
+  params(m0, n0, 0);
+
+  f16x4 held[TN][TM];        // the previous tile's outputs of this wave, fp16
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) held[i][j] = f16x4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  // The held tile is stored through a buffer descriptor that starts at the tile's first element and ends with the matrix:
+  // rows at or beyond M are dropped by the hardware range check, "nothing held yet" is a descriptor of zero bytes.  The
+  // whole byte offset goes into the VGPR operand -- only that (not the scalar offset) takes part in the range check --
+  // as (lane constant) + (scalar: wave, slice and column-block part); columns at or beyond N (last n-tile when N is not
+  // a multiple of 256) are sent out of range the same way: no divergent branch around the stores.
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  half_t* out = static_cast<half_t*>(a.out);
+  __amdgpu_buffer_rsrc_t ors = make_rsrc(out, 0);
+  int hn0 = 0;               // first column of the held tile
+  const int st_lane = (r16 * (int)a.ldo + g4 * 4) * 2;
+  const int slice_bytes = 16 * (int)a.ldo * 2;
+  const int wave_soff = (wave_m * T::WTM * (int)a.ldo + wave_n * 64) * 2;   // scalar
+  auto flush_slice = [&](int j) {   // rows 16 j .. 16 j + 15 of this wave's part of the held tile
+    const int col = hn0 + wave_n * 64 + g4 * 4;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int voff = col + i * 16 < a.N ? row_off(st_lane, wave_soff + j * slice_bytes + i * 32) : (int)0xFFFFFFF0;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, held[i][j]), ors, voff, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+  // one K-step; SLICE >= 0: also store rows 16*SLICE .. +15 of the held tile.
+  // VMEM operations retire in order, so a wait for stage kt also waits for every store issued before stage kt's DMA -- but
+  // not for the four stores of the slice sent during the previous K-step, which were issued AFTER it: after a K-step that
+  // sent a slice the wait is vmcnt(4), and a store has two K-steps (~3 us) to be acknowledged before anything waits for it.
+  // Raw s_barrier: __syncthreads() would add its own vmcnt(0) while LDS-DMA is in flight.
+  auto kstep = [&](auto slice_tag, auto prev_sent_tag, int kt) {
+    constexpr int SLICE = decltype(slice_tag)::value;
+    constexpr bool PREV_SENT = decltype(prev_sent_tag)::value;
+    const int buf = (first_buf + kt) & 1;
+    if constexpr (PREV_SENT) wait_vmcnt<TN>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
+#ifdef CLIPMI_TUNING
+    if constexpr (SLICE >= 0) { if (!(a.knob & 1)) flush_slice(SLICE); }
+#else
+    if constexpr (SLICE >= 0) flush_slice(SLICE);
+#endif
+    const char* st = smem + buf * T::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {   // activation fragments in two halves that share registers; weight fragments one ahead
+        f16x8 xf[TM / 2], wcur, wnext;
+#pragma unroll
+        for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + (h * (TM / 2) + j) * 2048 + foff[ks]);
+        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int j = 0; j < TM / 2; ++j)
+            acc[i][h * (TM / 2) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][h * (TM / 2) + j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          wcur = wnext;
+        }
+      }
+    }
+  };
+
+#ifdef CLIPMI_TUNING
+  const bool stamp = a.stamps != nullptr && tid == 0;
+#endif
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef CLIPMI_TUNING
+    if (stamp) {
+      a.stamps[vb * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
+    }
+#endif
+    constexpr std::false_type no{};
+    constexpr std::true_type yes{};
+    kstep(std::integral_constant<int, -1>{}, no, 0);
+#ifdef CLIPMI_TUNING
+    if (stamp) a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    kstep(std::integral_constant<int, 0>{}, no, 1);
+    kstep(std::integral_constant<int, 1>{}, yes, 2);
+    kstep(std::integral_constant<int, 2>{}, yes, 3);
+    kstep(std::integral_constant<int, 3>{}, yes, 4);
+    kstep(std::integral_constant<int, 4>{}, yes, 5);
+    kstep(std::integral_constant<int, 5>{}, yes, 6);
+    kstep(std::integral_constant<int, 6>{}, yes, 7);
+    kstep(std::integral_constant<int, 7>{}, yes, 8);
+    kstep(std::integral_constant<int, -1>{}, yes, 9);   // K >= 10 K-steps (checked by the launcher)
+    for (int kt = 10; kt < nk; ++kt) kstep(std::integral_constant<int, -1>{}, no, kt);
+
+    const int last_buf = (first_buf + nk - 1) & 1;
+    const int cm0 = m0, cn0 = n0;
+    [[maybe_unused]] const int cvb = vb;
+#ifdef CLIPMI_TUNING
+    if (stamp) a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < a.nwg;
+    if (has_next) {   // the buffer that is NOT the last one read is free: the next tile's first stage goes there now
+      vb = nvb;
+      coords(vb, m0, n0);
+      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+      first_buf = last_buf ^ 1;
+      stage(xrs, wrs, first_buf, 0);
+      params(m0, n0, par ^ 1);
+    }
+    // ---- element-wise epilogue into `held` (row / column parameters from LDS, DMA'd a whole tile ago)
+    {
+      int le = lane;
+      asm volatile("" : "+v"(le));   // keeps the lane-derived offsets below out of the K loop's live ranges
+      const int er16 = le & 15, eg4 = le >> 4;
+      const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM;
+      const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+#ifdef CLIPMI_TUNING
+        if (a.knob & 8) break;
+#endif
+        const float2 pr = lnp[wave_m * T::WTM + j * 16 + er16];
+        const float rs = pr.x, mrs = pr.y;
+        // the column parameters are the same for every slice: left to itself hipcc loads all eight vectors once, keeps
+        // them across the whole conversion (32 registers the kernel does not have) and spills them.  An opaque copy of
+        // the lane's column offset makes every slice re-read its eight LDS vectors instead.
+        int nl0 = wave_n * 64 + eg4 * 4;
+        asm volatile("" : "+v"(nl0));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nl = nl0 + i * 16;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + BN + nl);
+          f32x4 v = acc[i][j] * rs + (bb - mrs * gg);
+          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          held[i][j] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one 16-row slice at a time: the accumulators die as they are converted
+      }
+    }
+    ors = make_rsrc(out + (int64_t)cm0 * a.ldo + cn0, ((int64_t)(a.M - cm0) * a.ldo - cn0) * 2);
+    hn0 = cn0;
+    par ^= 1;
+#ifdef CLIPMI_TUNING
+    if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    if (!has_next) break;
+  }
+  // the last tile's outputs: nothing left to hide them behind
+#pragma unroll
+  for (int j = 0; j < TM; ++j) flush_slice(j);
+}
+
+template <int EPI>
+int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
+  using T = TStream;
+  constexpr int SMEM = T::SMEM + 2 * T::BM * 8 + 2 * 2 * T::BN * 4;
+  static_assert(SMEM <= 160 * 1024, "stream kernel LDS");
+  static DeviceOnce attr_once;
+  auto fn = gemm_stream_kernel<EPI>;
+  ensure_dynamic_lds(fn, SMEM, attr_once);
+  const int n_cu = device_cus() & ~7;   // the XCD label of a virtual block id must not change across rounds
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  CLIPMI_REQUIRE(257 * k.ldo * 2 < (1ll << 31), CLIPMI_ERR_SHAPE, "gemm: output rows too long for the 32-bit tile offsets of the streamed epilogue");
+  k.nwg = (int)nwg;
+  if (k.ln_stats) {   // the row partials -> (rstd, mean * rstd), once per GEMM
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((k.M + 255) / 256), dim3(256), 0, s, k, ln_rows);
+    const int rc = check_launch("ln_finalize_kernel");
+    if (rc) return rc;
+  }
+  const int grid = k.nwg < n_cu ? k.nwg : n_cu;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k, static_cast<const float2*>(k.ln_stats ? ln_rows : nullptr));
+  return check_launch("gemm_stream_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1702,11 +2051,25 @@ int launch_basic(const KArgs& k, hipStream_t s) {
 }
 
 template <int EPI, bool OUT_F32>
-int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
+int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = nullptr) {
   int variant = pick_variant(k);
+  // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 9 K-steps: the streamed-epilogue persistent kernel
+  // (the cost model above only ranks the one-tile-per-workgroup kernels)
+  if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
+    const int pm = options().gemm_persist.load(std::memory_order_relaxed);
+    if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && pm >= 2 && (k.N & 7) == 0 && (k.ldo & 7) == 0 &&
+        (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
+      variant = pm == 3 ? 9 : 11;   // persistent tiles with DMA'd parameters: 2 = 16 waves, 3 = 8 waves
+  }
+  if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
+    if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && options().gemm_stream.load(std::memory_order_relaxed) == 1 &&
+        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 10 * BK && (!k.ln_stats || ln_rows) &&
+        (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
+      variant = 13;
+  }
   if (k.x16) {   // producer fold: needs the non-persistent epilogue and at most LN_MAX_PARTS column tiles
     if (variant == 9) variant = 2;
-    if (variant == 11 || variant == 12) variant = 1;
+    if (variant == 11 || variant == 12 || variant == 13) variant = 1;
     const int bn = (variant == 0) ? 128 : (variant == 3 || variant == 7) ? 128 : 256;
     if ((k.N + bn - 1) / bn > LN_MAX_PARTS) variant = 1;
     CLIPMI_REQUIRE((k.N + 255) / 256 <= LN_MAX_PARTS, CLIPMI_ERR_SHAPE, "gemm: N=%d has too many column tiles for the LayerNorm fold", k.N);
@@ -1722,9 +2085,14 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out) {
     case 6: return launch_ring<T128x256o4, 3, EPI, OUT_F32>(k, s);   // 72 KiB -> 2 workgroups / CU
     case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
-    case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s);
+    case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s, ln_rows);
     case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
-    case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s);
+    case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);
+    case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
+      if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
+        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 10 * BK && (!k.ln_stats || ln_rows)) return launch_stream<EPI>(k, ln_rows, s);
+      }
+      return launch_tile<T256w16, EPI, OUT_F32>(k, s);
     case 15:   // deferred-store persistent kernel: fp16-out epilogues on 8-column-aligned outputs only
       if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
         if ((k.N & 7) == 0 && (k.ldo & 7) == 0) return launch_defer<EPI>(k, s);
@@ -1762,6 +2130,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
 #ifdef CLIPMI_TUNING
   k.stamps = g_tuning_stamps.load(std::memory_order_relaxed);   // clipmi_tuning_set_stamps (tools/gemm_stamps.py), tuning build only
+  k.knob = g_tuning_knob.load(std::memory_order_relaxed);
 #endif
   CLIPMI_REQUIRE(!a.ln_stats || (a.ln_g && a.ln_dim > 0 && a.ln_parts >= 1 && a.ln_parts <= LN_MAX_PARTS &&
                                  (a.epilogue == CLIPMI_EPI_BIAS || a.epilogue == CLIPMI_EPI_BIAS_QUICKGELU)),
@@ -1773,13 +2142,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:
-      return f32 ? launch_one<CLIPMI_EPI_NONE, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_NONE, false>(k, s, a.parts_out);
+      return f32 ? launch_one<CLIPMI_EPI_NONE, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_NONE, false>(k, s, a.parts_out, reinterpret_cast<float2*>(a.ln_rows));
     case CLIPMI_EPI_BIAS:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
-      return f32 ? launch_one<CLIPMI_EPI_BIAS, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS, false>(k, s, a.parts_out);
+      return f32 ? launch_one<CLIPMI_EPI_BIAS, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS, false>(k, s, a.parts_out, reinterpret_cast<float2*>(a.ln_rows));
     case CLIPMI_EPI_BIAS_QUICKGELU:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
-      return f32 ? launch_one<CLIPMI_EPI_BIAS_QUICKGELU, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS_QUICKGELU, false>(k, s, a.parts_out);
+      return f32 ? launch_one<CLIPMI_EPI_BIAS_QUICKGELU, true>(k, s, a.parts_out) : launch_one<CLIPMI_EPI_BIAS_QUICKGELU, false>(k, s, a.parts_out, reinterpret_cast<float2*>(a.ln_rows));
     case CLIPMI_EPI_BIAS_RESIDUAL:
       CLIPMI_REQUIRE(a.bias && (uintptr_t)a.bias % 16 == 0, CLIPMI_ERR_ARG, "gemm: bias missing/unaligned");
       if (a.residual_f16) {

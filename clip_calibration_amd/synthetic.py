@@ -162,6 +162,51 @@ def synthetic_state_dict(geom: ClipGeometry | str = "ViT-B/16", seed: int = 0,
     return sd
 
 
+def outlier_state_dict(geom: ClipGeometry | str = "ViT-B/16", seed: int = 0, logit_scale: float = 4.6052,
+                       n_outlier: int = 4, outlier_gain: float = 96.0, offset: float = 2.5) -> Dict[str, torch.Tensor]:
+    """``synthetic_state_dict`` reshaped to the activation statistics of trained CLIP towers (SURVEY §7 risk: a handful of
+    "massive" residual channels, LayerNorm gains spread over an order of magnitude, a common offset in the stream):
+
+    * ``n_outlier`` residual channels per tower: their rows of ``attn.out_proj`` / ``mlp.c_proj`` in the first two blocks
+      are scaled by ``outlier_gain`` and get biases of +-(6..12), so those channels of the residual stream sit 30-100x above
+      the rest for the remaining depth; their LayerNorm gains are small (as in trained checkpoints), the others are
+      log-uniform in [0.3, 3]; LayerNorm biases ~ N(0, 0.3);
+    * ``ln_pre`` (image) / the positional embedding (text) add a common offset, so that mean^2 is comparable with E[x^2]
+      in every row -- the cancellation a LayerNorm computed from (sum x, sum x^2) has to survive.
+
+    Deterministic in (geom, seed); every tensor fp16-representable, like ``synthetic_state_dict``."""
+    if isinstance(geom, str):
+        geom = GEOMETRIES[geom]
+    sd = synthetic_state_dict(geom, seed=seed, logit_scale=logit_scale)
+    g = torch.Generator().manual_seed(7919 + seed)
+
+    def tower(prefix: str, width: int, layers: int):
+        ch = torch.randperm(width, generator=g)[:n_outlier]
+        sign = torch.where(torch.rand(n_outlier, generator=g) < 0.5, -1.0, 1.0)
+        for i in range(layers):
+            p = f"{prefix}resblocks.{i}."
+            for ln in ("ln_1", "ln_2"):
+                gain = torch.exp(torch.empty(width).uniform_(-1.2, 1.1, generator=g))      # log-uniform in [0.3, 3]
+                gain[ch] = 0.02 + 0.05 * torch.rand(n_outlier, generator=g)
+                sd[p + ln + ".weight"] = _r16(gain)
+                sd[p + ln + ".bias"] = _r16(0.3 * torch.randn(width, generator=g))
+            if i < 2:
+                for w, b in (("attn.out_proj.weight", "attn.out_proj.bias"), ("mlp.c_proj.weight", "mlp.c_proj.bias")):
+                    sd[p + w][ch] = _r16(sd[p + w][ch] * outlier_gain)
+                    sd[p + b][ch] = _r16(sign * (6.0 + 6.0 * torch.rand(n_outlier, generator=g)))
+        return ch
+
+    vch = tower("visual.transformer.", geom.vision_width, geom.vision_layers)
+    tch = tower("transformer.", geom.transformer_width, geom.transformer_layers)
+    sd["visual.ln_pre.bias"] = _r16(sd["visual.ln_pre.bias"] + offset)
+    sd["positional_embedding"] = _r16(sd["positional_embedding"] + 0.04 * offset)   # token embeddings are ~0.02: the same ratio
+    for name, ch in (("visual.ln_post", vch), ("ln_final", tch)):
+        gain = sd[name + ".weight"].clone()
+        gain[ch] = 0.05
+        sd[name + ".weight"] = _r16(gain)
+    return sd
+
+
 def synthetic_resnet_state_dict(layers=(1, 1, 1, 1), width: int = 64, image_resolution: int = 64, text_geom: str = "tiny",
                                 seed: int = 0, logit_scale: float = 4.6052) -> Dict[str, torch.Tensor]:
     """Seeded checkpoint with a ModifiedResNet image tower (key names of clip/model.py:10-150: ``visual.conv1.weight``,

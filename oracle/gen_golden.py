@@ -47,9 +47,9 @@ def sd_checksum(sd):
     return float(sum(v.double().abs().sum().item() for v in sd.values()))
 
 
-def ref_forward(ref_model, geom_name, seed, n_img, n_cls, capture=False):
+def ref_forward(ref_model, geom_name, seed, n_img, n_cls, capture=False, make_sd=None):
     """Run reference build_model + encode_image/encode_text/forward in fp32 (reading A) and fp16-on-CPU (reading B)."""
-    sd = syn.synthetic_state_dict(geom_name, seed=seed)
+    sd = (make_sd or syn.synthetic_state_dict)(geom_name, seed=seed)
     images = syn.synthetic_images(n_img, geom_name, seed=seed)
     ids = syn.synthetic_token_ids(n_cls, geom_name, seed=seed)
     out = {"images": images.numpy(), "ids": ids.numpy(), "sd_checksum": np.float64(sd_checksum(sd)), "seed": seed}
@@ -226,6 +226,29 @@ def main():
     out.pop("images")  # regenerated from the seed; ids are tiny so they stay
     np.savez_compressed(os.path.join(OUT, "vitb16_seed0.npz"), **out)
     print("wrote vitb16_seed0.npz")
+
+    # ---------------- full ViT-B/16 geometry with trained-CLIP-like activation statistics (massive residual channels, spread
+    # LayerNorm gains, common offset): the reference in fp32 and in fp16-on-CPU; weights regenerated from the seed ----------------
+    sd_o, m32_o, out = ref_forward(ref_model, "ViT-B/16", seed=0, n_img=4, n_cls=16, make_sd=syn.outlier_state_dict)
+    out.pop("images")
+    stats = {}
+    def stat_hook(i):
+        def f(_m, _i, o):
+            a = o.detach().abs().mean(dim=(0, 1))
+            stats[i] = (float(a.median()), float(a.max()), float(o.mean(-1).abs().mean()), float(o.std(-1).mean()))
+        return f
+    for i, blk in enumerate(m32_o.visual.transformer.resblocks):
+        blk.register_forward_hook(stat_hook(i))
+    with torch.no_grad():
+        m32_o.encode_image(syn.synthetic_images(4, "ViT-B/16", seed=0))
+    out["residual_stats"] = np.array([stats[i] for i in sorted(stats)])   # per block: median |x| per channel, max, mean |row mean|, mean row std
+    np.savez_compressed(os.path.join(OUT, "vitb16_outliers.npz"), **out)
+    print("wrote vitb16_outliers.npz; image-tower residual stream (median |x|, max |x| per channel, |row mean|, row std) per block:")
+    print(np.round(out["residual_stats"], 2))
+    i32, i16 = out["image_features"], out["image_features_fp16"]
+    t32, t16 = out["text_features"], out["text_features_fp16"]
+    nrm = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    print("  reference fp16-vs-fp32 cosine-logit error on this fixture:", np.abs(nrm(i16) @ nrm(t16).T - nrm(i32) @ nrm(t32).T).max())
 
     # ---------------- ECE (tools/metrics.py:90-130) ----------------
     rng = np.random.default_rng(0)

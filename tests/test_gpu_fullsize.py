@@ -224,3 +224,41 @@ def test_config4_dataset_sweep_class_counts():
         ops.ece_accumulate(conf, pred, labels, bins, 10)
         ref_bins = bin_statistics(conf.cpu().numpy(), pred.cpu().numpy(), labels.cpu().numpy(), 10)
         assert np.array_equal(bins.cpu().numpy().reshape(3, 11)[[0, 2]], ref_bins[[0, 2]]), Cn
+
+
+@pytest.mark.parametrize("Cn", [199, 24])
+def test_config4_per_rank_path_towers_and_tail(Cn):
+    """BASELINE configs[3] as a PATH at its per-rank shape: 128 images per GPU through the ViT-B/16 image tower, a class list
+    of the sweep's size (SUN397 base half: 199 prompts; DTD base half: 24) through the text tower, then what each rank of the
+    8-GPU run executes after the all-gather -- fp16 embeddings, fused tail with DAC, softmax top-1, ECE bins.  Checked against
+    the oracle on a 12-image slice (full towers on the CPU) and by batch invariance for the other rows."""
+    from clip_calibration_amd import ops
+    from clip_calibration_amd.model import build_model
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    from clip_calibration_amd.metrics import bin_statistics
+    sd = syn.synthetic_state_dict("ViT-B/16", seed=0)
+    model = build_model(dict(sd), None).cuda()
+    images = syn.synthetic_images(128, "ViT-B/16", seed=9, device="cuda")
+    ids = syn.synthetic_token_ids(Cn, "ViT-B/16", seed=9)
+    zs = ZeroshotCLIP(model, ids)
+    rng = np.random.default_rng(Cn)
+    dac = torch.from_numpy(rng.uniform(0.8, 1.2, Cn).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rng.integers(0, Cn, 128)).cuda()
+    bins = torch.zeros(33, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        feats = model.image_features_f32(images)
+        emb = ops.l2_normalize(feats, torch.float16)                       # what crosses xGMI
+        logits, _, conf, pred = ops.fused_tail(emb, zs.text_features, zs.scale, dac, True, False, labels, bins, 10)
+        sl = slice(40, 52)
+        feats_sl = model.image_features_f32(images[sl])
+        ref_i = orc.l2_normalize(orc.encode_image(sd, images[sl].cpu()))
+        ref_t = orc.l2_normalize(orc.encode_text(sd, ids))
+    assert torch.equal(feats[sl], feats_sl)                                # batch invariance, bitwise
+    ref = orc.dac_predict((zs.scale * ref_i @ ref_t.t()).numpy(), dac.cpu().numpy())
+    assert np.abs(logits[sl].cpu().numpy() - ref).max() < zs.scale * COS_TOL * 1.3     # DAC factors up to 1.2, fp16 embeddings
+    rc, rp = orc.conf_pred(orc.softmax_probs(ref.astype(np.float64)))
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * zs.scale * COS_TOL
+    assert np.array_equal(pred[sl].cpu().numpy()[clear], rp[clear])
+    ref_bins = bin_statistics(conf.cpu().numpy(), pred.cpu().numpy(), labels.cpu().numpy(), 10)
+    assert np.array_equal(bins.cpu().numpy().reshape(3, 11)[[0, 2]], ref_bins[[0, 2]])

@@ -152,6 +152,40 @@ def test_golden_vitb16():
     assert e.dtype == torch.float32 and torch.allclose(e, img, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["default", "ln_fold=0", "residual_f16=0", "residual_f16=1"])
+def test_golden_vitb16_outlier_statistics(clipmi_option, mode):
+    """Parity where it can fall over (SURVEY §7 risk; clip/model.py:153-159,185-188): ViT-B/16 depth with massive residual
+    channels (~60 against a typical 2.5), LayerNorm gains spread over an order of magnitude and a common offset, so that
+    mean^2 ~ E[x^2]/2 in every row -- against the REFERENCE's fp32 outputs on the same weights (tests/golden/
+    vitb16_outliers.npz).  The default path (LayerNorm folded from sum x / sum x^2 partials + fp16 image stream), the
+    separate-LayerNorm path, the fp32 stream and the all-fp16 stream must each stay within 1e-3 on cosine logits and within
+    twice the reference's own fp16-vs-fp32 distance on this fixture."""
+    from clip_calibration_amd.model import build_model
+    g = load_golden("vitb16_outliers.npz")
+    if mode != "default":
+        name, value = mode.split("=")
+        clipmi_option(name, int(value))
+    sd = syn.outlier_state_dict("ViT-B/16", seed=0)
+    model = build_model(dict(sd), dict(PLAIN)).cuda()
+    images = syn.synthetic_images(4, "ViT-B/16", seed=0).cuda()
+    ids = torch.from_numpy(g["ids"]).cuda()
+    with torch.no_grad():
+        img = model.image_features_f32(images).cpu().numpy()
+        txt = model.text_features_f32(ids).cpu().numpy()
+    assert np.isfinite(img).all() and np.isfinite(txt).all()
+    ref = _cos(g["image_features"], g["text_features"])
+    ref16_err = np.abs(_cos(g["image_features_fp16"], g["text_features_fp16"]) - ref).max()
+    err_both = np.abs(_cos(img, txt) - ref).max()
+    err_img = np.abs(_cos(img, g["text_features"]) - ref).max()
+    err_txt = np.abs(_cos(g["image_features"], txt) - ref).max()
+    print(f"[{mode}] cosine-logit error: both towers {err_both:.2e}, image side {err_img:.2e}, text side {err_txt:.2e}; "
+          f"reference fp16 vs fp32 {ref16_err:.2e}")
+    assert max(err_both, err_img, err_txt) < COS_TOL
+    assert err_both <= 2 * ref16_err + 2e-5
+    _feat_close(img, g["image_features"], "image features (outlier statistics)")
+    _feat_close(txt, g["text_features"], "text features (outlier statistics)")
+
+
 @pytest.mark.parametrize("B", [1, 5, 32])
 def test_zeroshot_pipeline_vs_oracle(B):
     """BASELINE config 1: ViT-B/16, C=100 prompts, synthetic batch; logits, (conf, pred) and ECE vs the CPU path."""

@@ -156,6 +156,27 @@ def test_vitb16_full_geometry():
     assert np.abs(g["logits_fp16"] - g["logits"]).max() / float(sd["logit_scale"].exp()) < 1e-3
 
 
+def test_vitb16_outlier_statistics_fixture():
+    """ViT-B/16 geometry with trained-CLIP-like activation statistics (massive residual channels ~60 against a typical 2.5,
+    LayerNorm gains over an order of magnitude, a common offset: mean^2 ~ E[x^2]/2): the oracle against the reference's own
+    fp32 outputs, and the reference's fp16-vs-fp32 distance recorded as the noise floor of this fixture."""
+    g = load_golden("vitb16_outliers.npz")
+    sd = syn.outlier_state_dict("ViT-B/16", seed=0)
+    assert _sd_checksum(sd) == pytest.approx(float(g["sd_checksum"]), rel=1e-12)
+    st = g["residual_stats"]                       # per block: median |x| per channel, max, mean |row mean|, mean row std
+    assert st.shape == (12, 4) and (st[1:, 1] > 20 * st[1:, 0]).all() and (st[:, 2] > 0.5 * st[:, 3]).all()
+    images = syn.synthetic_images(4, "ViT-B/16", seed=0)
+    ids = torch.from_numpy(g["ids"])
+    img = orc.encode_image(sd, images)
+    txt = orc.encode_text(sd, ids)
+    n = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    ref = n(g["image_features"]) @ n(g["text_features"]).T
+    assert np.abs(n(img.numpy()) @ n(txt.numpy()).T - ref).max() < 5e-5
+    np.testing.assert_allclose(img.numpy(), g["image_features"], rtol=1e-3, atol=1e-3 * np.abs(g["image_features"]).max())
+    ref16 = np.abs(n(g["image_features_fp16"]) @ n(g["text_features_fp16"]).T - ref).max()
+    assert 1e-5 < ref16 < 1e-3
+
+
 def test_ece_cases():
     g = load_golden("ece_cases.npz")
     names = sorted({k.split(":")[0] for k in g})

@@ -30,11 +30,12 @@ with torch.no_grad():
 torch.cuda.synchronize()
 
 CASES = [("in_proj", 0, None), ("out_proj", 2, None), ("c_fc", 3, None), ("c_proj", 4, None),
-         ("in_proj persistent", 0, 11), ("c_fc persistent", 3, 11)]
+         ("in_proj persistent", 0, 11), ("c_fc persistent", 3, 11), ("in_proj stream", 0, 13), ("c_fc stream", 3, 13)]
 if os.environ.get("CASES"):
     CASES = [c for c in CASES if c[0] in os.environ["CASES"].split(",")]
 for name, step, variant in CASES:
     _lib.set_option("gemm_variant", -1 if variant is None else variant)
+    _lib.set_option("gemm_stream", 0 if variant is None else 1)
     stamps = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
     model.profile_block_ms(B, iters=2, only=step)
     _lib.lib.clipmi_tuning_set_stamps(stamps.data_ptr())
@@ -46,7 +47,7 @@ for name, step, variant in CASES:
     t = (s[:, :5] - s[:, 0].min()) / 100.0      # 100 MHz -> microseconds
     order = np.argsort(t[:, 0])
     t = t[order]
-    if variant == 11:   # persistent: stamps are per tile (virtual block id); column 5 = physical workgroup
+    if variant in (11, 13):   # persistent: stamps are per tile (virtual block id); column 5 = physical workgroup
         wg = s[order][:, 5]
         pro, main, epi_i = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
         per_wg = {}

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of `bench.py` -> profiles/gemm_traffic.json (stdout).
+
+Per image-tower GEMM kernel (in_proj, out_proj, c_fc, c_proj at batch 256): mean FETCH_SIZE and WRITE_SIZE (KB) per
+dispatch, HBM-side traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 counts a 128-B read request as 64 B for wide coalesced
+streams: MI355X_MICROARCH.md, HBM section; WRITE_SIZE is exact for 16-B stores), the algorithmic bytes, and the sha256 of
+the gemm.hip the numbers belong to.  out_proj and c_proj run the same kernel instantiation: they alternate in dispatch
+order (out_proj first in every layer)."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+M, D = 256 * 197, 768
+SHAPES = {"in_proj": (M, 3 * D, D), "out_proj": (M, D, D), "c_fc": (M, 4 * D, D), "c_proj": (M, D, 4 * D)}
+
+
+def rows(directory):
+    out = []
+    for path in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
+        out += list(csv.DictReader(open(path)))
+    out.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return out
+
+
+def classify(rs):
+    """Kernel_Name -> role, from the template arguments gemm_f16_kernel<Tile<..>, EPI, OUT_F32> (EPI 1 bias = in-proj,
+    2 QuickGELU = c_fc, 101 / 102 residual fold = out-proj and c_proj alternating)."""
+    per = defaultdict(list)
+    alt = defaultdict(int)
+    for r in rs:
+        name = r["Kernel_Name"]
+        if "gemm_f16_kernel" not in name and "gemm_" not in name:
+            continue
+        grid = int(r.get("Grid_Size", 0) or 0)
+        args = name.split(">,")[-1] if ">," in name else ""
+        epi = args.split(",")[0].strip() if args else ""
+        if epi == "1" and grid >= 256 * 1000:
+            per["in_proj"].append(float(r["Counter_Value"]))
+        elif epi == "2":
+            per["c_fc"].append(float(r["Counter_Value"]))
+        elif epi in ("101", "102"):
+            role = "out_proj" if alt[name] % 2 == 0 else "c_proj"
+            alt[name] += 1
+            per[role].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    fetch, write = classify(rows(sys.argv[1])), classify(rows(sys.argv[2]))
+    sha = hashlib.sha256(open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    kernels = {}
+    for role, (m, n, k) in SHAPES.items():
+        if not fetch.get(role) or not write.get(role):
+            continue
+        f = sum(fetch[role]) / len(fetch[role])
+        w = sum(write[role]) / len(write[role])
+        out_bytes = 2.0 * m * n * (2 if role in ("out_proj", "c_proj") else 1)   # fp16 stream: read + write of the residual tile
+        kernels[role] = {"shape": {"M": m, "N": n, "K": k}, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "dispatches": len(fetch[role]),
+                         "traffic_bytes": (2.0 * f + w) * 1024.0, "algorithmic_bytes": 2.0 * (m * k + n * k) + out_bytes}
+    print(json.dumps({"gemm_hip_sha256": sha,
+                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
+                                "--no-cpu-baseline --no-roofline; tools/measure_traffic.sh",
+                      "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams -> x2; WRITE_SIZE exact for 16-B stores",
+                      "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
