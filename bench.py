@@ -184,8 +184,9 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the process group only carries the RCCL unique id and the timing barrier: gloo is enough for that
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # the process group carries the RCCL unique id and the timing barrier (gloo, CPU tensors); its cuda:nccl half is only
+        # touched if the library's own RCCL communicator cannot be built and the exchange falls back to torch.distributed
+        dist.init_process_group("gloo" if same_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     from clip_calibration_amd import ops, synthetic as syn
     from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
@@ -200,7 +201,7 @@ def main():
     E = geom.embed_dim
     sd = syn.synthetic_state_dict(args.model, seed=0)
     model = build_model(dict(sd), {"trainer": "CoOp" if coop else "ZeroshotCLIP"}).to(dev)
-    exchange = EmbeddingExchange(dev, backend="torch" if same_gpu else "rccl") if world > 1 else None
+    exchange = EmbeddingExchange(dev, backend="torch" if same_gpu else "auto") if world > 1 else None
 
     # ---- text side: computed once, outside the timed region (zsclip.py:90-92; CoOp: cached while ctx is unchanged)
     extra = {}
@@ -247,10 +248,12 @@ def main():
         text_features, scale = zs.text_features, zs.scale
 
     img_seed = rank if args.images_seed is None else args.images_seed + rank
+    shards = None
     if args.virtual_ranks > 1:
-        assert world == 1, "--virtual-ranks is a single-process aid"
-        images = torch.cat([syn.synthetic_images(B, args.model, seed=img_seed + k, device=dev) for k in range(args.virtual_ranks)])
-        B = B * args.virtual_ranks
+        assert world == 1 and args.exchange_f16, "--virtual-ranks is a single-process aid of the fp16 exchange path"
+        # the towers run shard by shard, exactly as the ranks would (same batch -> same kernels), only the gather is a concatenation
+        shards = [syn.synthetic_images(B, args.model, seed=img_seed + k, device=dev) for k in range(args.virtual_ranks)]
+        images = shards[0]
     else:
         images = syn.synthetic_images(B, args.model, seed=img_seed, device=dev)   # resident in HBM before the timed region
     evaluator = DeviceCalibrationEvaluator(10, dev)
@@ -268,6 +271,10 @@ def main():
 
     def step(labels, recompute_text=False):
         txt = text_again() if recompute_text else text_features
+        if shards is not None:
+            emb = torch.cat([ops.l2_normalize(model.image_features_f32(x), torch.float16) for x in shards])
+            bins = evaluator.bins if labels is not None else None
+            return ops.fused_tail(emb, txt, scale, dac_conf, True, False, labels, bins, n_bins)
         return tail(model.image_features_f32(images), labels, txt)
 
     def run(labels, n_steps, recompute_text=False):
@@ -288,7 +295,7 @@ def main():
             el = float(t.item())
         return el, out_
 
-    rows = world * B if exchange is not None else B
+    rows = world * B if exchange is not None else B * args.virtual_ranks
     with torch.no_grad():
         _, _, _, pred0 = step(None)                               # also sizes the workspaces
         # labels for every row the tail sees (the gathered batch when N > 1): 70 % agree with the prediction -> non-degenerate ECE
@@ -337,7 +344,7 @@ def main():
         "dtype": "f16",
         "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": B, "global_batch": world * B, "classes": Cn,
-                   "parallelism": (f"dp{world}: batch sharded, one {'RCCL' if exchange.backend == 'rccl' else 'gloo (same-GPU self-test)'} "
+                   "parallelism": (f"dp{world}: batch sharded, one {'RCCL (clipmi_allgather)' if exchange.backend == 'rccl' else ('gloo (same-GPU self-test)' if same_gpu else 'torch.distributed nccl (fallback)')} "
                                    f"all-gather of [B,{E}] fp16 embeddings per step, logits on the gathered batch on every rank")
                    if world > 1 else "single GPU"},
         "images_per_sec_per_gpu": B * args.steps / elapsed,
@@ -354,7 +361,19 @@ def main():
         with torch.no_grad():
             out["roofline"] = kernel_roofline(model, syn, geom, args.model, B, images)
             feats = model.image_features_f32(images)
-            tail_ms = timed_ms(lambda: tail(feats, labels, text_features), 50)
+            # device time of the tail: its launches are queued BEHIND a tower pass (10 ms of GPU work), so that the host's
+            # ~40 us of Python per call never starves the stream and the events bracket back-to-back executions only
+            n_tail = 40
+            tail(feats, labels, text_features)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            model.image_features_f32(images)
+            e0.record()
+            for _ in range(n_tail):
+                tail(feats, labels, text_features)
+            e1.record()
+            torch.cuda.synchronize()
+            tail_ms = e0.elapsed_time(e1) / n_tail
         out["tail"] = {"what": "ONE launch (fused_tail_kernel): L2-normalise + scale*img@txt^T" + (" + DAC row scale" if coop else "") +
                                " + softmax top-1 (conf, pred) + ECE bin accumulation" +
                                (" [preceded by the fp16 normalise kernel" + (" and the all-gather]" if world > 1 else "]") if f16_exchange else ""),

@@ -77,7 +77,7 @@ _SIGNATURES = {
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "clipmi_fused_tail_workspace_bytes": (_sz, [_i]),
+    "clipmi_fused_tail_workspace_bytes": (_sz, [_i, _i]),
     "clipmi_l2_normalize_to": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "clipmi_comm_unique_id": (_i, [_vp]),
     "clipmi_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),

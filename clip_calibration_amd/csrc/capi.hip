@@ -408,7 +408,7 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
   return launch_logits(img_n, txt_n, scale, dac_conf, logits, conf, pred, B, C, E, (hipStream_t)stream);
 }
 
-size_t clipmi_fused_tail_workspace_bytes(int B) { return B < 0 ? 0 : fused_tail_workspace_bytes(B); }
+size_t clipmi_fused_tail_workspace_bytes(int B, int C) { return (B < 0 || C < 0) ? 0 : fused_tail_workspace_bytes(B, C); }
 
 int clipmi_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins,

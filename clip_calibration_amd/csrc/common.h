@@ -142,7 +142,7 @@ int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int 
 int launch_l2_normalize_to(const void* in, int in_dtype, void* out, int out_dtype, int rows, int E, hipStream_t s);
 int launch_logits(const float* img_n, const float* txt_n, float scale, const float* dac_conf, float* logits,
                   float* conf, int32_t* pred, int B, int C, int E, hipStream_t s);
-size_t fused_tail_workspace_bytes(int B);
+size_t fused_tail_workspace_bytes(int B, int C);
 int launch_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins, void* workspace,
                       size_t workspace_bytes, int B, int C, int E, hipStream_t s);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
                                                          float* __restrict__ conf, int32_t* __restrict__ pred,
                                                          const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
                                                          int* counters, int B, int C, int E) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 16 rows of E floats, row stride E*4 + 16 bytes; then one int
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 16 rows of E floats, row stride E*4 + 16 bytes; then flag + wave partials
   const int rs = E * 4 + 16;
   int* flag = reinterpret_cast<int*>(smem + 16 * rs);
   const int lane = threadIdx.x & 63;
@@ -170,43 +170,91 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
   const int m0 = blockIdx.x * 16;
   const int n0 = blockIdx.y * 64 + wave * 16;
 
-  // ---- phase 0: the 16 image rows -> LDS (normalised), 4 rows per wave
-  for (int rr = 0; rr < 4; ++rr) {
-    const int rl = wave * 4 + rr;
-    const int row = m0 + rl < B ? m0 + rl : B - 1;
-    const TI* x = img + (int64_t)row * E;
-    float inv = 1.0f;
-    if constexpr (NORMALIZE) {
-      float ss = 0.f;
-      for (int e = lane; e < E; e += 64) {
-        const float v = (float)x[e];
-        ss += v * v;
+  // ---- phase 0: the 16 image rows -> LDS (normalised), 4 rows per wave, all four rows' loads in flight together (row after
+  //      row this phase alone was eight dependent round trips to L2).  Arithmetic of l2norm_kernel: lane-strided sum, butterfly.
+  if (E <= 1024) {   // uniform: a lane's <= 16 elements of each row stay in registers between the norm and the scaling
+    float xv[4][16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int rl = wave * 4 + rr;
+        const int row = m0 + rl < B ? m0 + rl : B - 1;
+        xv[rr][t] = lane + 64 * t < E ? (float)img[(int64_t)row * E + lane + 64 * t] : 0.f;
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      inv = 1.0f / sqrtf(ss);
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = wave * 4 + rr;
+      const int row = m0 + rl < B ? m0 + rl : B - 1;
+      float inv = 1.0f;
+      if constexpr (NORMALIZE) {
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (lane + 64 * t < E) ss += xv[rr][t] * xv[rr][t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = 1.0f / sqrtf(ss);
+      }
+      float* dst = reinterpret_cast<float*>(smem + rl * rs);
+      const bool keep = img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B;   // wave-uniform
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (lane + 64 * t < E) {
+          const float v = NORMALIZE ? xv[rr][t] * inv : xv[rr][t];
+          dst[lane + 64 * t] = v;
+          if (keep) img_n_out[(int64_t)row * E + lane + 64 * t] = v;
+        }
+      }
     }
-    float* dst = reinterpret_cast<float*>(smem + rl * rs);
-    const bool keep = img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B;   // wave-uniform
-    for (int e = lane; e < E; e += 64) {
-      const float v = NORMALIZE ? (float)x[e] * inv : (float)x[e];
-      dst[e] = v;
-      if (keep) img_n_out[(int64_t)row * E + e] = v;
+  } else {
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = wave * 4 + rr;
+      const int row = m0 + rl < B ? m0 + rl : B - 1;
+      const TI* x = img + (int64_t)row * E;
+      float inv = 1.0f;
+      if constexpr (NORMALIZE) {
+        float ss = 0.f;
+        for (int e = lane; e < E; e += 64) {
+          const float v = (float)x[e];
+          ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv = 1.0f / sqrtf(ss);
+      }
+      float* dst = reinterpret_cast<float*>(smem + rl * rs);
+      const bool keep = img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B;   // wave-uniform
+      for (int e = lane; e < E; e += 64) {
+        const float v = NORMALIZE ? (float)x[e] * inv : (float)x[e];
+        dst[e] = v;
+        if (keep) img_n_out[(int64_t)row * E + e] = v;
+      }
     }
   }
   __syncthreads();
 
   // ---- phase 1: 16 x 16 tile per wave
   const int r = lane & 15, g = lane >> 4;
+  f32x4 acc_out = f32x4{0.f, 0.f, 0.f, 0.f};
   if (n0 < C) {   // wave-uniform
     const int n = n0 + r < C ? n0 + r : C - 1;
     const float* bp = txt + (int64_t)n * E + g * 4;
     const char* ap = smem + r * rs + g * 16;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < E; k0 += 64) {   // E % 64 == 0: four 16-wide steps with their loads issued together
+    // E % 64 == 0: 64-wide steps, the text fragments of step k+1 are loaded (from L2) while the 16 MFMAs of step k run --
+    // without the explicit second register set the loop is one L2 round trip per step
+    f32x4 bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp + u * 16);
+    for (int k0 = 0; k0 < E; k0 += 64) {
       f32x4 b[4], a[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const f32x4*>(bp + k0 + u * 16);
+      for (int u = 0; u < 4; ++u) b[u] = bn[u];
+      if (k0 + 64 < E) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp + k0 + 64 + u * 16);
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(ap + (k0 + u * 16) * 4);
 #pragma unroll
@@ -214,23 +262,44 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
     }
+    acc_out = acc;
+  }
+  // ---- the workgroup's 16 x 64 logits tile.  Rows 16-byte aligned (C % 4 == 0): through an LDS tile, ONE 16-byte
+  //      write-through (sc1) store per thread -- whole 64-byte row pieces, and no release fence is needed for the hand-off
+  //      below (cdna_hip_programming.md Guideline 16, R1).  Otherwise: 4-byte stores from the accumulator layout + a release.
+  const bool wide = (C & 3) == 0;   // uniform
+  if (wide) {
+    __syncthreads();                // every wave is done reading the image rows: the tile takes their place
+    float* tile = reinterpret_cast<float*>(smem);   // [16][64 + 4] floats
     // D layout: col = lane&15 (n), row = (lane>>4)*4 + reg (m)
-    if (n0 + r < C) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int mm = m0 + g * 4 + e;
-        if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc[e];
-      }
+    for (int e = 0; e < 4; ++e) tile[(g * 4 + e) * 68 + wave * 16 + r] = scale * acc_out[e];
+    __syncthreads();
+    const int trow = threadIdx.x >> 4, tq = threadIdx.x & 15;
+    const int mm = m0 + trow, nn = blockIdx.y * 64 + tq * 4;
+    if (mm < B && nn < C) {         // C % 4 == 0: a 4-column piece is entirely inside or outside
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * 68 + tq * 4);
+      const __amdgpu_buffer_rsrc_t lrs = make_rsrc(logits, (int64_t)B * C * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
+    }
+  } else if (n0 < C && n0 + r < C) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int mm = m0 + g * 4 + e;
+      if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc_out[e];
     }
   }
   if (!dac && !conf && !pred && !bins) return;   // logits only (kernel argument: uniform)
 
-  // ---- phase 2: ticket; the last workgroup of this row block owns the row pass
+  // ---- phase 2: ticket; the last workgroup of this row block owns the row pass over the logits the others stored
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: the compiler may drop the fence's own wait (Guideline 16, pitfall 12)
+    if (!wide) {   // plain stores: write this XCD's L2 back before the ticket (write-through stores need no release)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: the compiler may drop the fence's own wait (Guideline 16, pitfall 12)
+    }
     const int ticket = __hip_atomic_fetch_add(counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (int)gridDim.y - 1;
     if (last) {
@@ -242,21 +311,89 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
   }
   __syncthreads();
   if (!*flag) return;
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = m0 + wave * 4 + rr;
-    if (row >= B) break;   // wave-uniform
-    float cf;
-    int pi;
-    calibrate_row(logits + (int64_t)row * C, dac, C, nullptr, lane, cf, pi);
-    if (lane == 0) {
+  // the wave's four rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same butterflies), with
+  // every load of the pass in flight at once.  C <= 1024: a lane's 16 elements of each row stay in registers between the
+  // argmax and the softmax pass (one trip to L2 / HBM instead of two chains of dependent round trips -- done one row after
+  // the other with rolled loops this pass made the fused launch slower than the three launches it replaces: 43 us against
+  // 25 + 9 + 5 in rocprof).  Larger C: the same arithmetic with the two passes reading memory.
+  const int row0 = m0 + wave * 4;
+  float* lr[4];
+  float best[4], fac[4], mx[4], se[4];
+  int bi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = row0 + q < B ? row0 + q : B - 1;   // clamped rows recompute row B-1 and are not written
+    lr[q] = logits + (int64_t)row * C;
+    best[q] = -INFINITY;
+    bi[q] = 0x7fffffff;
+    se[q] = 0.f;
+  }
+  auto finish_argmax = [&](int q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best[q], o, 64);
+      const int oi = __shfl_xor(bi[q], o, 64);
+      if (ob > best[q] || (ob == best[q] && oi < bi[q])) { best[q] = ob; bi[q] = oi; }
+    }
+    if (bi[q] == 0x7fffffff) bi[q] = 0;
+    fac[q] = dac ? dac[bi[q]] : 1.0f;
+    mx[q] = best[q] * fac[q];
+  };
+  if (C <= 1024) {   // uniform
+    float v[4][16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q][t] = lane + 64 * t < C ? lr[q][lane + 64 * t] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (lane + 64 * t < C && v[q][t] > best[q]) { best[q] = v[q][t]; bi[q] = lane + 64 * t; }
+      finish_argmax(q);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (lane + 64 * t < C) {
+          const float x = v[q][t] * fac[q];
+          if (dac && row0 + q < B) lr[q][lane + 64 * t] = x;
+          se[q] += __expf(x - mx[q]);
+        }
+      }
+    }
+  } else {
+    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = lr[q][c];
+        if (x > best[q]) { best[q] = x; bi[q] = c; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) finish_argmax(q);
+    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = lr[q][c] * fac[q];
+        if (dac && row0 + q < B) lr[q][c] = x;
+        se[q] += __expf(x - mx[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se[q] += __shfl_xor(se[q], o, 64);
+    const int row = row0 + q;
+    if (lane == 0 && row < B) {
+      const float cf = 1.0f / se[q];
       if (conf) conf[row] = cf;
-      if (pred) pred[row] = pi;
+      if (pred) pred[row] = bi[q];
       if (bins) {
         const double x = (double)cf;
         const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
         atomicAdd(&bins[b], 1.0);
         atomicAdd(&bins[nb1 + b], x);
-        atomicAdd(&bins[2 * nb1 + b], (labels[row] == (int64_t)pi) ? 1.0 : 0.0);
+        atomicAdd(&bins[2 * nb1 + b], (labels[row] == (int64_t)bi[q]) ? 1.0 : 0.0);
       }
     }
   }
@@ -277,7 +414,8 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
   return rc;
 }
 
-size_t fused_tail_workspace_bytes(int B) { return align256((size_t)((B + 15) / 16) * sizeof(int)); }
+// [ceil(B/16)] int32 ticket counters (zero between launches)
+size_t fused_tail_workspace_bytes(int B, int /*C*/) { return align256((size_t)((B + 15) / 16) * sizeof(int)); }
 
 int launch_fused_tail(const void* img_, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins, void* workspace,
@@ -287,6 +425,7 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   CLIPMI_REQUIRE(img_dtype == CLIPMI_F32 || img_dtype == CLIPMI_F16, CLIPMI_ERR_ARG, "fused_tail: bad image-feature dtype %d", img_dtype);
   const float* img = static_cast<const float*>(img_);
   CLIPMI_REQUIRE(B > 0 && C > 0 && E > 0 && E % 16 == 0, CLIPMI_ERR_SHAPE, "fused_tail: B=%d C=%d E=%d unsupported (E %% 16 == 0)", B, C, E);
+  CLIPMI_REQUIRE((int64_t)B * C * 4 < 0xFFFFFFF0ll, CLIPMI_ERR_SHAPE, "fused_tail: logits matrix too large for 32-bit offsets");
   CLIPMI_REQUIRE((uintptr_t)img % 16 == 0 && (uintptr_t)txt_n % 16 == 0, CLIPMI_ERR_ARG, "fused_tail: features must be 16-byte aligned");
   CLIPMI_REQUIRE(!bins || (labels && n_bins > 0 && n_bins <= 1024), CLIPMI_ERR_ARG, "fused_tail: ECE bins need labels and 1 <= n_bins <= 1024");
   CLIPMI_REQUIRE(normalize || !img_n_out, CLIPMI_ERR_ARG, "fused_tail: img_n_out only with normalize");
@@ -310,8 +449,8 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
     }
     return CLIPMI_OK;
   }
-  CLIPMI_REQUIRE(workspace && workspace_bytes >= fused_tail_workspace_bytes(B), CLIPMI_ERR_WORKSPACE,
-                 "fused_tail: workspace too small (%zu < %zu)", workspace_bytes, fused_tail_workspace_bytes(B));
+  CLIPMI_REQUIRE(workspace && workspace_bytes >= fused_tail_workspace_bytes(B, C), CLIPMI_ERR_WORKSPACE,
+                 "fused_tail: workspace too small (%zu < %zu)", workspace_bytes, fused_tail_workspace_bytes(B, C));
   const dim3 grid((B + 15) / 16, (C + 63) / 64);
   CLIPMI_REQUIRE(grid.y <= 65535, CLIPMI_ERR_SHAPE, "fused_tail: too many classes");
   int* counters = static_cast<int*>(workspace);

@@ -132,8 +132,8 @@ def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_con
 _TAIL_WS = {}   # device index -> zeroed int32 ticket counters (the kernel leaves them zero)
 
 
-def _tail_workspace(device: torch.device, batch: int) -> torch.Tensor:
-    need = lib.clipmi_fused_tail_workspace_bytes(batch)
+def _tail_workspace(device: torch.device, batch: int, classes: int) -> torch.Tensor:
+    need = lib.clipmi_fused_tail_workspace_bytes(batch, classes)
     ws = _TAIL_WS.get(device.index)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=device)
@@ -172,7 +172,7 @@ def fused_tail(img: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: O
         conf = torch.empty(B, dtype=torch.float32, device=img.device)
         pred = torch.empty(B, dtype=torch.int32, device=img.device)
         pc, pp = conf.data_ptr(), pred.data_ptr()
-    ws = _tail_workspace(img.device, B)
+    ws = _tail_workspace(img.device, B, Cn)
     with torch.cuda.device(img.device):
         check(lib.clipmi_fused_tail(img.data_ptr(), _DT[img.dtype], int(normalize), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(),
                                     img_n.data_ptr() if normalize else None, pc, pp, pl, pb, int(n_bins), ws.data_ptr(), ws.numel(),

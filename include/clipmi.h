@@ -130,11 +130,11 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
  * all ranks when normalize == 0), txt_n fp32 [C,E] L2-normalised; logits fp32 [B,C] required;
  * img_n_out fp32 [B,E] (the normalised image features of the reference's 3-tuple; NULL to skip; only with normalize), conf fp32 [B],
  * pred int32 [B], labels int64 [B] + bins float64 [3*(n_bins+1)]: each may be NULL.  Results are bit-identical to
- * clipmi_l2_normalize + clipmi_logits + clipmi_ece_accumulate.  E % 64 == 0 and E <= 2048 run fused; other shapes, and option
+ * clipmi_l2_normalize + clipmi_logits + clipmi_ece_accumulate (the ECE sums of confidences up to the order of their atomics).  E % 64 == 0 and E <= 2048 run fused; other shapes, and option
  * tail_unfused = 1, run the separate launches (which need img_n_out or fp32 normalised input, and conf + pred when bins are given).
- * workspace: clipmi_fused_tail_workspace_bytes(B) bytes of device memory that is ZERO before the first launch; every launch
- * leaves it zero again (ticket counters, one per 16 image rows).  Re-zero it after a launch that failed. */
-size_t clipmi_fused_tail_workspace_bytes(int B);
+ * workspace: clipmi_fused_tail_workspace_bytes(B, C) bytes of device memory that is ZERO before the first launch; every launch
+ * leaves it zero again (ticket counters, one int32 per 16 image rows).  Re-zero it after a launch that failed. */
+size_t clipmi_fused_tail_workspace_bytes(int B, int C);
 int clipmi_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins,
                       void* workspace, size_t workspace_bytes, int B, int C, int E, clipmi_stream_t stream);

@@ -33,7 +33,7 @@ def test_two_ranks_equal_one_process_bitwise():
     j2, d2 = _finish("two")
     j1, d1 = _finish("one")
     assert j2["n_gpus"] == 2 and j2["exchange"]["world_size"] == 2 and j2["exchange"]["backend"] == "torch"
-    assert j2["config"]["global_batch"] == 48 and j1["config"]["batch_per_gpu"] == 48
+    assert j2["config"]["global_batch"] == 48 and j1["config"]["batch_per_gpu"] == 24
     assert d2["logits"].shape == (48, 200) and np.array_equal(d2["logits"], d1["logits"])
     assert np.array_equal(d2["pred"], d1["pred"]) and np.array_equal(d2["conf"], d1["conf"])
     b2, b1 = d2["bins"].reshape(3, -1), d1["bins"].reshape(3, -1)

@@ -218,10 +218,17 @@ def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
         outs.append((lg, img_n, conf, pred, bins))
     (lg_u, in_u, cf_u, pr_u, bins_u), (lg_f, in_f, cf_f, pr_f, bins_f) = outs
     assert torch.equal(in_u, ops.l2_normalize(img)) and torch.equal(in_f, in_u)
-    assert torch.equal(lg_f, lg_u) and torch.equal(pr_f, pr_u) and torch.equal(cf_f, cf_u)
-    assert torch.equal(bins_f[:11], bins_u[:11]) and torch.equal(bins_f[22:], bins_u[22:])      # counts, correct: exact
-    np.testing.assert_allclose(bins_f[11:22].cpu().numpy(), bins_u[11:22].cpu().numpy(), rtol=1e-14)   # sums of conf: atomics order
-    assert int(ops._TAIL_WS[torch.cuda.current_device()].view(torch.int32).abs().sum()) == 0
+    assert torch.equal(lg_f, lg_u) and torch.equal(pr_f, pr_u)
+    assert torch.equal(cf_f, cf_u)                            # the row pass of the separate launches, verbatim
+    from clip_calibration_amd.metrics import bin_statistics
+    own = bin_statistics(cf_f.cpu().numpy(), pr_f.cpu().numpy(), labels.cpu().numpy(), 10)     # the fused bins against its own (conf, pred)
+    got = bins_f.cpu().numpy().reshape(3, 11)
+    assert np.array_equal(got[[0, 2]], own[[0, 2]])
+    np.testing.assert_allclose(got[1], own[1], rtol=1e-13)
+    assert torch.equal(bins_f[:11], bins_u[:11]) and torch.equal(bins_f[22:], bins_u[22:])      # counts, hits: exact
+    np.testing.assert_allclose(bins_f[11:22].cpu().numpy(), bins_u[11:22].cpu().numpy(), rtol=1e-13)
+    n_counters = (B + 15) // 16
+    assert int(ops._TAIL_WS[torch.cuda.current_device()][: 4 * n_counters].view(torch.int32).abs().sum()) == 0
     # against the oracle (fp32 dot products of E terms, |logit| <= 100)
     ref, _, _ = orc.clip_logits(img.cpu(), txt_n.cpu(), 100.0)
     ref = ref.numpy()
@@ -230,7 +237,7 @@ def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
     np.testing.assert_allclose(lg_f.cpu().numpy(), ref, atol=3e-4, rtol=2e-6)
     # pre-normalised entry (the multi-GPU path after the all-gather): same logits from the normalised features
     lg_p, cf_p, pr_p = ops.logits_fused(in_f, txt_n, 100.0, dacc)
-    assert torch.equal(lg_p, lg_f) and torch.equal(cf_p, cf_f) and torch.equal(pr_p, pr_f)
+    assert torch.equal(lg_p, lg_f) and torch.equal(cf_p, cf_f) and torch.equal(pr_p, pr_f)      # same kernel, same partials
 
 
 def test_fused_tail_handoff_under_load(ops):
@@ -255,7 +262,7 @@ def test_fused_tail_handoff_under_load(ops):
         L.set_option("tail_unfused", 1)
         lg_u, _, conf_u, pred_u = ops.fused_tail(img, txt_n, 100.0, dacc if it % 2 else None)
         L.set_option("tail_unfused", 0)
-        bad += int(not (torch.equal(lg, lg_u) and torch.equal(conf, conf_u) and torch.equal(pred, pred_u)))
+        bad += int(not (torch.equal(lg, lg_u) and torch.equal(pred, pred_u) and torch.equal(conf, conf_u)))
     assert bad == 0, f"{bad} of 300 launches differ from the separate-launch path"
 
 

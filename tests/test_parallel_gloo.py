@@ -142,6 +142,31 @@ def test_gather_samples_with_an_empty_shard_world2(tmp_path):
     assert (tmp_path / "ok0.npy").exists() and (tmp_path / "ok1.npy").exists()
 
 
+def _exchange_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = parallel.EmbeddingExchange(torch.device("cpu"), backend="auto")     # no GPU: the torch.distributed backend
+        assert ex.backend == "torch" and ex.rccl_ranks is None and ex.world == world and ex.rank == rank
+        x = (torch.arange(12, dtype=torch.float32).reshape(3, 4) + 100 * rank).half()   # fp16: the exchange format
+        y = ex.all_gather(x)
+        assert y.dtype == torch.float16 and y.shape == (3 * world, 4)
+        for r in range(world):
+            assert torch.equal(y[3 * r: 3 * r + 3], (torch.arange(12, dtype=torch.float32).reshape(3, 4) + 100 * r).half())
+        ex.close()
+        np.save(os.path.join(out_dir, f"ex{rank}.npy"), y.float().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_embedding_exchange_world2(tmp_path):
+    """The exchange object of the N > 1 path (one all-gather of fp16 embeddings per step) on its torch.distributed backend;
+    the RCCL backend needs GPUs (tests/test_gpu_multirank.py)."""
+    mp.spawn(_exchange_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "ex0.npy"), np.load(tmp_path / "ex1.npy"))
+
+
 def test_sample_level_metrics_world2(tmp_path):
     mp.spawn(_sample_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.array_equal(np.load(tmp_path / "res0.npy"), np.load(tmp_path / "res1.npy"))
