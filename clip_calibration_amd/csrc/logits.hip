@@ -311,6 +311,14 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
   }
   __syncthreads();
   if (!*flag) return;
+  // ECE bins of this row block: summed in LDS first (the image-row region is free by now), then at most 3 * (n_bins + 1)
+  // global atomics per row block -- one set of three per ROW on a dozen hot addresses serialised the whole grid
+  // (B = 2048: 41 us of the launch).
+  double* sbins = reinterpret_cast<double*>(smem + 8192);
+  if (bins) {
+    for (int t = threadIdx.x; t < 3 * (n_bins + 1); t += 256) sbins[t] = 0.0;
+    __syncthreads();
+  }
   // the wave's four rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same butterflies), with
   // every load of the pass in flight at once.  C <= 1024: a lane's 16 elements of each row stay in registers between the
   // argmax and the softmax pass (one trip to L2 / HBM instead of two chains of dependent round trips -- done one row after
@@ -391,11 +399,16 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
       if (bins) {
         const double x = (double)cf;
         const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
-        atomicAdd(&bins[b], 1.0);
-        atomicAdd(&bins[nb1 + b], x);
-        atomicAdd(&bins[2 * nb1 + b], (labels[row] == (int64_t)bi[q]) ? 1.0 : 0.0);
+        atomicAdd(&sbins[b], 1.0);
+        atomicAdd(&sbins[nb1 + b], x);
+        atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)bi[q]) ? 1.0 : 0.0);
       }
     }
+  }
+  if (bins) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * (n_bins + 1); t += 256)
+      if (sbins[t] != 0.0) atomicAdd(&bins[t], sbins[t]);
   }
 }
 
@@ -430,7 +443,7 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   CLIPMI_REQUIRE(!bins || (labels && n_bins > 0 && n_bins <= 1024), CLIPMI_ERR_ARG, "fused_tail: ECE bins need labels and 1 <= n_bins <= 1024");
   CLIPMI_REQUIRE(normalize || !img_n_out, CLIPMI_ERR_ARG, "fused_tail: img_n_out only with normalize");
   const int lds = 16 * (E * 4 + 16) + 16;
-  const bool fits = E % 64 == 0 && lds <= 160 * 1024;
+  const bool fits = E % 64 == 0 && lds <= 160 * 1024 && (!bins || 8192 + 3 * (n_bins + 1) * 8 <= 16 * (E * 4 + 16));
   if (options().tail_unfused.load(std::memory_order_relaxed) == 1 || !fits) {
     // the same arithmetic as separate launches (A/B aid; also shapes the fused kernel does not take)
     int rc;
