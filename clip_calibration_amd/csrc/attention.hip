@@ -13,6 +13,8 @@
 //   O^T tile += V^T(32 d x 16 keys) * P^T             the S^T accumulators, packed to fp16, ARE the B operand
 //                                                     (cdna_hip_programming.md §3 "accumulator tile as the next
 //                                                     MFMA's operand"); A = V^T via transposed LDS reads
+#include <type_traits>
+
 #include "common.h"
 
 namespace clipmi {
@@ -346,6 +348,191 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Vision kernel (non-causal, 193 <= L <= 200: ViT-B/16 and B/32-style towers at 224 px, 197 tokens, 199 with MaPLe's
+// prompts): the persistent kernel above with EVERY operand of the next item -- K, V and now Q too -- brought in by
+// LDS-DMA from dedicated loader wave(s), so that a query wave's instruction stream holds no VMEM load at all.
+//
+// Why (tools/attn_stamps.py + the ISA, round 2): in the kernel above a query wave issues its share of the K/V prefetch and
+// its own next Q fragments right after the item's barrier, and hipcc then waits for them at once -- it copies the freshly
+// loaded Q registers into their home registers behind an s_waitcnt vmcnt(0), and because VMEM retires in order that wait
+// also covers the K/V DMA issued just before.  Every item therefore paid the whole load latency (1.3-1.9 us of a 5.7 us
+// item) in front of its first MFMA: nothing was prefetched.  With no VMEM load left in the query waves there is nothing
+// for the compiler to wait on (stores need no wait, raw s_barrier), and the loaders run a whole item ahead.  (Query waves
+// that issue LDS-DMA themselves do not work either: hipcc puts an s_waitcnt vmcnt(0) in front of the ds_read_b64_tr_b16
+// of the P.V product -- the builtin carries no address-space-precise memory operand, so it may alias the pending DMA.)
+//
+// LDS (dynamic, zeroed once): 2 buffers x (K | V | Q) x 200 rows x 128 B = 153,600 B + 3 KiB tail pad.  The seventh key /
+// query tile spans rows 192-223; rows 200-223 of an array fall into the NEXT array (always finite data: rows at or beyond
+// L lie outside the DMA descriptor and read as zero, the tail pad is zero): keys >= L are masked in the scores, their
+// P = 0 annihilates whatever V row is read, and queries >= L are never stored.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int VROWS = 200;
+constexpr int VARR = VROWS * 128;            // one operand image
+constexpr int VBUF = 3 * VARR;               // K | V | Q
+constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of the last array
+
+template <int NLOAD, int PRIO, int GROUP = 4>
+__global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
+                                                                                               int L, int H, int n_items
+#ifdef CLIPMI_TUNING
+                                                                                               , long long* stamps   // diagnostic build: [item][query wave 0 | loader][8]
+#endif
+                                                                                               ) {
+  constexpr int NKT = 7, NT = 448 + 64 * NLOAD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..6 query waves, 7.. loader waves
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int D = H * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  for (int i = tid * 16; i < VSMEM; i += NT * 16) *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+
+  if (wave >= 7) {
+    // ---- loader wave(s): ALL DMA of item (i + 1) while the query waves work on item i -- 25 groups of 8 rows x 128 B per
+    // operand, loader j takes the groups g = j (mod NLOAD).  Per-lane source offsets are precomputed (a group's swizzle
+    // depends on its parity only), so a DMA costs one v_add + the M0 update + the instruction itself.
+    if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+    const int lr = lane >> 3, cs = lane & 7;
+    const int swv = (cs ^ (((lr >> 1) & 1) << 2)) << 4;                                        // V: chunk ^ (((row >> 1) & 1) << 2)
+    const int swk[2] = {(cs ^ (lr >> 1)) << 4, (cs ^ (4 + (lr >> 1))) << 4};                    // K, Q: chunk ^ ((row >> 1) & 7), by group parity
+    const int lane_row = lr * (int)ld * 2;
+    const int gstep = 8 * (int)ld * 2;                                                          // one group further
+    auto radd = [](int base, int add) {
+      int r;
+      asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+      return r;
+    };
+    auto stage = [&](auto jtag, int it_, int buf) {   // J = which loader this is: every group index below is a constant
+      constexpr int J = decltype(jtag)::value;
+      const int n = it_ / H, h = it_ - n * H;
+      const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);   // rows >= L: outside, read as zero
+      char* B = smem + buf * VBUF;
+#pragma unroll
+      for (int g = J; g < VROWS / 8; g += NLOAD) {
+        const int kq = lane_row + swk[g & 1];
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + g * 1024, radd(kq + D * 2, g * gstep), 0);                        // K
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + VARR + g * 1024, radd(lane_row + swv + 2 * D * 2, g * gstep), 0);  // V
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
+      }
+    };
+    auto run = [&](auto jtag) {
+      stage(jtag, item, 0);
+      int buf = 0;
+      for (; item < n_items; item += gridDim.x, buf ^= 1) {
+#ifdef CLIPMI_TUNING
+        const bool stamp = stamps != nullptr && lane == 0 && wave == 7;
+        long long* sp = stamps + ((size_t)item * 2 + 1) * 8;
+        if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's operands have landed
+#ifdef CLIPMI_TUNING
+        if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+        __builtin_amdgcn_s_barrier();                       // ... and every query wave is done with the other buffer
+#ifdef CLIPMI_TUNING
+        if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+        const int next = item + gridDim.x;
+        if (next < n_items) stage(jtag, next, buf ^ 1);
+#ifdef CLIPMI_TUNING
+        if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+      }
+    };
+    if (NLOAD == 1 || wave == 7) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, NLOAD - 1>{});
+    return;
+  }
+
+  // ---- query waves: no VMEM load in their instruction stream
+  const int q0 = wave * 32;
+  const int q = q0 + r32;
+  const int kswz = (r32 >> 1) & 7;
+  int kro[4], vro[2], qro[4];   // lane-constant byte offsets inside a buffer
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+    qro[ks] = 2 * VARR + (q0 + r32) * 128 + (((2 * ks + hh) ^ kswz) << 4);   // (q0 >> 1) & 7 == 0: the swizzle of row q is kswz
+  }
+  {
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int fq = (qq >> 1) & 1;
+    const int lane_base = VARR + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+    vro[0] = lane_base + fq * 64;
+    vro[1] = lane_base + (1 - fq) * 64;
+  }
+  int buf = 0;
+  for (; item < n_items; item += gridDim.x, buf ^= 1) {
+#ifdef CLIPMI_TUNING
+    const bool stamp = stamps != nullptr && lane == 0 && wave == 0;
+    long long* sp = stamps + ((size_t)item * 2) * 8;
+    if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    __builtin_amdgcn_s_barrier();   // the loaders' vmcnt(0) came first: this item's K / V / Q are in LDS
+#ifdef CLIPMI_TUNING
+    if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    const char* b = smem + buf * VBUF;
+    const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
+    const char* const vread[2] = {b + vro[0], b + vro[1]};
+    f16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(b + qro[ks]);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+    float m_run = NEG_BIG;
+    f32x16 lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    attend_block<NKT, GROUP, true, 1>(kread, vread, qf, 0, L, 0, q0, q, hh, m_run, oacc, lacc);
+#ifdef CLIPMI_TUNING
+    asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[1][15]), "v"(lacc[0]));
+    if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    if (q < L) {
+      const int n = item / H, h = item - n * H;
+      store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
+    }
+#ifdef CLIPMI_TUNING
+    if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  }
+}
+
+template <int NLOAD, int PRIO, int GROUP = 4>
+int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
+  static DeviceOnce attr_once;
+  auto fn = attention_vision_kernel<NLOAD, PRIO, GROUP>;
+  ensure_dynamic_lds(fn, VSMEM, attr_once);
+  const int n_cu = device_cus();
+  const int n_items = N * H;
+  const int grid = n_items < n_cu ? n_items : n_cu;
+#ifdef CLIPMI_TUNING
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(448 + 64 * NLOAD), VSMEM, s, qkv, out, L, H, n_items, g_tuning_stamps.load(std::memory_order_relaxed));
+#else
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(448 + 64 * NLOAD), VSMEM, s, qkv, out, L, H, n_items);   // 7 query waves + the loaders
+#endif
+  return check_launch("attention_vision_kernel");
+}
+
+// mode 1 (default): one loader wave; 2: two loader waves (A/B aid).  Measured on MI355X, B = 256 (tools/block_ab2.py): persistent
+// kernel without loaders 81-83 us, one loader 74-78 us, two loaders 78 us (74 with raised priority), one loader with all seven key
+// tiles in one softmax group 79.5 us, groups of two 80.3 us.
+int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, int mode, hipStream_t s) {
+  if (mode == 2) return launch_vision_t<2, 0>(qkv, out, N, L, H, s);
+  return launch_vision_t<1, 0>(qkv, out, N, L, H, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Streaming variant for sequences longer than one key block (ViT-L/14: 257 tokens, ViT-L/14@336: 577): the key
 // blocks (NKT*32 keys) of one (sequence, head) pass through a TWO-slot LDS ring -- block kb+1 is DMA'd while block kb
 // is computed, so the staging latency that the single-buffer kernel above pays once per block (load -> wait ->
@@ -494,7 +681,12 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
       return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);
     }
     if (L <= 224) {
-      if (!causal && L > 192) return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
+      if (!causal && L > 192) {
+        // 193..200 tokens: every operand by DMA from a loader wave (attention_vision_kernel); wider rows do not fit the LDS
+        const int lm = options().attn_loader.load(std::memory_order_relaxed);   // 1: one loader wave (default), 2: two
+        if (L <= VROWS && lm >= 1) return launch_vision(qkv, out, N, L, H, lm, s);
+        return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
+      }
       return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
     }
     // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks 73 us against 81 us for the single-buffer kernel;

@@ -45,6 +45,7 @@ const OptionDesc kOptions[] = {
     {"attn_no_persist", "CLIPMI_ATTN_NO_PERSIST", &Options::attn_no_persist},
     {"attn_no_stream", "CLIPMI_ATTN_NO_STREAM", &Options::attn_no_stream},
     {"attn_stagger", "CLIPMI_ATTN_STAGGER", &Options::attn_stagger},
+    {"attn_loader", "CLIPMI_ATTN_LOADER", &Options::attn_loader},
     {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
 };
 

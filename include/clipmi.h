@@ -70,7 +70,9 @@ const char* clipmi_last_error(void);
  *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
  *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
  *                                             (default; env 'v'), 3 = text tower only (env 't')
- *   attn_no_tr / attn_no_persist / attn_no_stream / attn_stagger   (CLIPMI_ATTN_*)  attention kernel selection
+ *   attn_no_tr / attn_no_persist / attn_no_stream / attn_stagger / attn_loader   (CLIPMI_ATTN_*)  attention kernel selection
+ *                                             (attn_loader = 1, default: 193..200-token non-causal attention runs the kernel whose operands all
+ *                                             arrive by LDS-DMA from a dedicated loader wave; 2 = two loader waves; 0 = the persistent kernel)
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits as three launches instead of the fused tail kernel */
 int clipmi_set_option(const char* name, int value);
 int clipmi_get_option(const char* name, int* value);

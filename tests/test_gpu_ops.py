@@ -133,6 +133,24 @@ def test_attention(ops, n, l, h, causal, tr, clipmi_option):
     assert err < 4e-3, f"max err {err}"
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,l,h", [(3, 197, 12), (2, 199, 12), (1, 193, 2), (5, 200, 1), (40, 197, 12)])
+def test_attention_vision_loader_modes(ops, clipmi_option, mode, n, l, h):
+    """193..200-token non-causal attention (the image towers at 224 px; clip/model.py:181-183): the persistent kernel
+    (attn_loader 0) and the all-DMA kernel with one / two loader waves give the SAME bits -- only the operand transport differs --
+    and match the fp32 reference.  40 sequences x 12 heads = several items per workgroup (both LDS buffers in use)."""
+    clipmi_option("attn_loader", mode)
+    g = torch.Generator().manual_seed(n * 1000 + l + h)
+    qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
+    got = ops.attention(_cuda(qkv), n, l, h, False)
+    clipmi_option("attn_loader", 0)
+    base = ops.attention(_cuda(qkv), n, l, h, False)
+    assert torch.equal(got, base)
+    ref = _attn_ref(qkv[: 2 * l], 2 if n >= 2 else 1, l, h, False) if n >= 2 else _attn_ref(qkv, n, l, h, False)
+    err = (got[: ref.shape[0]].float().cpu() - ref).abs().max().item()
+    assert err < 4e-3, f"max err {err}"
+
+
 def test_attention_peaked_rows(ops):
     """softmax with a dominant key (forces large score ranges through the online rescale across key groups)."""
     n, l, h = 1, 197, 2

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Diagnostic (tuning build): where an item of the vision attention kernel spends its time.
+query wave 0: 0 arrive at the barrier, 1 past it, 2 S / softmax / PV done, 3 outputs stored;  loader (wave 7): 0 arrive at its wait,
+1 operands landed (vmcnt 0), 2 past the barrier, 3 next item's DMA issued."""
+import ctypes, os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clip_calibration_amd import _lib, ops
+assert hasattr(_lib.lib, "clipmi_tuning_set_stamps"), "needs CLIPMI_LIBRARY=.../libclipmi_tuning.so"
+_lib.lib.clipmi_tuning_set_stamps.argtypes = [ctypes.c_void_p]
+n, l, h = 256, 197, 12
+qkv = torch.randn(n * l, 3 * 64 * h, device="cuda").half()
+for mode in [int(x) for x in os.environ.get("MODES", "1,2").split(",")]:
+    _lib.set_option("attn_loader", mode)
+    for _ in range(3):
+        ops.attention(qkv, n, l, h, False)
+    stamps = torch.zeros(n * h * 2 * 8, dtype=torch.int64, device="cuda")
+    _lib.lib.clipmi_tuning_set_stamps(stamps.data_ptr())
+    ops.attention(qkv, n, l, h, False)
+    torch.cuda.synchronize()
+    _lib.lib.clipmi_tuning_set_stamps(None)
+    s = stamps.cpu().numpy().reshape(n * h, 2, 8).astype(np.float64) / 100.0   # us
+    qv, ldr = s[:, 0, :], s[:, 1, :]
+    ok = qv[:, 0] > 0
+    qv, ldr = qv[ok], ldr[ok]
+    d = np.diff(qv[:, :4], axis=1)
+    print(f"attn_loader={mode}: query wave 0 per item: wait at barrier {np.median(d[:,0]):5.2f}  compute {np.median(d[:,1]):5.2f}  store {np.median(d[:,2]):5.2f} us")
+    e = np.diff(ldr[:, :4], axis=1)
+    print(f"   loader per item: wait for landing {np.median(e[:,0]):5.2f}  wait at barrier {np.median(e[:,1]):5.2f}  issue next {np.median(e[:,2]):5.2f} us;  "
+          f"kernel span {qv[:,3].max() - qv[:,0].min():.1f} us")
