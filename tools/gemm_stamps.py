@@ -44,9 +44,21 @@ for name, step, variant in CASES:
     _lib.lib.clipmi_tuning_set_stamps(None)
     s = stamps.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] > 0]
+    bid = np.nonzero(stamps.cpu().numpy().reshape(-1, 8)[:, 0] > 0)[0]
     t = (s[:, :5] - s[:, 0].min()) / 100.0      # 100 MHz -> microseconds
     order = np.argsort(t[:, 0])
     t = t[order]
+    if variant is None:   # one tile per workgroup: idle time of a CU between two workgroups (CU = (hardware id, XCD = blockIdx % 8))
+        cu = {}
+        for row, hw, b in zip(t, s[order][:, 5], bid[order]):
+            cu.setdefault((int(hw), int(b) & 7), []).append(row)
+        gaps = [b[0] - a[4] for rows in cu.values() for a, b in zip(rows[:-1], rows[1:])]
+        busy = [sum(r[4] - r[0] for r in rows) for rows in cu.values()]
+        if gaps:
+            print(f"   {len(cu)} CUs; workgroups per CU {min(len(r) for r in cu.values())}..{max(len(r) for r in cu.values())}; "
+                  f"end -> next start on the same CU med {np.median(gaps):5.2f} us  p90 {np.percentile(gaps,90):5.2f}; "
+                  f"busy per CU med {np.median(busy):.1f} us; last end per CU p10 {np.percentile([r[-1][4] for r in cu.values()],10):.1f} "
+                  f"med {np.median([r[-1][4] for r in cu.values()]):.1f} max {max(r[-1][4] for r in cu.values()):.1f}")
     if variant in (11, 13):   # persistent: stamps are per tile (virtual block id); column 5 = physical workgroup
         wg = s[order][:, 5]
         pro, main, epi_i = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
