@@ -130,8 +130,161 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
   }
 }
 
-__device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2], float l_run, int hh) {
+// ---------------------------------------------------------------------------------------------------------------
+// attend_block with the LDS fragment reads PINNED AHEAD of their consumers (round 2).
+//
+// The ISA of attend_block as hipcc schedules it reads ONE fragment into the same four registers in front of every MFMA:
+//     ds_read_b128 v[4:7] ; s_waitcnt lgkmcnt(0) ; v_mfma ... v[4:7] ; ds_read_b128 v[4:7] ; s_waitcnt lgkmcnt(0) ; v_mfma ...
+// so each of the 28 S MFMAs and most of the 42 P.V MFMAs of a query tile pays a whole LDS round trip (~100+ cycles in
+// front of a 32-cycle instruction; amdgpu_waves_per_eu does not change the schedule).  Here the reads are inline asm
+// (cdna_hip_programming.md §5.7, form (ii): "=v" loads, later a wait statement that names every destination "+v" -- the
+// data dependency keeps the consumers below the wait): the K fragments of key tile t+1 are in flight while tile t's four
+// MFMAs run (two register sets), the first K tile of the next softmax group is read before the P.V phase of the current
+// one, and the four transposed V reads of a 16-key step are issued before that step's exponent work, one step ahead.
+// LDS operations return in order, so the counted lgkmcnt(N) waits below only assume that the N youngest operations are
+// the ones issued after the awaited set; an LDS operation hipcc adds on its own (the cross-half shuffle) makes a wait
+// stricter, never weaker.  Dense single-block form only (vision towers: no causal mask, (NKT-1)*32 < L <= NKT*32).
+// ---------------------------------------------------------------------------------------------------------------
+#define CLIPMI_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define CLIPMI_DS_READ_TR16_B64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int N>
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4h(f16x4& a, f16x4& b, f16x4& c, f16x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+template <int KT>
+__device__ __forceinline__ void read_k(f16x8 (&dst)[4], const uint32_t (&ka)[4]) {
+  CLIPMI_DS_READ_B128(dst[0], ka[0], KT * 4096);
+  CLIPMI_DS_READ_B128(dst[1], ka[1], KT * 4096);
+  CLIPMI_DS_READ_B128(dst[2], ka[2], KT * 4096);
+  CLIPMI_DS_READ_B128(dst[3], ka[3], KT * 4096);
+}
+template <int OFF>
+__device__ __forceinline__ void read_v(f16x4 (&dst)[4], const uint32_t (&va)[2]) {
+  CLIPMI_DS_READ_TR16_B64(dst[0], va[0], OFF);
+  CLIPMI_DS_READ_TR16_B64(dst[1], va[0], OFF + 1024);
+  CLIPMI_DS_READ_TR16_B64(dst[2], va[1], OFF);
+  CLIPMI_DS_READ_TR16_B64(dst[3], va[1], OFF + 1024);
+}
+
+// ka[ks] / va[dt]: the lane's LDS byte addresses (key tile 0) of its K fragment ks and of its transposed V reads for d-tile dt.
+template <int NKT, int GROUP>
+__device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const uint32_t (&va)[2], const uint32_t (&qa)[4], int L,
+                                                int hh, f32x16 (&oacc)[2], f32x16& lacc) {
+  constexpr float C = 0.125f * LOG2E;
+  const f16x8 ones = f16x8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+  const f32x16 zero16 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f16x8 kf[2][4];
+  f16x4 vf[2][4];   // [buffer][dt * 2 + (lo | hi)]
+  float m_run = NEG_BIG;
+  f16x8 qf[4];      // this wave's 32 query rows (B operand of S^T = K Q^T), read like a K tile: qa = the lane's LDS addresses
+  read_k<0>(qf, qa);
+  read_k<0>(kf[0], ka);
+
+  auto group = [&](auto g0_tag) {
+    constexpr int G0 = decltype(g0_tag)::value;
+    constexpr int G = NKT - G0 < GROUP ? NKT - G0 : GROUP;
+    constexpr bool MORE = G0 + G < NKT;
+    f32x16 s[G];
+    // ---- S^T = K Q^T, the next tile's fragments in flight
+    auto s_tile = [&](auto t_tag) {
+      constexpr int T = decltype(t_tag)::value;
+      constexpr int KT = G0 + T;
+      constexpr int CUR = KT & 1;
+      if constexpr (T + 1 < G) {
+        read_k<KT + 1>(kf[CUR ^ 1], ka);
+        lds_wait4<4>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
+        if constexpr (KT == 0) lds_wait4<4>(qf[0], qf[1], qf[2], qf[3]);   // older than the K reads: already back; names the registers
+      } else {
+        lds_wait4<0>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
+      }
+      s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+      if constexpr (KT == NKT - 1) {   // the only tile that can hold keys at or beyond L
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = KT * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          s[T][e] = key >= L ? NEG_BIG : s[T][e];
+        }
+      }
+    };
+    s_tile(std::integral_constant<int, 0>{});
+    if constexpr (G > 1) s_tile(std::integral_constant<int, 1>{});
+    if constexpr (G > 2) s_tile(std::integral_constant<int, 2>{});
+    if constexpr (G > 3) s_tile(std::integral_constant<int, 3>{});
+    static_assert(G <= 4, "softmax groups of at most four key tiles");
+    // the reads that the P.V phase (and the next group's first S tile) open with: behind the exponent work by the time they are needed
+    if constexpr (MORE) read_k<G0 + G>(kf[(G0 + G) & 1], ka);
+    read_v<G0 * 4096>(vf[0], va);
+    // ---- group max of the raw scores, online rescale (nothing to rescale in the first group)
+    float mloc = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < G; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = G0 == 0 ? mloc : fmaxf(m_run, mloc);
+    if constexpr (G0 > 0) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+      lacc[0] *= alpha;
+    }
+    const float mc = m_new * C;
+    m_run = m_new;
+    // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
+    auto pv_step = [&](auto t_tag, auto ss_tag) {
+      constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
+      constexpr int STEP = T * 2 + SS, CUR = STEP & 1;
+      constexpr bool LAST = STEP == 2 * G - 1;
+      if constexpr (!LAST) read_v<(G0 + (STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
+      f16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
+      if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+      else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
+        const f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (G0 == 0 && STEP == 0) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pf, zero16, 0, 0, 0);
+        else oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pf, oacc[dt], 0, 0, 0);
+      }
+      if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, zero16, 0, 0, 0);
+      else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+    };
+    auto pv_tile = [&](auto t_tag) {
+      pv_step(t_tag, std::integral_constant<int, 0>{});
+      pv_step(t_tag, std::integral_constant<int, 1>{});
+    };
+    pv_tile(std::integral_constant<int, 0>{});
+    if constexpr (G > 1) pv_tile(std::integral_constant<int, 1>{});
+    if constexpr (G > 2) pv_tile(std::integral_constant<int, 2>{});
+    if constexpr (G > 3) pv_tile(std::integral_constant<int, 3>{});
+  };
+  group(std::integral_constant<int, 0>{});
+  if constexpr (NKT > GROUP) group(std::integral_constant<int, GROUP>{});
+  static_assert(NKT <= 2 * GROUP, "at most two softmax groups");
+}
+
+// O^T tile (64 d x 32 queries) -> the 32 query rows of `out`, 128 B each.  A lane holds 8 groups of 4 consecutive d of ITS query
+// (group g = dt * 4 + rr: d = 8 g + 4 hh + e), the lane 32 further on the other 4 of every group.  One v_permlane32_swap per
+// register and group pair (cdna_hip_programming.md T21) gives the lower half-wave d = 8k .. 8k+7 of the even groups and the
+// upper half-wave those of the odd groups: four 16-byte stores per lane instead of eight 8-byte ones (the tail is store-ISSUE
+// bound).  Every lane of the wave must call this (the swap is a cross-lane exchange); `valid` masks the stores only.
+__device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2], float l_run, int hh, bool valid = true) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   const float inv = 1.0f / l_run;
+  u32x2 o2[8];
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -139,8 +292,16 @@ __device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2],
       f16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[dt][rr * 4 + e] * inv);
-      *reinterpret_cast<f16x4*>(orow + dt * 32 + rr * 8 + hh * 4) = o;
+      o2[dt * 4 + rr] = __builtin_bit_cast(u32x2, o);
     }
+  char* row = reinterpret_cast<char*>(orow) + (hh ? 16 : 0);
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    u32x2 a = o2[k], b = o2[k + 1];
+    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    if (valid) *reinterpret_cast<u32x4*>(row + 16 * k) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+  }
 }
 
 template <int NKT, int GROUP, bool TR>
@@ -371,11 +532,11 @@ constexpr int VARR = VROWS * 128;            // one operand image
 constexpr int VBUF = 3 * VARR;               // K | V | Q
 constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of the last array
 
-template <int NLOAD, int PRIO, int GROUP = 4>
+template <int NLOAD, int PRIO, int GROUP = 4, bool PF = true>
 __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                                                int L, int H, int n_items
 #ifdef CLIPMI_TUNING
-                                                                                               , long long* stamps   // diagnostic build: [item][query wave 0 | loader][8]
+                                                                                               , long long* stamps   // diagnostic build: [item][wave 0..7 (7 = loader)][8]
 #endif
                                                                                                ) {
   constexpr int NKT = 7, NT = 448 + 64 * NLOAD;
@@ -427,7 +588,7 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
       for (; item < n_items; item += gridDim.x, buf ^= 1) {
 #ifdef CLIPMI_TUNING
         const bool stamp = stamps != nullptr && lane == 0 && wave == 7;
-        long long* sp = stamps + ((size_t)item * 2 + 1) * 8;
+        long long* sp = stamps + ((size_t)item * 8 + 7) * 8;
         if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's operands have landed
@@ -451,6 +612,7 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
   }
 
   // ---- query waves: no VMEM load in their instruction stream
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int q0 = wave * 32;
   const int q = q0 + r32;
   const int kswz = (r32 >> 1) & 7;
@@ -470,8 +632,8 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
   int buf = 0;
   for (; item < n_items; item += gridDim.x, buf ^= 1) {
 #ifdef CLIPMI_TUNING
-    const bool stamp = stamps != nullptr && lane == 0 && wave == 0;
-    long long* sp = stamps + ((size_t)item * 2) * 8;
+    const bool stamp = stamps != nullptr && lane == 0;
+    long long* sp = stamps + ((size_t)item * 8 + wave) * 8;
     if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     __builtin_amdgcn_s_barrier();   // the loaders' vmcnt(0) came first: this item's K / V / Q are in LDS
@@ -479,21 +641,29 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
     if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     const char* b = smem + buf * VBUF;
-    const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
-    const char* const vread[2] = {b + vro[0], b + vro[1]};
-    f16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(b + qro[ks]);
     f32x16 oacc[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-    float m_run = NEG_BIG;
     f32x16 lacc;
+    if constexpr (PF) {   // fragment reads pinned ahead of their MFMAs (attend_dense_pf)
+      const uint32_t lb = lds_base + (uint32_t)(buf * VBUF);
+      const uint32_t ka[4] = {lb + (uint32_t)kro[0], lb + (uint32_t)kro[1], lb + (uint32_t)kro[2], lb + (uint32_t)kro[3]};
+      const uint32_t va[2] = {lb + (uint32_t)vro[0], lb + (uint32_t)vro[1]};
+      const uint32_t qa[4] = {lb + (uint32_t)qro[0], lb + (uint32_t)qro[1], lb + (uint32_t)qro[2], lb + (uint32_t)qro[3]};
+      attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc);
+    } else {
+      f16x8 qf[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-    attend_block<NKT, GROUP, true, 1>(kread, vread, qf, 0, L, 0, q0, q, hh, m_run, oacc, lacc);
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(b + qro[ks]);
+      const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
+      const char* const vread[2] = {b + vro[0], b + vro[1]};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+      float m_run = NEG_BIG;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+      attend_block<NKT, GROUP, true, 1>(kread, vread, qf, 0, L, 0, q0, q, hh, m_run, oacc, lacc);
+    }
 #ifdef CLIPMI_TUNING
     asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[1][15]), "v"(lacc[0]));
     if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -508,10 +678,10 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
   }
 }
 
-template <int NLOAD, int PRIO, int GROUP = 4>
+template <int NLOAD, int PRIO, int GROUP = 4, bool PF = true>
 int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = attention_vision_kernel<NLOAD, PRIO, GROUP>;
+  auto fn = attention_vision_kernel<NLOAD, PRIO, GROUP, PF>;
   ensure_dynamic_lds(fn, VSMEM, attr_once);
   const int n_cu = device_cus();
   const int n_items = N * H;
@@ -528,7 +698,8 @@ int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStre
 // kernel without loaders 81-83 us, one loader 74-78 us, two loaders 78 us (74 with raised priority), one loader with all seven key
 // tiles in one softmax group 79.5 us, groups of two 80.3 us.
 int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, int mode, hipStream_t s) {
-  if (mode == 2) return launch_vision_t<2, 0>(qkv, out, N, L, H, s);
+  if (mode == 2) return launch_vision_t<2, 0, 4, false>(qkv, out, N, L, H, s);
+  if (mode == 3) return launch_vision_t<1, 0, 4, false>(qkv, out, N, L, H, s);   // compiler-placed fragment reads (A/B aid)
   return launch_vision_t<1, 0>(qkv, out, N, L, H, s);
 }
 

@@ -605,7 +605,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt landed for every wave; everyone finished reading the other buffer
 #ifdef CLIPMI_TUNING
-    if (stamp && kt == 0) a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (stamp && kt == 0) {
+      a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();   // shader-clock counter: in-kernel clock of the main loop
+    }
 #endif
     if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* st = smem + (kt & 1) * T::STAGE;
@@ -652,7 +655,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) 
   }
 
 #ifdef CLIPMI_TUNING
-  if (stamp) a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+  if (stamp) {
+    a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
+  }
 #endif
   epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
 #ifdef CLIPMI_TUNING
@@ -960,7 +966,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 #ifdef CLIPMI_TUNING
-      if (stamp && kt == 0) a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (stamp && kt == 0) {
+        a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
+      }
 #endif
       if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
       const char* st = smem + buf * T::STAGE;
@@ -988,7 +997,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs
     const int cm0 = m0, cn0 = n0;
     [[maybe_unused]] const int cvb = vb;
 #ifdef CLIPMI_TUNING
-    if (stamp) a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (stamp) {
+      a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[cvb * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
+    }
 #endif
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < a.nwg;
@@ -1499,7 +1511,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     constexpr std::true_type yes{};
     kstep(std::integral_constant<int, -1>{}, no, 0);
 #ifdef CLIPMI_TUNING
-    if (stamp) a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (stamp) {
+      a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
+    }
 #endif
     kstep(std::integral_constant<int, 0>{}, no, 1);
     kstep(std::integral_constant<int, 1>{}, yes, 2);
@@ -1516,7 +1531,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     const int cm0 = m0, cn0 = n0;
     [[maybe_unused]] const int cvb = vb;
 #ifdef CLIPMI_TUNING
-    if (stamp) a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (stamp) {
+      a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+      a.stamps[cvb * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
+    }
 #endif
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < a.nwg;

@@ -133,11 +133,12 @@ def test_attention(ops, n, l, h, causal, tr, clipmi_option):
     assert err < 4e-3, f"max err {err}"
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,l,h", [(3, 197, 12), (2, 199, 12), (1, 193, 2), (5, 200, 1), (40, 197, 12)])
 def test_attention_vision_loader_modes(ops, clipmi_option, mode, n, l, h):
     """193..200-token non-causal attention (the image towers at 224 px; clip/model.py:181-183): the persistent kernel
-    (attn_loader 0) and the all-DMA kernel with one / two loader waves give the SAME bits -- only the operand transport differs --
+    (attn_loader 0) and the all-DMA kernel with one / two loader waves (1: fragment reads pinned ahead of their MFMAs by inline asm,
+    the default; 2, 3: compiler-placed reads) give the SAME bits -- only the operand transport and the instruction order differ --
     and match the fp32 reference.  40 sequences x 12 heads = several items per workgroup (both LDS buffers in use)."""
     clipmi_option("attn_loader", mode)
     g = torch.Generator().manual_seed(n * 1000 + l + h)

@@ -13,17 +13,20 @@ for mode in [int(x) for x in os.environ.get("MODES", "1,2").split(",")]:
     _lib.set_option("attn_loader", mode)
     for _ in range(3):
         ops.attention(qkv, n, l, h, False)
-    stamps = torch.zeros(n * h * 2 * 8, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(n * h * 8 * 8, dtype=torch.int64, device="cuda")
     _lib.lib.clipmi_tuning_set_stamps(stamps.data_ptr())
     ops.attention(qkv, n, l, h, False)
     torch.cuda.synchronize()
     _lib.lib.clipmi_tuning_set_stamps(None)
-    s = stamps.cpu().numpy().reshape(n * h, 2, 8).astype(np.float64) / 100.0   # us
-    qv, ldr = s[:, 0, :], s[:, 1, :]
-    ok = qv[:, 0] > 0
-    qv, ldr = qv[ok], ldr[ok]
-    d = np.diff(qv[:, :4], axis=1)
-    print(f"attn_loader={mode}: query wave 0 per item: wait at barrier {np.median(d[:,0]):5.2f}  compute {np.median(d[:,1]):5.2f}  store {np.median(d[:,2]):5.2f} us")
-    e = np.diff(ldr[:, :4], axis=1)
-    print(f"   loader per item: wait for landing {np.median(e[:,0]):5.2f}  wait at barrier {np.median(e[:,1]):5.2f}  issue next {np.median(e[:,2]):5.2f} us;  "
-          f"kernel span {qv[:,3].max() - qv[:,0].min():.1f} us")
+    s = stamps.cpu().numpy().reshape(n * h, 8, 8).astype(np.float64) / 100.0   # us; [item][wave 0..6 query, 7 loader][stamp]
+    ok = s[:, 0, 0] > 0
+    s = s[ok]
+    print(f"attn_loader={mode}: kernel span {s[:, :7, 3].max() - s[:, :7, 0].min():.1f} us, {ok.sum()} items")
+    for w in range(7):
+        d = np.diff(s[:, w, :4], axis=1)
+        print(f"   query wave {w}: wait at barrier {np.median(d[:,0]):5.2f}  compute {np.median(d[:,1]):5.2f}  store {np.median(d[:,2]):5.2f} us")
+    arrive = s[:, :, 0]                                    # arrival at the item's barrier, all 8 waves
+    last = np.argmax(arrive, axis=1)
+    print("   last wave to arrive at the barrier (share of items, waves 0..7):", np.round(np.bincount(last, minlength=8) / len(last), 2))
+    e = np.diff(s[:, 7, :4], axis=1)
+    print(f"   loader per item: wait for landing {np.median(e[:,0]):5.2f}  wait at barrier {np.median(e[:,1]):5.2f}  issue next {np.median(e[:,2]):5.2f} us")

@@ -23,6 +23,7 @@ if not hasattr(_lib.lib, "clipmi_tuning_set_stamps"):
 _lib.lib.clipmi_tuning_set_stamps.argtypes = [ctypes.c_void_p]
 
 B = int(os.environ.get("B", "256"))
+WARM_S = float(os.environ.get("WARM_S", "0"))
 model = build_model(dict(syn.synthetic_state_dict("ViT-B/16", seed=0)), None).cuda()
 images = syn.synthetic_images(B, "ViT-B/16", seed=0, device="cuda")
 with torch.no_grad():
@@ -38,6 +39,14 @@ for name, step, variant in CASES:
     _lib.set_option("gemm_stream", 0 if variant is None else 1)
     stamps = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
     model.profile_block_ms(B, iters=2, only=step)
+    if WARM_S > 0:   # steady-state clocks: the whole tower back to back for WARM_S seconds right before the stamped launch
+        import time
+        t_end = time.time() + WARM_S
+        with torch.no_grad():
+            while time.time() < t_end:
+                for _ in range(10):
+                    model.image_features_f32(images)
+                torch.cuda.synchronize()
     _lib.lib.clipmi_tuning_set_stamps(stamps.data_ptr())
     ms = model.profile_block_ms(B, iters=1, only=step)[model.BLOCK_KERNELS[step]]   # warm-up launch + timed launch: the last one's stamps stay
     torch.cuda.synchronize()
@@ -48,6 +57,12 @@ for name, step, variant in CASES:
     t = (s[:, :5] - s[:, 0].min()) / 100.0      # 100 MHz -> microseconds
     order = np.argsort(t[:, 0])
     t = t[order]
+    # in-kernel shader clock over the main loop: d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back 6)
+    dreal = (s[:, 2] - s[:, 1]).astype(np.float64)
+    ok = (dreal > 0) & (s[:, 6] > 0) & (s[:, 7] > s[:, 6])
+    if ok.any():
+        clk = (s[ok, 7] - s[ok, 6]) / dreal[ok] * 100.0
+        print(f"   in-kernel clock over the main loop: med {np.median(clk):.0f} MHz  p10 {np.percentile(clk,10):.0f}  p90 {np.percentile(clk,90):.0f}")
     if variant is None:   # one tile per workgroup: idle time of a CU between two workgroups (CU = (hardware id, XCD = blockIdx % 8))
         cu = {}
         for row, hw, b in zip(t, s[order][:, 5], bid[order]):
