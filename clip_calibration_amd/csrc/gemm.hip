@@ -1331,6 +1331,27 @@ int launch_defer(KArgs k, hipStream_t s) {
 // unrolled (straight-line code: hipcc's waitcnt pass keeps counted lgkmcnt waits), the remaining ones run in a loop.
 // Needs K >= 10 * 64, an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
 // ---------------------------------------------------------------------------------------------------------------
+// LDS fragment reads as inline asm (pinned where they are written; hipcc's waitcnt pass does not see them) and the counted
+// waits that name their destinations (cdna_hip_programming.md §5.7, form (ii)).
+// (a function template, not a macro used inside the kernel's generic lambdas: clang does not implicitly capture a variable
+// that a generic lambda names only as an asm operand)
+// CLIPMI_ABLATE (build-time, diagnostic builds only: results are wrong with any bit set): 2 no LDS-DMA pieces inside the K loop of
+// the streamed-epilogue kernel, 4 no MFMAs, 16 no fragment reads (the registers are left as they are)
+#ifndef CLIPMI_ABLATE
+#define CLIPMI_ABLATE 0
+#endif
+template <int OFF>
+__device__ __forceinline__ void ds_read128(f16x8& dst, uint32_t addr) {
+  if constexpr (CLIPMI_ABLATE & 16) asm volatile("" : "=v"(dst) : "v"(addr));
+  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait1(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void lgkm_wait5(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
 using TStream = Tile<256, 256, 2, 4, 2>;
 
 template <int EPI>
@@ -1386,6 +1407,17 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #pragma unroll
     for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff0, i * wstep), k0);
   };
+  // one 1 KiB piece per wave of a stage (P = 0 .. XI-1: activations, XI .. XI+WI-1: weights): the K loop issues a stage's pieces
+  // one per 4-MFMA step instead of all at once -- eight waves each issuing eight LDS-DMA instructions right behind the barrier
+  // queued up behind the CU's one address path (64 KB at 64 B/clk) with no MFMA in flight: that, not the LDS reads, held the
+  // first version of this loop at ~50 % of the matrix rate (in-kernel clock stamps: 46 k cycles per tile against 24.6 k of MFMAs)
+  auto stage_piece = [&](auto p_tag, const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
+    constexpr int P = decltype(p_tag)::value;
+    char* xs = smem + buf * T::STAGE + lds_wave_off;
+    const int k0 = kt * BK * 2;
+    if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
+    else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+  };
   // row / column parameters of a tile -> LDS by DMA, one 1 KiB piece per wave (waves 0-3); rows / columns outside the
   // matrix lie outside the descriptors and read as zero.  They ride on the same vmcnt wait as the tile's first stage.
   auto params = [&](int row0, int col0, int which) {
@@ -1425,82 +1457,137 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   stage(xrs, wrs, first_buf, 0);
   params(m0, n0, 0);
 
-  f16x4 held[TN][TM];        // the previous tile's outputs of this wave, fp16
+  // ---- outputs of the previous tile.  The first HD 16-row slices of a wave's 128 x 64 part are stored as soon as they are
+  // converted (before the next tile's K loop starts); the other TM - HD slices are HELD as fp16 in registers and leave one
+  // per K-step inside the next tile's K loop (K-steps 1 .. TM - HD).  Holding all eight slices (the first version) left 24
+  // registers for operand fragments: every 16-MFMA block then opened with an un-hidden LDS round trip (ds_read x 6,
+  // s_waitcnt lgkmcnt(1)) and the loop ran at 48 % of the matrix rate at 2.3 GHz (in-kernel clock stamps, tools/gemm_stamps.py).
+  constexpr int HD = 4, NHELD = TM - HD;
+  f16x4 held[TN][NHELD];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < TM; ++j) held[i][j] = f16x4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-  // The held tile is stored through a buffer descriptor that starts at the tile's first element and ends with the matrix:
-  // rows at or beyond M are dropped by the hardware range check, "nothing held yet" is a descriptor of zero bytes.  The
-  // whole byte offset goes into the VGPR operand -- only that (not the scalar offset) takes part in the range check --
-  // as (lane constant) + (scalar: wave, slice and column-block part); columns at or beyond N (last n-tile when N is not
-  // a multiple of 256) are sent out of range the same way: no divergent branch around the stores.
+    for (int j = 0; j < NHELD; ++j) held[i][j] = f16x4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  // Stores go through a buffer descriptor that starts at the tile's first element and ends with the matrix: rows at or beyond
+  // M are dropped by the hardware range check, "nothing held yet" is a descriptor of zero bytes.  The whole byte offset goes
+  // into the VGPR operand -- only that (not the scalar offset) takes part in the range check -- as (lane constant) + (scalar:
+  // wave, slice and column-block part); columns at or beyond N (last n-tile when N is not a multiple of 256) are sent out of
+  // range the same way (a select, no divergent branch around the stores).
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   half_t* out = static_cast<half_t*>(a.out);
   __amdgpu_buffer_rsrc_t ors = make_rsrc(out, 0);
-  int hn0 = 0;               // first column of the held tile
+  int hn0 = 0;               // first column of the tile `ors` describes
   const int st_lane = (r16 * (int)a.ldo + g4 * 4) * 2;
   const int slice_bytes = 16 * (int)a.ldo * 2;
   const int wave_soff = (wave_m * T::WTM * (int)a.ldo + wave_n * 64) * 2;   // scalar
-  auto flush_slice = [&](int j) {   // rows 16 j .. 16 j + 15 of this wave's part of the held tile
+  auto store_slice = [&](int j, const f16x4 (&v)[TN]) {   // rows 16 j .. 16 j + 15 of this wave's part of the tile
     const int col = hn0 + wave_n * 64 + g4 * 4;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int voff = col + i * 16 < a.N ? row_off(st_lane, wave_soff + j * slice_bytes + i * 32) : (int)0xFFFFFFF0;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, held[i][j]), ors, voff, 0, 0);
+      const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + i * 32);
+      const int voff = col + i * 16 < a.N ? in_range : (int)0xFFFFFFF0;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[i]), ors, voff, 0, 0);
     }
   };
+  auto flush_held = [&](int jh) {
+    const f16x4 v[TN] = {held[0][jh], held[1][jh], held[2][jh], held[3][jh]};
+    store_slice(HD + jh, v);
+  };
+  auto flush_held_piece = [&](int jh, int i) {   // one of the four stores of a held slice
+    const int col = hn0 + wave_n * 64 + g4 * 4;
+    const int in_range = row_off(st_lane, wave_soff + (HD + jh) * slice_bytes + i * 32);
+    const int voff = col + i * 16 < a.N ? in_range : (int)0xFFFFFFF0;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, held[i][jh]), ors, voff, 0, 0);
+  };
+
+  // ---- operand fragments: inline-asm LDS reads, pinned ahead of the MFMAs that use them (cdna_hip_programming.md §5.7 form
+  // (ii); same construction as attend_dense_pf in attention.hip).  Per K-step and wave: 2 k-halves x 8 activation blocks
+  // (B operand, xf) x 4 weight blocks (A operand, wf) = 64 MFMAs.  The four weight fragments of a k-half stay resident (two
+  // register sets: the second half's are read during the first half), the activation fragments stream through a ring of
+  // three: the read for step s + 3 is issued right after the MFMAs of step s, so a fragment has two steps (128 matrix-pipe
+  // cycles of this wave, 256 of the SIMD) to arrive.  LDS returns in order: the counted waits below name how many reads were
+  // issued after the awaited one.
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t xo[2] = {(uint32_t)(xbase + foff[0]), (uint32_t)(xbase + foff[1])};
+  const uint32_t wo[2] = {(uint32_t)(wbase + foff[0]), (uint32_t)(wbase + foff[1])};
 
   f32x4 acc[TN][TM];
-  // one K-step; SLICE >= 0: also store rows 16*SLICE .. +15 of the held tile.
-  // VMEM operations retire in order, so a wait for stage kt also waits for every store issued before stage kt's DMA -- but
-  // not for the four stores of the slice sent during the previous K-step, which were issued AFTER it: after a K-step that
-  // sent a slice the wait is vmcnt(4), and a store has two K-steps (~3 us) to be acknowledged before anything waits for it.
+  // one K-step.  SLICE >= 0: also store held slice SLICE.  VMW: the vmcnt that leaves only operations YOUNGER than this step's
+  // stage DMA in flight (VMEM retires in order: the 16 direct stores of the previous tile's epilogue behind the prefetched
+  // first stage, the 4 stores of a held slice behind the stage issued in the same K-step).  FIRSTK: the accumulators start at 0.
   // Raw s_barrier: __syncthreads() would add its own vmcnt(0) while LDS-DMA is in flight.
-  auto kstep = [&](auto slice_tag, auto prev_sent_tag, int kt) {
+  auto kstep = [&](auto slice_tag, auto vmw_tag, auto first_tag, auto more_tag, int kt) {
     constexpr int SLICE = decltype(slice_tag)::value;
-    constexpr bool PREV_SENT = decltype(prev_sent_tag)::value;
+    constexpr int VMW = decltype(vmw_tag)::value;
+    constexpr bool FIRSTK = decltype(first_tag)::value;
     const int buf = (first_buf + kt) & 1;
-    if constexpr (PREV_SENT) wait_vmcnt<TN>();
-    else wait_vmcnt<0>();
+    wait_vmcnt<VMW>();
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
-#ifdef CLIPMI_TUNING
-    if constexpr (SLICE >= 0) { if (!(a.knob & 1)) flush_slice(SLICE); }
-#else
-    if constexpr (SLICE >= 0) flush_slice(SLICE);
-#endif
-    const char* st = smem + buf * T::STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {   // activation fragments in two halves that share registers; weight fragments one ahead
-        f16x8 xf[TM / 2], wcur, wnext;
-#pragma unroll
-        for (int j = 0; j < TM / 2; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + (h * (TM / 2) + j) * 2048 + foff[ks]);
-        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
+    const uint32_t sb = lds_base + (uint32_t)(buf * T::STAGE);
+    uint32_t xa0 = sb + xo[0], xa1 = sb + xo[1], wa0 = sb + wo[0], wa1 = sb + wo[1];   // not const: odr-used by the asm operands in the lambda below
+    f16x8 wf[2][4], xf[3];
+    ds_read128<0>(wf[0][0], wa0);
+    ds_read128<2048>(wf[0][1], wa0);
+    ds_read128<4096>(wf[0][2], wa0);
+    ds_read128<6144>(wf[0][3], wa0);
+    ds_read128<0>(xf[0], xa0);
+    ds_read128<2048>(xf[1], xa0);
+    ds_read128<4096>(xf[2], xa0);
+    constexpr bool MORE = decltype(more_tag)::value;   // a next K-step exists: its stage is DMA'd during this one
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](auto s_tag) {
+      constexpr int S = decltype(s_tag)::value;
+      constexpr int KS = S >> 3, J = S & 7, SLOT = S % 3;
+      constexpr int YOUNGER = S == 0 ? 2 : (S <= 3 ? 6 : (S <= 13 ? 2 : 15 - S));
+      if constexpr (S == 0) lgkm_wait5<YOUNGER>(wf[0][0], wf[0][1], wf[0][2], wf[0][3], xf[SLOT]);
+      else if constexpr (S == 8) lgkm_wait5<YOUNGER>(wf[1][0], wf[1][1], wf[1][2], wf[1][3], xf[SLOT]);   // wf[1]: older, long back
+      else lgkm_wait1<YOUNGER>(xf[SLOT]);
+      if constexpr (CLIPMI_ABLATE & 4) {
+        asm volatile("" :: "v"(wf[KS][0]), "v"(wf[KS][1]), "v"(wf[KS][2]), "v"(wf[KS][3]), "v"(xf[SLOT]));
+      } else {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int j = 0; j < TM / 2; ++j)
-            acc[i][h * (TM / 2) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][h * (TM / 2) + j], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          wcur = wnext;
+          if constexpr (FIRSTK && KS == 0)
+            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[KS][i], xf[SLOT], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else
+            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[KS][i], xf[SLOT], acc[i][J], 0, 0, 0);
         }
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);   // the read below overwrites xf[SLOT]: keep it behind the MFMAs that use the old value
+      if constexpr (S + 3 < 16) {
+        constexpr int S3 = S + 3;
+        if constexpr ((S3 >> 3) == 0) ds_read128<(S3 & 7) * 2048>(xf[SLOT], xa0);
+        else ds_read128<(S3 & 7) * 2048>(xf[SLOT], xa1);
+      }
+      if constexpr (S == 0) {
+        ds_read128<0>(wf[1][0], wa1);
+        ds_read128<2048>(wf[1][1], wa1);
+        ds_read128<4096>(wf[1][2], wa1);
+        ds_read128<6144>(wf[1][3], wa1);
+      }
+      // VMEM of this K-step, spread over its steps: the four stores of a held slice and the next stage's eight DMA pieces in
+      // the first half (the pieces have the second half to land)
+      if constexpr (SLICE >= 0 && S < TN) {   // first: the slice's registers are free for the rest of the K-step
+        if constexpr (!(CLIPMI_ABLATE & 1)) flush_held_piece(SLICE, S);
+      }
+      if constexpr (S < T::XI + T::WI) {
+        if constexpr (MORE && !(CLIPMI_ABLATE & 2)) stage_piece(s_tag, xrs, wrs, buf ^ 1, kt + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});  step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});  step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});  step(std::integral_constant<int, 8>{});
+    step(std::integral_constant<int, 9>{});  step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+    step(std::integral_constant<int, 15>{});
   };
 
 #ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
 #endif
+  bool first_tile = true;
   while (true) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1509,23 +1596,26 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #endif
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
-    kstep(std::integral_constant<int, -1>{}, no, 0);
+    using I = std::integral_constant<int, -1>;
+    // K-step 0: the stage was prefetched before the previous tile's epilogue; its 4 * HD direct stores are younger
+    if (first_tile) kstep(I{}, std::integral_constant<int, 0>{}, yes, yes, 0);
+    else kstep(I{}, std::integral_constant<int, 4 * HD>{}, yes, yes, 0);
+    first_tile = false;
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
     }
 #endif
-    kstep(std::integral_constant<int, 0>{}, no, 1);
-    kstep(std::integral_constant<int, 1>{}, yes, 2);
-    kstep(std::integral_constant<int, 2>{}, yes, 3);
-    kstep(std::integral_constant<int, 3>{}, yes, 4);
-    kstep(std::integral_constant<int, 4>{}, yes, 5);
-    kstep(std::integral_constant<int, 5>{}, yes, 6);
-    kstep(std::integral_constant<int, 6>{}, yes, 7);
-    kstep(std::integral_constant<int, 7>{}, yes, 8);
-    kstep(std::integral_constant<int, -1>{}, yes, 9);   // K >= 10 K-steps (checked by the launcher)
-    for (int kt = 10; kt < nk; ++kt) kstep(std::integral_constant<int, -1>{}, no, kt);
+    // a slice's stores are issued before the same K-step's last DMA pieces, so the next wait is vmcnt(0) for them too: they
+    // were sent a whole K-step earlier (K-step 1 also waits for the previous tile's direct stores: VMEM retires in order)
+    kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, no, yes, 1);
+    kstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, no, yes, 2);
+    kstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, no, yes, 3);
+    kstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, no, yes, 4);
+    static_assert(NHELD == 4, "K-steps 1..4 carry the held slices");
+    for (int kt = 5; kt < nk - 1; ++kt) kstep(I{}, std::integral_constant<int, 0>{}, no, yes, kt);   // K >= 10 K-steps (checked by the launcher)
+    kstep(I{}, std::integral_constant<int, 0>{}, no, no, nk - 1);
 
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cn0 = n0;
@@ -1547,7 +1637,10 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       stage(xrs, wrs, first_buf, 0);
       params(m0, n0, par ^ 1);
     }
-    // ---- element-wise epilogue into `held` (row / column parameters from LDS, DMA'd a whole tile ago)
+    // ---- element-wise epilogue (row / column parameters from LDS, DMA'd a whole tile ago): slices 0 .. HD-1 are stored at
+    // once, slices HD .. TM-1 go into `held`
+    ors = make_rsrc(out + (int64_t)cm0 * a.ldo + cn0, ((int64_t)(a.M - cm0) * a.ldo - cn0) * 2);
+    hn0 = cn0;
     {
       int le = lane;
       asm volatile("" : "+v"(le));   // keeps the lane-derived offsets below out of the K loop's live ranges
@@ -1566,6 +1659,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         // the lane's column offset makes every slice re-read its eight LDS vectors instead.
         int nl0 = wave_n * 64 + eg4 * 4;
         asm volatile("" : "+v"(nl0));
+        f16x4 cv[TN];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const int nl = nl0 + i * 16;
@@ -1576,22 +1670,26 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
           }
-          held[i][j] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+        if (j < HD) {
+          store_slice(j, cv);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TN; ++i) held[i][j - HD] = cv[i];
         }
         __builtin_amdgcn_sched_barrier(0);   // one 16-row slice at a time: the accumulators die as they are converted
       }
     }
-    ors = make_rsrc(out + (int64_t)cm0 * a.ldo + cn0, ((int64_t)(a.M - cm0) * a.ldo - cn0) * 2);
-    hn0 = cn0;
     par ^= 1;
 #ifdef CLIPMI_TUNING
     if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     if (!has_next) break;
   }
-  // the last tile's outputs: nothing left to hide them behind
+  // the last tile's held slices: nothing left to hide them behind
 #pragma unroll
-  for (int j = 0; j < TM; ++j) flush_slice(j);
+  for (int j = 0; j < NHELD; ++j) flush_held(j);
 }
 
 template <int EPI>

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic (tuning build only, never a benchmark): ablations of the streamed-epilogue GEMM kernel.  knob bits: 1 no slice
-flush at all, 2 flush without the stores, 4 no per-tile parameter computation, 8 no conversion of the accumulators.
+"""Diagnostic (tuning build only, never a benchmark): ablations of the streamed-epilogue GEMM kernel.  knob bits: 1 no held-slice
+stores in the K loop, 2 no LDS-DMA pieces in the K loop (the stages keep their first contents), 4 no MFMAs, 8 no conversion of the
+accumulators (timing only: results are wrong with any bit set).
     make -C clip_calibration_amd/csrc tuning && CLIPMI_LIBRARY=.../libclipmi_tuning.so python tools/stream_ablate.py"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ with torch.no_grad():
     model.image_features_f32(images)
 res = {}
 for rnd in range(4):
-    for stream, knob in ((0, 0), (1, 0), (1, 1), (1, 8), (1, 9)):
+    for stream, knob in ((0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 7), (1, 8), (1, 15)):
         _lib.set_option("gemm_stream", stream)
         _lib.lib.clipmi_tuning_set_knob(knob)
         with torch.no_grad():
