@@ -1348,10 +1348,21 @@ __device__ __forceinline__ void ds_read128(f16x8& dst, uint32_t addr) {
 template <int N>
 __device__ __forceinline__ void lgkm_wait1(f16x8& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <int N>
+__device__ __forceinline__ void lgkm_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait8(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e, f16x8& f, f16x8& g, f16x8& h) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void lgkm_wait5(f16x8& a, f16x8& b, f16x8& c, f16x8& d, f16x8& e) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
 }
 
+#ifndef CLIPMI_STREAM_HD
+#define CLIPMI_STREAM_HD 2
+#endif
 using TStream = Tile<256, 256, 2, 4, 2>;
 
 template <int EPI>
@@ -1462,43 +1473,48 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   // per K-step inside the next tile's K loop (K-steps 1 .. TM - HD).  Holding all eight slices (the first version) left 24
   // registers for operand fragments: every 16-MFMA block then opened with an un-hidden LDS round trip (ds_read x 6,
   // s_waitcnt lgkmcnt(1)) and the loop ran at 48 % of the matrix rate at 2.3 GHz (in-kernel clock stamps, tools/gemm_stamps.py).
-  constexpr int HD = 4, NHELD = TM - HD;
-  f16x4 held[TN][NHELD];
+  constexpr int HD = CLIPMI_STREAM_HD, NHELD = TM - HD;
+  static_assert(NHELD >= 1 && NHELD <= 6, "K-steps 1 .. NHELD carry the held slices");
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 held[2][NHELD];
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int j = 0; j < NHELD; ++j) held[i][j] = f16x4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    for (int j = 0; j < NHELD; ++j) held[p][j] = u32x4{0u, 0u, 0u, 0u};
   // Stores go through a buffer descriptor that starts at the tile's first element and ends with the matrix: rows at or beyond
   // M are dropped by the hardware range check, "nothing held yet" is a descriptor of zero bytes.  The whole byte offset goes
   // into the VGPR operand -- only that (not the scalar offset) takes part in the range check -- as (lane constant) + (scalar:
   // wave, slice and column-block part); columns at or beyond N (last n-tile when N is not a multiple of 256) are sent out of
   // range the same way (a select, no divergent branch around the stores).
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  // A converted slice is 4 n-blocks x 4 consecutive columns (8 bytes) per lane; v_permlane16_swap on each block pair (i, i + 1)
+  // -- odd 16-lane rows of block i against even rows of block i + 1 -- leaves every lane with 8 consecutive columns: lanes
+  // g4 = 0, 2 get columns 16 i + 4 g4 .. + 7 of block i, lanes g4 = 1, 3 columns 16 (i + 1) + 4 (g4 - 1) .. + 7 of block i + 1.
+  // Two 16-byte stores per slice (64 contiguous bytes per row and instruction) instead of four 8-byte ones: VMEM issue, not
+  // bandwidth, is what these stores cost the K loop.
   half_t* out = static_cast<half_t*>(a.out);
   __amdgpu_buffer_rsrc_t ors = make_rsrc(out, 0);
   int hn0 = 0;               // first column of the tile `ors` describes
-  const int st_lane = (r16 * (int)a.ldo + g4 * 4) * 2;
+  const int lcol = (g4 & 1) * 16 + (g4 >> 1) * 8;          // the lane's first column inside a block pair after the swap
+  const int st_lane = (r16 * (int)a.ldo + lcol) * 2;
   const int slice_bytes = 16 * (int)a.ldo * 2;
   const int wave_soff = (wave_m * T::WTM * (int)a.ldo + wave_n * 64) * 2;   // scalar
-  auto store_slice = [&](int j, const f16x4 (&v)[TN]) {   // rows 16 j .. 16 j + 15 of this wave's part of the tile
-    const int col = hn0 + wave_n * 64 + g4 * 4;
+  auto pack_slice = [&](const f16x4 (&v)[TN], u32x4 (&o)[2]) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + i * 32);
-      const int voff = col + i * 16 < a.N ? in_range : (int)0xFFFFFFF0;
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v[i]), ors, voff, 0, 0);
+    for (int p = 0; p < 2; ++p) {
+      const u32x2 lo = __builtin_bit_cast(u32x2, v[2 * p]), hi = __builtin_bit_cast(u32x2, v[2 * p + 1]);
+      const auto r0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+      o[p] = u32x4{r0[0], r1[0], r0[1], r1[1]};
     }
   };
-  auto flush_held = [&](int jh) {
-    const f16x4 v[TN] = {held[0][jh], held[1][jh], held[2][jh], held[3][jh]};
-    store_slice(HD + jh, v);
+  auto store_piece = [&](int j, int p, const u32x4& v) {   // rows 16 j .. 16 j + 15 of this wave's part of the tile, block pair p
+    const int col = hn0 + wave_n * 64 + lcol + p * 32;
+    const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + p * 64);
+    const int voff = col < a.N ? in_range : (int)0xFFFFFFF0;
+    __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
   };
-  auto flush_held_piece = [&](int jh, int i) {   // one of the four stores of a held slice
-    const int col = hn0 + wave_n * 64 + g4 * 4;
-    const int in_range = row_off(st_lane, wave_soff + (HD + jh) * slice_bytes + i * 32);
-    const int voff = col + i * 16 < a.N ? in_range : (int)0xFFFFFFF0;
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, held[i][jh]), ors, voff, 0, 0);
-  };
+  constexpr int SPS = 2;   // stores per slice and wave
 
   // ---- operand fragments: inline-asm LDS reads, pinned ahead of the MFMAs that use them (cdna_hip_programming.md §5.7 form
   // (ii); same construction as attend_dense_pf in attention.hip).  Per K-step and wave: 2 k-halves x 8 activation blocks
@@ -1512,81 +1528,114 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   const uint32_t wo[2] = {(uint32_t)(wbase + foff[0]), (uint32_t)(wbase + foff[1])};
 
   f32x4 acc[TN][TM];
-  // one K-step.  SLICE >= 0: also store held slice SLICE.  VMW: the vmcnt that leaves only operations YOUNGER than this step's
-  // stage DMA in flight (VMEM retires in order: the 16 direct stores of the previous tile's epilogue behind the prefetched
-  // first stage, the 4 stores of a held slice behind the stage issued in the same K-step).  FIRSTK: the accumulators start at 0.
-  // Raw s_barrier: __syncthreads() would add its own vmcnt(0) while LDS-DMA is in flight.
-  auto kstep = [&](auto slice_tag, auto vmw_tag, auto first_tag, auto more_tag, int kt) {
+  // ---- K loop: PING-PONG between the two waves of a SIMD (waves w and w + 4; MI355X_MICROARCH.md "Two waves per SIMD").
+  // A K-step is four phases per wave (k-half ks = p >> 1, row half jh = p & 1), each a LOAD part -- the phase's operand
+  // fragments (4 activation blocks, plus the 4 weight blocks when jh == 0) by pinned LDS reads, this wave's share of the next
+  // stage's LDS-DMA pieces (3 + 3 + 2 over phases 0..2) or a held slice's stores (phase 3), then the wait for the reads --
+  // and a COMPUTE part of 16 MFMAs on registers only, with a workgroup barrier after each part.  Group 1 (waves 4-7) runs one
+  // part behind group 0, so on every SIMD one wave issues MFMAs while its partner issues memory instructions: in the first
+  // version each wave interleaved both, and eight VMEM instructions (~100 issue cycles each) per wave and K-step left the
+  // matrix pipe idle a third of the time (build-time ablations: no DMA -26 %, no stores -19 %, no MFMAs only -19 %).
+  // Hazards (slot = one part; group 0 is in slot 8k + 2p (load) / + 2p + 1 (compute) of K-step k, group 1 one slot later):
+  //   WAR  stage k + 1 is DMA'd into the buffer of stage k - 1, whose last reads (group 1, phase 3) finished before the barrier
+  //        that ends slot 8k - 1; the first piece is issued in slot 8k.
+  //   RAW  the last pieces are issued in slot 8k + 5; every wave waits for its own pieces at the end of slot 8k + 7 (group 0:
+  //        after its compute part, group 1: after its load part), the first read of stage k + 1 is in slot 8k + 8.
+  // The fragment registers are single-buffered: a wave overwrites them in its load part, after its MFMAs of the previous
+  // compute part have been issued.
+  const int grp = wave >> 2;   // uniform
+  auto kstep = [&](auto slice_tag, auto first_tag, auto more_tag, int kt) {
     constexpr int SLICE = decltype(slice_tag)::value;
-    constexpr int VMW = decltype(vmw_tag)::value;
-    constexpr bool FIRSTK = decltype(first_tag)::value;
+    constexpr bool FIRSTK = decltype(first_tag)::value;   // the accumulators start at 0
+    constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
+    constexpr int NST = (SLICE >= 0 && !(CLIPMI_ABLATE & 1)) ? SPS : 0;   // stores issued behind this K-step's DMA pieces
     const int buf = (first_buf + kt) & 1;
-    wait_vmcnt<VMW>();
-    __builtin_amdgcn_s_barrier();
     const uint32_t sb = lds_base + (uint32_t)(buf * T::STAGE);
-    uint32_t xa0 = sb + xo[0], xa1 = sb + xo[1], wa0 = sb + wo[0], wa1 = sb + wo[1];   // not const: odr-used by the asm operands in the lambda below
-    f16x8 wf[2][4], xf[3];
-    ds_read128<0>(wf[0][0], wa0);
-    ds_read128<2048>(wf[0][1], wa0);
-    ds_read128<4096>(wf[0][2], wa0);
-    ds_read128<6144>(wf[0][3], wa0);
-    ds_read128<0>(xf[0], xa0);
-    ds_read128<2048>(xf[1], xa0);
-    ds_read128<4096>(xf[2], xa0);
-    constexpr bool MORE = decltype(more_tag)::value;   // a next K-step exists: its stage is DMA'd during this one
-    __builtin_amdgcn_sched_barrier(0);
-    auto step = [&](auto s_tag) {
-      constexpr int S = decltype(s_tag)::value;
-      constexpr int KS = S >> 3, J = S & 7, SLOT = S % 3;
-      constexpr int YOUNGER = S == 0 ? 2 : (S <= 3 ? 6 : (S <= 13 ? 2 : 15 - S));
-      if constexpr (S == 0) lgkm_wait5<YOUNGER>(wf[0][0], wf[0][1], wf[0][2], wf[0][3], xf[SLOT]);
-      else if constexpr (S == 8) lgkm_wait5<YOUNGER>(wf[1][0], wf[1][1], wf[1][2], wf[1][3], xf[SLOT]);   // wf[1]: older, long back
-      else lgkm_wait1<YOUNGER>(xf[SLOT]);
-      if constexpr (CLIPMI_ABLATE & 4) {
-        asm volatile("" :: "v"(wf[KS][0]), "v"(wf[KS][1]), "v"(wf[KS][2]), "v"(wf[KS][3]), "v"(xf[SLOT]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if constexpr (FIRSTK && KS == 0)
-            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[KS][i], xf[SLOT], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          else
-            acc[i][J] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[KS][i], xf[SLOT], acc[i][J], 0, 0, 0);
+    uint32_t xa0 = sb + xo[0], xa1 = sb + xo[1], wa0 = sb + wo[0], wa1 = sb + wo[1];
+    f16x8 wf[4], xf[4];
+    auto phase = [&](auto p_tag) {
+      constexpr int P = decltype(p_tag)::value;
+      constexpr int KS = P >> 1, JH = P & 1;
+      // ---- load part
+      {
+        const uint32_t xa = KS ? xa1 : xa0;
+        ds_read128<(JH * 4 + 0) * 2048>(xf[0], xa);
+        ds_read128<(JH * 4 + 1) * 2048>(xf[1], xa);
+        ds_read128<(JH * 4 + 2) * 2048>(xf[2], xa);
+        ds_read128<(JH * 4 + 3) * 2048>(xf[3], xa);
+        if constexpr (JH == 0) {
+          const uint32_t wa = KS ? wa1 : wa0;
+          ds_read128<0>(wf[0], wa);
+          ds_read128<2048>(wf[1], wa);
+          ds_read128<4096>(wf[2], wa);
+          ds_read128<6144>(wf[3], wa);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);   // the read below overwrites xf[SLOT]: keep it behind the MFMAs that use the old value
-      if constexpr (S + 3 < 16) {
-        constexpr int S3 = S + 3;
-        if constexpr ((S3 >> 3) == 0) ds_read128<(S3 & 7) * 2048>(xf[SLOT], xa0);
-        else ds_read128<(S3 & 7) * 2048>(xf[SLOT], xa1);
+      if constexpr (MORE && !(CLIPMI_ABLATE & 2)) {
+        if constexpr (P == 0) {
+          stage_piece(std::integral_constant<int, 0>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 1>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 2>{}, xrs, wrs, buf ^ 1, kt + 1);
+        } else if constexpr (P == 1) {
+          stage_piece(std::integral_constant<int, 3>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 4>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 5>{}, xrs, wrs, buf ^ 1, kt + 1);
+        } else if constexpr (P == 2) {
+          stage_piece(std::integral_constant<int, 6>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 7>{}, xrs, wrs, buf ^ 1, kt + 1);
+        }
       }
-      if constexpr (S == 0) {
-        ds_read128<0>(wf[1][0], wa1);
-        ds_read128<2048>(wf[1][1], wa1);
-        ds_read128<4096>(wf[1][2], wa1);
-        ds_read128<6144>(wf[1][3], wa1);
+      static_assert(T::XI + T::WI == 8, "eight DMA pieces per wave and stage");
+      if constexpr (P == 3 && NST > 0) {
+        store_piece(HD + SLICE, 0, held[0][SLICE]);
+        store_piece(HD + SLICE, 1, held[1][SLICE]);
       }
-      // VMEM of this K-step, spread over its steps: the four stores of a held slice and the next stage's eight DMA pieces in
-      // the first half (the pieces have the second half to land)
-      if constexpr (SLICE >= 0 && S < TN) {   // first: the slice's registers are free for the rest of the K-step
-        if constexpr (!(CLIPMI_ABLATE & 1)) flush_held_piece(SLICE, S);
-      }
-      if constexpr (S < T::XI + T::WI) {
-        if constexpr (MORE && !(CLIPMI_ABLATE & 2)) stage_piece(s_tag, xrs, wrs, buf ^ 1, kt + 1);
+      if constexpr (JH == 0) lgkm_wait8<0>(xf[0], xf[1], xf[2], xf[3], wf[0], wf[1], wf[2], wf[3]);
+      else lgkm_wait4<0>(xf[0], xf[1], xf[2], xf[3]);
+      if constexpr (P == 3) {
+        if (grp == 1) wait_vmcnt<NST>();   // this wave's pieces of the next stage have landed (see RAW above)
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- compute part: registers only
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (CLIPMI_ABLATE & 4) {
+        asm volatile("" :: "v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(wf[3]), "v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(xf[3]));
+      } else {
+        // MFMAs as asm with the accumulator TIED to the destination: left to the builtin, hipcc's allocator sends the results of
+        // the first k-half to 64 fresh registers and brings them back in the second (v_mfma v[192:195], .., v[12:15] ...), which
+        // this kernel does not have -- it spilled the held outputs to scratch.  Back-to-back MFMAs on different accumulators, or
+        // accumulating in place, need no wait states; nothing but MFMAs reads an accumulator before the tile's epilogue.
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            if constexpr (FIRSTK && KS == 0)
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][JH * 4 + j]) : "v"(wf[i]), "v"(xf[j]));
+            else
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * 4 + j]) : "v"(wf[i]), "v"(xf[j]));
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (P == 3) {
+        if (grp == 0) wait_vmcnt<NST>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     };
-    step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});  step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});  step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
-    step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});  step(std::integral_constant<int, 8>{});
-    step(std::integral_constant<int, 9>{});  step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
-    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
-    step(std::integral_constant<int, 15>{});
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
   };
 
 #ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
 #endif
-  bool first_tile = true;
+  wait_vmcnt<0>();                 // the first tile's stage 0 and parameters
+  __builtin_amdgcn_s_barrier();
   while (true) {
 #ifdef CLIPMI_TUNING
     if (stamp) {
@@ -1597,25 +1646,24 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
     using I = std::integral_constant<int, -1>;
-    // K-step 0: the stage was prefetched before the previous tile's epilogue; its 4 * HD direct stores are younger
-    if (first_tile) kstep(I{}, std::integral_constant<int, 0>{}, yes, yes, 0);
-    else kstep(I{}, std::integral_constant<int, 4 * HD>{}, yes, yes, 0);
-    first_tile = false;
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 starts one part later
+    kstep(I{}, yes, yes, 0);
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
     }
 #endif
-    // a slice's stores are issued before the same K-step's last DMA pieces, so the next wait is vmcnt(0) for them too: they
-    // were sent a whole K-step earlier (K-step 1 also waits for the previous tile's direct stores: VMEM retires in order)
-    kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, no, yes, 1);
-    kstep(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, no, yes, 2);
-    kstep(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, no, yes, 3);
-    kstep(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, no, yes, 4);
-    static_assert(NHELD == 4, "K-steps 1..4 carry the held slices");
-    for (int kt = 5; kt < nk - 1; ++kt) kstep(I{}, std::integral_constant<int, 0>{}, no, yes, kt);   // K >= 10 K-steps (checked by the launcher)
-    kstep(I{}, std::integral_constant<int, 0>{}, no, no, nk - 1);
+    kstep(std::integral_constant<int, 0 < NHELD ? 0 : -1>{}, no, yes, 1);   // K-steps 1 .. NHELD carry the held slices
+    kstep(std::integral_constant<int, 1 < NHELD ? 1 : -1>{}, no, yes, 2);
+    kstep(std::integral_constant<int, 2 < NHELD ? 2 : -1>{}, no, yes, 3);
+    kstep(std::integral_constant<int, 3 < NHELD ? 3 : -1>{}, no, yes, 4);
+    kstep(std::integral_constant<int, 4 < NHELD ? 4 : -1>{}, no, yes, 5);
+    kstep(std::integral_constant<int, 5 < NHELD ? 5 : -1>{}, no, yes, 6);
+    for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt);   // K >= 10 K-steps (checked by the launcher)
+    kstep(I{}, no, no, nk - 1);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and group 0 waits out group 1's last compute part
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
 
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cn0 = n0;
@@ -1628,17 +1676,18 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #endif
     const int nvb = vb + gridDim.x;
     const bool has_next = nvb < a.nwg;
-    if (has_next) {   // the buffer that is NOT the last one read is free: the next tile's first stage goes there now
+    if (has_next) {   // the buffer that is NOT the last one read is free: the next tile's first stage goes there (below)
       vb = nvb;
       coords(vb, m0, n0);
       xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
       wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
       first_buf = last_buf ^ 1;
-      stage(xrs, wrs, first_buf, 0);
       params(m0, n0, par ^ 1);
     }
     // ---- element-wise epilogue (row / column parameters from LDS, DMA'd a whole tile ago): slices 0 .. HD-1 are stored at
-    // once, slices HD .. TM-1 go into `held`
+    // once, slices HD .. TM-1 go into `held`.  All parameters of the tile are read up front (the fragment registers are free
+    // now: 8 column vectors + 8 row pairs, one LDS round trip instead of one per slice), and the next tile's first stage is
+    // DMA'd one piece per slice, between the slices' arithmetic.
     ors = make_rsrc(out + (int64_t)cm0 * a.ldo + cn0, ((int64_t)(a.M - cm0) * a.ldo - cn0) * 2);
     hn0 = cn0;
     {
@@ -1647,37 +1696,59 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       const int er16 = le & 15, eg4 = le >> 4;
       const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM;
       const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
+      f32x4 bb[TN], gg[TN];
+      float2 pr[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nl = wave_n * 64 + eg4 * 4 + i * 16;
+        bb[i] = *reinterpret_cast<const f32x4*>(colp + nl);
+        gg[i] = *reinterpret_cast<const f32x4*>(colp + BN + nl);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) pr[j] = lnp[wave_m * T::WTM + j * 16 + er16];
+      auto piece = [&](auto p_tag) {
+        if (has_next) stage_piece(p_tag, xrs, wrs, first_buf, 0);
+      };
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #ifdef CLIPMI_TUNING
         if (a.knob & 8) break;
 #endif
-        const float2 pr = lnp[wave_m * T::WTM + j * 16 + er16];
-        const float rs = pr.x, mrs = pr.y;
-        // the column parameters are the same for every slice: left to itself hipcc loads all eight vectors once, keeps
-        // them across the whole conversion (32 registers the kernel does not have) and spills them.  An opaque copy of
-        // the lane's column offset makes every slice re-read its eight LDS vectors instead.
-        int nl0 = wave_n * 64 + eg4 * 4;
-        asm volatile("" : "+v"(nl0));
+        const float rs = pr[j].x, mrs = pr[j].y;
         f16x4 cv[TN];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          const int nl = nl0 + i * 16;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
-          const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + BN + nl);
-          f32x4 v = acc[i][j] * rs + (bb - mrs * gg);
+          f32x4 v = acc[i][j] * rs + (bb[i] - mrs * gg[i]);
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+            const f32x4 t = v * -2.4554669595930157f;   // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): packed where hipcc can
+            f32x4 e;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            for (int q = 0; q < 4; ++q) e[q] = __builtin_amdgcn_exp2f(t[q]);
+            const f32x4 d = e + 1.0f;
+            f32x4 r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = __builtin_amdgcn_rcpf(d[q]);
+            v = v * r;
           }
           cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         }
+        u32x4 pk[2];
+        pack_slice(cv, pk);
         if (j < HD) {
-          store_slice(j, cv);
+          store_piece(j, 0, pk[0]);
+          store_piece(j, 1, pk[1]);
         } else {
-#pragma unroll
-          for (int i = 0; i < TN; ++i) held[i][j - HD] = cv[i];
+          held[0][j - HD] = pk[0];
+          held[1][j - HD] = pk[1];
         }
+        if (j == 0) piece(std::integral_constant<int, 0>{});
+        if (j == 1) piece(std::integral_constant<int, 1>{});
+        if (j == 2) piece(std::integral_constant<int, 2>{});
+        if (j == 3) piece(std::integral_constant<int, 3>{});
+        if (j == 4) piece(std::integral_constant<int, 4>{});
+        if (j == 5) piece(std::integral_constant<int, 5>{});
+        if (j == 6) piece(std::integral_constant<int, 6>{});
+        if (j == 7) piece(std::integral_constant<int, 7>{});
         __builtin_amdgcn_sched_barrier(0);   // one 16-row slice at a time: the accumulators die as they are converted
       }
     }
@@ -1686,10 +1757,16 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     if (!has_next) break;
+    wait_vmcnt<0>();                 // the next tile's stage 0 and parameters (their pieces went out between the slices, the last one
+                                     // behind the direct stores)
+    __builtin_amdgcn_s_barrier();
   }
   // the last tile's held slices: nothing left to hide them behind
 #pragma unroll
-  for (int j = 0; j < NHELD; ++j) flush_held(j);
+  for (int j = 0; j < NHELD; ++j) {
+    store_piece(HD + j, 0, held[0][j]);
+    store_piece(HD + j, 1, held[1][j]);
+  }
 }
 
 template <int EPI>
