@@ -187,17 +187,40 @@ __global__ __launch_bounds__(256) void cast16_kernel(const half_t* __restrict__ 
   if (i < n) dst[i] = (TO)(float)src[i];
 }
 
-// out[r,:] = in[r,:] / ||in[r,:]||_2, one wave per row, fp32 math
+// out[r,:] = in[r,:] / ||in[r,:]||_2, one wave per row, fp32 math.
+// Summation order (the fused tail of logits.hip forms its norms in exactly this order: its normalised rows are bit-identical):
+// E % 8 == 0 and 16-byte aligned rows: a lane takes the 8-element chunks lane, lane + 64, ..., adds their squares in ascending
+// order with fused multiply-adds; otherwise element lane, lane + 64, ...; then the xor butterfly 32, 16, ..., 1.
 template <typename TI, typename TO = float>
-__global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int E) {
+__global__ __launch_bounds__(256) void l2norm_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int E, int vec8) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const TI* x = in + (int64_t)row * E;
   float ss = 0.f;
-  for (int e = lane; e < E; e += 64) {
-    const float v = (float)x[e];
-    ss += v * v;
+  auto load8 = [&](const TI* p8, float (&v)[8]) {
+    if constexpr (sizeof(TI) == 4) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(p8), q = *reinterpret_cast<const f32x4*>(p8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = p[e]; v[4 + e] = q[e]; }
+    } else {
+      const f16x8 h = *reinterpret_cast<const f16x8*>(p8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    }
+  };
+  if (vec8) {   // uniform
+    for (int c = lane; c < (E >> 3); c += 64) {
+      float v[8];
+      load8(x + c * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[e], v[e], ss);
+    }
+  } else {
+    for (int e = lane; e < E; e += 64) {
+      const float v = (float)x[e];
+      ss = __builtin_fmaf(v, v, ss);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -360,12 +383,13 @@ int launch_l2_normalize_to(const void* in, int in_dtype, void* out_, int out_dty
   CLIPMI_REQUIRE(in && out_, CLIPMI_ERR_ARG, "l2_normalize: null pointer");
   CLIPMI_REQUIRE(rows > 0 && E > 0, CLIPMI_ERR_SHAPE, "l2_normalize: bad shape");
   const dim3 grid((rows + 3) / 4);
+  const int vec8 = (E % 8 == 0 && (uintptr_t)in % 16 == 0) ? 1 : 0;   // 8-element chunks (see l2norm_kernel: the summation order)
   if (out_dtype == CLIPMI_F16) {   // the exchange format of the multi-GPU path (fp16 embeddings over xGMI)
     half_t* o16 = static_cast<half_t*>(out_);
     if (in_dtype == CLIPMI_F32)
-      hipLaunchKernelGGL((l2norm_kernel<float, half_t>), grid, dim3(256), 0, s, (const float*)in, o16, rows, E);
+      hipLaunchKernelGGL((l2norm_kernel<float, half_t>), grid, dim3(256), 0, s, (const float*)in, o16, rows, E, vec8);
     else if (in_dtype == CLIPMI_F16)
-      hipLaunchKernelGGL((l2norm_kernel<half_t, half_t>), grid, dim3(256), 0, s, (const half_t*)in, o16, rows, E);
+      hipLaunchKernelGGL((l2norm_kernel<half_t, half_t>), grid, dim3(256), 0, s, (const half_t*)in, o16, rows, E, vec8);
     else {
       set_error("l2_normalize: bad dtype %d", in_dtype);
       return CLIPMI_ERR_ARG;
@@ -375,9 +399,9 @@ int launch_l2_normalize_to(const void* in, int in_dtype, void* out_, int out_dty
   CLIPMI_REQUIRE(out_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "l2_normalize: bad output dtype %d", out_dtype);
   float* out = static_cast<float*>(out_);
   if (in_dtype == CLIPMI_F32)
-    hipLaunchKernelGGL(l2norm_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, rows, E);
+    hipLaunchKernelGGL(l2norm_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, rows, E, vec8);
   else if (in_dtype == CLIPMI_F16)
-    hipLaunchKernelGGL(l2norm_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)in, out, rows, E);
+    hipLaunchKernelGGL(l2norm_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)in, out, rows, E, vec8);
   else {
     set_error("l2_normalize: bad dtype %d", in_dtype);
     return CLIPMI_ERR_ARG;

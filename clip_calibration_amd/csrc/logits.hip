@@ -1,57 +1,85 @@
 // Tail of the hot path (SURVEY a-10..a-12), fp32 end to end so that logits match the fp32 oracle given the same features:
 //
 //   cosine_logits_kernel   logits[B,C] = scale * img_n @ txt_n^T        (zsclip.py:100-101; coop.py:215-217)
-//                          exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), operands straight from global/L2
+//                          fp16 matrix cores on hi/lo-split fp32 operands (fp32 accuracy), operands straight from global/L2
 //   row_calibrate_kernel   pred = argmax_c ; logits[i,:] *= dac_conf[pred]  (distanse_aware_calibration.py:49-58)
 //                          conf = max_c softmax(logits[i,:])               (vl_calibrator.py:91; vl_evaluator.py:68,83)
 //   ece_accumulate_kernel  per-bin (count, sum conf, sum correct)          (tools/metrics.py:90-130)
 //
 // HBM-bound: algorithmic bytes = 4*(B*E + C*E) read + 4*B*C written (+ 4*B*C re-read/re-written from L2 when DAC is on).
+#include <type_traits>
+
 #include "common.h"
 
 namespace clipmi {
 namespace {
 
-// One wave computes a 16(m) x 64(n) tile; a workgroup of 4 waves covers 16 x 256.  Lane l holds, for a 16-wide k step,
-// A[m = l&15][k0 + 4*(l>>4) .. +3] and B[n = l&15][same k] as one 16-byte load each; the four elements feed four
-// 16x16x4 MFMAs (any bijection of k onto (l>>4, element) is valid as long as A and B use the same one).
+// ---------------------------------------------------------------------------------------------------------------
+// The dot products of the tail on the fp16 matrix cores at fp32 accuracy: every fp32 operand is split into
+//     x = hi + lo,   hi = fp16(x),  lo = fp16(x - hi)          (|x| <= 1: L2-normalised features)
+// and a product block is accumulated (fp32 accumulators, v_mfma_f32_16x16x32_f16) as
+//     acc += hi_a . hi_b ;  acc += hi_a . lo_b ;  acc += lo_a . hi_b          (in this order, per 32-wide k-step)
+// The dropped lo.lo term and the residual of lo are ~2^-22 of a product: on scaled logits (|logit| <= 100, 512 terms of
+// ~1/512) that is ~1e-6 absolute, against 3e-4 allowed by the oracle tests -- and 3 MFMAs of the 2.5 PFLOP/s pipe replace 8
+// of the exact-f32 one (v_mfma_f32_16x16x4_f32, 1/16 of the rate): at B = 2048, C = 1000 the exact form alone needs 13.5 us of
+// matrix-pipe time, more than the whole 14.4 MB of the tail take to move at 1 TB/s.  An output element depends only on its
+// own row and column data and on the k order, never on where it sits in a tile: results are bit-identical between the fused
+// kernel, this kernel and any batch composition (the equivariance tests rely on it).
+// ---------------------------------------------------------------------------------------------------------------
+struct SplitFrag { f16x8 hi, lo; };
+__device__ __forceinline__ SplitFrag split8(const f32x4& p, const f32x4& q) {
+  SplitFrag s;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const half_t h0 = (half_t)p[e], h1 = (half_t)q[e];
+    s.hi[e] = h0;
+    s.hi[4 + e] = h1;
+    s.lo[e] = (half_t)(p[e] - (float)h0);
+    s.lo[4 + e] = (half_t)(q[e] - (float)h1);
+  }
+  return s;
+}
+__device__ __forceinline__ f32x4 split_mfma(const f16x8& a_hi, const f16x8& a_lo, const SplitFrag& b, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b.hi, acc, 0, 0, 0);
+  return acc;
+}
+
+// Separate-launch form (A/B aid and the shapes the fused kernel does not take): one wave = 16 rows x 16 classes, operands
+// straight from global memory.  Lane l holds row / class (l & 15), k = k0 + 8 (l >> 4) .. + 7 of a 32-wide step; E % 32 == 0
+// runs on the matrix cores, the remainder of other widths (E % 16 == 0) as an exact-f32 tail step of 16.
 __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
                                                             float scale, float* __restrict__ logits, int B, int C, int E) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 16;
-  const int n0 = blockIdx.y * 256 + wave * 64;
+  const int n0 = blockIdx.y * 64 + wave * 16;
   if (n0 >= C) return;  // wave-uniform
   const int r = lane & 15, g = lane >> 4;
   const int m = m0 + r < B ? m0 + r : B - 1;
-  const float* ap = img + (int64_t)m * E + g * 4;
-  const float* bp[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = n0 + t * 16 + r < C ? n0 + t * 16 + r : C - 1;
-    bp[t] = txt + (int64_t)n * E + g * 4;
+  const int n = n0 + r < C ? n0 + r : C - 1;
+  const float* ap = img + (int64_t)m * E + g * 8;
+  const float* bp = txt + (int64_t)n * E + g * 8;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k0 = 0;
+  for (; k0 + 32 <= E; k0 += 32) {
+    const SplitFrag a = split8(*reinterpret_cast<const f32x4*>(ap + k0), *reinterpret_cast<const f32x4*>(ap + k0 + 4));
+    const SplitFrag b = split8(*reinterpret_cast<const f32x4*>(bp + k0), *reinterpret_cast<const f32x4*>(bp + k0 + 4));
+    acc = split_mfma(a.hi, a.lo, b, acc);
   }
-  f32x4 acc[4];
+  if (k0 < E) {   // E % 32 == 16: one exact-f32 step (lane: k = k0 + 4 (l >> 4) .. + 3)
+    const f32x4 a = *reinterpret_cast<const f32x4*>(img + (int64_t)m * E + k0 + g * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(txt + (int64_t)n * E + k0 + g * 4);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < E; k0 += 16) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bp[t] + k0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[t], 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
   }
   // D layout: col = lane&15 (n), row = (lane>>4)*4 + reg (m)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = n0 + t * 16 + r;
-    if (n >= C) continue;
+  if (n0 + r < C) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int mm = m0 + g * 4 + e;
-      if (mm < B) logits[(int64_t)mm * C + n] = scale * acc[t][e];
+      if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc[e];
     }
   }
 }
@@ -146,153 +174,226 @@ __global__ __launch_bounds__(256) void ece_accumulate_kernel(const float* __rest
 //   pred = argmax; logits[i,:] *= dac[pred]    (distanse_aware_calibration.py:49-58)
 //   conf = max softmax(logits[i,:])            (vl_calibrator.py:91, vl_evaluator.py:68,83)
 //   ECE bin accumulation                       (tools/metrics.py:90-130)
-// Grid: (B/16) x (C/64) workgroups of 4 waves -- 256 workgroups at B = 256, C = 1000.  A workgroup normalises its 16
-// image rows into LDS (the arithmetic of l2norm_kernel, element for element: the row norm is a lane-strided sum and a
-// butterfly), each wave then runs a 16 x 16 tile of exact-f32 MFMAs (v_mfma_f32_16x16x4_f32, the k order of
-// cosine_logits_kernel) with its A fragments from LDS and its 16 text rows straight from L2, and stores its logits.
-// The workgroups of one 16-row block then draw a ticket; the LAST of them to arrive (agent-scope release before the
-// ticket, acquire after it: cdna_hip_programming.md Guideline 16, counter form) runs the row pass -- argmax, DAC
-// factor, softmax top-1, ECE bins -- over the block's 16 complete rows, one wave per row, with the arithmetic of
-// row_calibrate_kernel, and resets the ticket counter.  Results are bit-identical to the three-kernel path.
-// counters: ceil(B/16) int32, zero before the first launch, left zero by every launch.
+// Grid: (B/32) x (C/64) workgroups of 4 waves (512 at B = 2048, C = 1000; two per CU).  A workgroup
+//   0. starts the loads of its text fragments (each wave: its 16 classes, the first k-steps), then normalises its 32 image
+//      rows (the arithmetic of l2norm_kernel, element for element: lane-strided sum, butterfly) and leaves them in LDS ALREADY
+//      SPLIT into fp16 hi / lo halves (see split8 above), 16 bytes per lane and row chunk;
+//   1. runs, per wave, a 32 x 16 block of the product on the fp16 matrix cores (3 MFMAs per 16 x 16 x 32 step, fp32 accuracy):
+//      A fragments by ds_read_b128, text fragments from registers (split on the fly, next group of k-steps in flight);
+//   2. stores its 32 x 64 logits through an LDS tile as 16-byte write-through (sc1) stores;
+//   3. draws a ticket for its 32-row block; the LAST workgroup to arrive (agent-scope hand-off: cdna_hip_programming.md
+//      Guideline 16, counter form) runs the row pass -- argmax, DAC factor, softmax top-1, ECE bins -- over the block's 32
+//      complete rows, 8 per wave, with the arithmetic of row_calibrate_kernel, and resets the counter.
+// Results are bit-identical to the three-kernel path.  The first version (16-row blocks, exact-f32 MFMAs, text fragments read
+// from L2 one k-step ahead) took 24.7 us at B = 256 and 55.6 us at B = 2048 (260 GB/s): 13.5 us of that is the f32 matrix pipe
+// alone, the rest the 128 x 2 MB of text re-reads and a chain of dependent L2 round trips.
+// counters: ceil(B/32) int32 of the workspace, zero before the first launch, left zero by every launch.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool NORMALIZE, typename TI>
-__global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ img, const float* __restrict__ txt, float scale,
-                                                         const float* __restrict__ dac, float* logits, float* __restrict__ img_n_out,
-                                                         float* __restrict__ conf, int32_t* __restrict__ pred,
-                                                         const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
-                                                         int* counters, int B, int C, int E) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 16 rows of E floats, row stride E*4 + 16 bytes; then flag + wave partials
-  const int rs = E * 4 + 16;
-  int* flag = reinterpret_cast<int*>(smem + 16 * rs);
+constexpr int TAIL_TILE_LD = 64 + 4;        // floats per row of the LDS logits tile
+constexpr int tail_sbins_off(int rb) { return rb * TAIL_TILE_LD * 4 + 16; }
+
+// RB = image rows per workgroup: 32 for large batches (half the text re-reads from L2), 16 for small ones (twice the
+// workgroups, and a row pass of 4 instead of 8 rows per wave on the critical path of a launch that is all latency)
+template <bool NORMALIZE, typename TI, int RB>
+__global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict__ img, const float* __restrict__ txt, float scale,
+                                                            const float* __restrict__ dac, float* logits, float* __restrict__ img_n_out,
+                                                            float* __restrict__ conf, int32_t* __restrict__ pred,
+                                                            const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
+                                                            int* counters, int B, int C, int E, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rsb = E * 2 + 16;                         // bytes per fp16 row of an LDS operand image (16-byte pad)
+  char* hi_s = smem;
+  constexpr int RPW = RB / 4;                         // rows per wave in the row-wise phases
+  constexpr int NRB = RB / 16;                        // 16-row MFMA blocks per wave
+  char* lo_s = smem + RB * rsb;
+  int* flag = reinterpret_cast<int*>(smem + lds_bytes - 16);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int m0 = blockIdx.x * 16;
+  const int m0 = blockIdx.x * RB;
   const int n0 = blockIdx.y * 64 + wave * 16;
+  const int r = lane & 15, g = lane >> 4;
+  const int nsteps = E >> 5;                          // 32-wide k-steps (E % 64 == 0)
+  constexpr int G = 4;                                // k-steps per register group of text fragments
 
-  // ---- phase 0: the 16 image rows -> LDS (normalised), 4 rows per wave, all four rows' loads in flight together (row after
-  //      row this phase alone was eight dependent round trips to L2).  Arithmetic of l2norm_kernel: lane-strided sum, butterfly.
-  if (E <= 1024) {   // uniform: a lane's <= 16 elements of each row stay in registers between the norm and the scaling
-    float xv[4][16];
+  // ---- text fragments of the first group: in flight during phase 0
+  const bool cols_live = n0 < C;                      // wave-uniform
+  const float* bp = txt + (int64_t)(n0 + r < C ? n0 + r : C - 1) * E + g * 8;
+  f32x4 b0[G][2], b1[G][2];
+  auto load_group = [&](f32x4 (&dst)[G][2], int s0) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int rl = wave * 4 + rr;
-        const int row = m0 + rl < B ? m0 + rl : B - 1;
-        xv[rr][t] = lane + 64 * t < E ? (float)img[(int64_t)row * E + lane + 64 * t] : 0.f;
-      }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int rl = wave * 4 + rr;
-      const int row = m0 + rl < B ? m0 + rl : B - 1;
-      float inv = 1.0f;
-      if constexpr (NORMALIZE) {
-        float ss = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-          if (lane + 64 * t < E) ss += xv[rr][t] * xv[rr][t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        inv = 1.0f / sqrtf(ss);
-      }
-      float* dst = reinterpret_cast<float*>(smem + rl * rs);
-      const bool keep = img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B;   // wave-uniform
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (lane + 64 * t < E) {
-          const float v = NORMALIZE ? xv[rr][t] * inv : xv[rr][t];
-          dst[lane + 64 * t] = v;
-          if (keep) img_n_out[(int64_t)row * E + lane + 64 * t] = v;
-        }
+    for (int u = 0; u < G; ++u) {
+      if (s0 + u < nsteps) {                          // uniform
+        dst[u][0] = *reinterpret_cast<const f32x4*>(bp + (s0 + u) * 32);
+        dst[u][1] = *reinterpret_cast<const f32x4*>(bp + (s0 + u) * 32 + 4);
       }
     }
-  } else {
-    for (int rr = 0; rr < 4; ++rr) {
-      const int rl = wave * 4 + rr;
-      const int row = m0 + rl < B ? m0 + rl : B - 1;
-      const TI* x = img + (int64_t)row * E;
-      float inv = 1.0f;
+  };
+  // (requesting ALL 16 k-steps' fragments here -- 128 registers, one trip -- was measured 2x SLOWER at B >= 1024: VMEM returns in
+  // order, so phase 0's image rows then wait behind 32 text loads per lane, and every workgroup floods L2 at once)
+
+  // ---- phase 0: the RB image rows, RPW per wave, ONE trip to memory: a lane takes 8 consecutive elements per 512-element
+  //      stripe (16 / 32-byte loads), sums their squares in ascending order (l2norm_kernel's order for E % 8 == 0: fused
+  //      multiply-adds, then the butterfly) and writes x * inv back out and, split, into LDS as 16 bytes per lane.
+  {
+    auto load8 = [&](const TI* x, f32x4& p, f32x4& q) {
+      if constexpr (sizeof(TI) == 4) {
+        p = *reinterpret_cast<const f32x4*>(x);
+        q = *reinterpret_cast<const f32x4*>(x + 4);
+      } else {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(x);
+        p = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        q = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+      }
+    };
+    auto emit = [&](int rl, int row, int c, f32x4 p, f32x4 q, float inv) {
       if constexpr (NORMALIZE) {
-        float ss = 0.f;
-        for (int e = lane; e < E; e += 64) {
-          const float v = (float)x[e];
-          ss += v * v;
+        p *= inv;
+        q *= inv;
+      }
+      if (img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B) {   // wave-uniform
+        float* o = img_n_out + (int64_t)row * E + c * 8;
+        *reinterpret_cast<f32x4*>(o) = p;
+        *reinterpret_cast<f32x4*>(o + 4) = q;
+      }
+      const SplitFrag sp = split8(p, q);
+      *reinterpret_cast<f16x8*>(hi_s + rl * rsb + c * 16) = sp.hi;
+      *reinterpret_cast<f16x8*>(lo_s + rl * rsb + c * 16) = sp.lo;
+    };
+    const int nch = E >> 3;                           // 8-element chunks per row
+    if (nch <= 128) {   // uniform (E <= 1024): every row of the wave in registers between the norm and the scaling
+      constexpr int NU = 2;                           // 512-element stripes per row held in registers
+      f32x4 xp[RPW][NU], xq[RPW][NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int rl = wave * RPW + rr;
+          const int row = m0 + rl < B ? m0 + rl : B - 1;
+          if (lane + 64 * u < nch) load8(img + (int64_t)row * E + (lane + 64 * u) * 8, xp[rr][u], xq[rr][u]);
+        }
+      if (cols_live) load_group(b0, 0);   // behind the image rows (VMEM returns in order): in flight during the norms and the split
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int rl = wave * RPW + rr;
+        const int row = m0 + rl < B ? m0 + rl : B - 1;
+        float inv = 1.0f;
+        if constexpr (NORMALIZE) {
+          float ss = 0.f;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            if (lane + 64 * u < nch) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(xp[rr][u][e], xp[rr][u][e], ss);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(xq[rr][u][e], xq[rr][u][e], ss);
+            }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+          inv = 1.0f / sqrtf(ss);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        inv = 1.0f / sqrtf(ss);
+        for (int u = 0; u < NU; ++u)
+          if (lane + 64 * u < nch) emit(rl, row, lane + 64 * u, xp[rr][u], xq[rr][u], inv);
       }
-      float* dst = reinterpret_cast<float*>(smem + rl * rs);
-      const bool keep = img_n_out != nullptr && blockIdx.y == 0 && m0 + rl < B;   // wave-uniform
-      for (int e = lane; e < E; e += 64) {
-        const float v = NORMALIZE ? (float)x[e] * inv : (float)x[e];
-        dst[e] = v;
-        if (keep) img_n_out[(int64_t)row * E + e] = v;
+    } else {
+      if (cols_live) load_group(b0, 0);
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int rl = wave * RPW + rr;
+        const int row = m0 + rl < B ? m0 + rl : B - 1;
+        const TI* x = img + (int64_t)row * E;
+        float inv = 1.0f;
+        if constexpr (NORMALIZE) {
+          float ss = 0.f;
+          for (int c = lane; c < nch; c += 64) {
+            f32x4 p, q;
+            load8(x + c * 8, p, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(p[e], p[e], ss);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = __builtin_fmaf(q[e], q[e], ss);
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+          inv = 1.0f / sqrtf(ss);
+        }
+        for (int c = lane; c < nch; c += 64) {
+          f32x4 p, q;
+          load8(x + c * 8, p, q);
+          emit(rl, row, c, p, q, inv);
+        }
       }
     }
   }
   __syncthreads();
 
-  // ---- phase 1: 16 x 16 tile per wave
-  const int r = lane & 15, g = lane >> 4;
-  f32x4 acc_out = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (n0 < C) {   // wave-uniform
-    const int n = n0 + r < C ? n0 + r : C - 1;
-    const float* bp = txt + (int64_t)n * E + g * 4;
-    const char* ap = smem + r * rs + g * 16;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // E % 64 == 0: 64-wide steps, the text fragments of step k+1 are loaded (from L2) while the 16 MFMAs of step k run --
-    // without the explicit second register set the loop is one L2 round trip per step
-    f32x4 bn[4];
+  // ---- phase 1: RB x 16 block per wave
+  f32x4 acc[NRB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp + u * 16);
-    for (int k0 = 0; k0 < E; k0 += 64) {
-      f32x4 b[4], a[4];
+  for (int rb = 0; rb < NRB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (cols_live) {
+    const char* ah = hi_s + r * rsb + g * 16;
+    const char* al = lo_s + r * rsb + g * 16;
+    auto run_group = [&](const f32x4 (&bq)[G][2], int s0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = bn[u];
-      if (k0 + 64 < E) {
+      for (int u = 0; u < G; ++u) {
+        if (s0 + u < nsteps) {                        // uniform
+          const SplitFrag b = split8(bq[u][0], bq[u][1]);
+          const int kb = (s0 + u) * 64;               // byte offset of the k-step inside a row
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp + k0 + 64 + u * 16);
+          for (int rb = 0; rb < NRB; ++rb) {
+            const f16x8 a_hi = *reinterpret_cast<const f16x8*>(ah + rb * 16 * rsb + kb);
+            const f16x8 a_lo = *reinterpret_cast<const f16x8*>(al + rb * 16 * rsb + kb);
+            acc[rb] = split_mfma(a_hi, a_lo, b, acc[rb]);
+          }
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(ap + (k0 + u * 16) * 4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+    };
+    {
+      for (int s0 = 0; s0 < nsteps; s0 += 2 * G) {
+        if (s0 + G < nsteps) load_group(b1, s0 + G);
+        run_group(b0, s0);
+        if (s0 + 2 * G < nsteps) load_group(b0, s0 + 2 * G);
+        if (s0 + G < nsteps) run_group(b1, s0 + G);
+      }
     }
-    acc_out = acc;
   }
-  // ---- the workgroup's 16 x 64 logits tile.  Rows 16-byte aligned (C % 4 == 0): through an LDS tile, ONE 16-byte
-  //      write-through (sc1) store per thread -- whole 64-byte row pieces, and no release fence is needed for the hand-off
+  // ---- phase 2: the workgroup's 32 x 64 logits tile.  Rows 16-byte aligned (C % 4 == 0): through an LDS tile, two 16-byte
+  //      write-through (sc1) stores per thread -- whole 64-byte row pieces, and no release fence is needed for the hand-off
   //      below (cdna_hip_programming.md Guideline 16, R1).  Otherwise: 4-byte stores from the accumulator layout + a release.
   const bool wide = (C & 3) == 0;   // uniform
   if (wide) {
     __syncthreads();                // every wave is done reading the image rows: the tile takes their place
-    float* tile = reinterpret_cast<float*>(smem);   // [16][64 + 4] floats
+    float* tile = reinterpret_cast<float*>(smem);
     // D layout: col = lane&15 (n), row = (lane>>4)*4 + reg (m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) tile[(g * 4 + e) * 68 + wave * 16 + r] = scale * acc_out[e];
-    __syncthreads();
-    const int trow = threadIdx.x >> 4, tq = threadIdx.x & 15;
-    const int mm = m0 + trow, nn = blockIdx.y * 64 + tq * 4;
-    if (mm < B && nn < C) {         // C % 4 == 0: a 4-column piece is entirely inside or outside
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * 68 + tq * 4);
-      const __amdgpu_buffer_rsrc_t lrs = make_rsrc(logits, (int64_t)B * C * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
-    }
-  } else if (n0 < C && n0 + r < C) {
+    for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int mm = m0 + g * 4 + e;
-      if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc_out[e];
+      for (int e = 0; e < 4; ++e) tile[(rb * 16 + g * 4 + e) * TAIL_TILE_LD + wave * 16 + r] = scale * acc[rb][e];
+    __syncthreads();
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t lrs = make_rsrc(logits, (int64_t)B * C * 4);
+#pragma unroll
+    for (int h = 0; h < NRB; ++h) {
+      const int pidx = h * 256 + threadIdx.x;
+      const int trow = pidx >> 4, tq = pidx & 15;
+      const int mm = m0 + trow, nn = blockIdx.y * 64 + tq * 4;
+      if (mm < B && nn < C) {       // C % 4 == 0: a 4-column piece is entirely inside or outside
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * TAIL_TILE_LD + tq * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
+      }
     }
+  } else if (cols_live && n0 + r < C) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int mm = m0 + rb * 16 + g * 4 + e;
+        if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc[rb][e];
+      }
   }
   if (!dac && !conf && !pred && !bins) return;   // logits only (kernel argument: uniform)
 
-  // ---- phase 2: ticket; the last workgroup of this row block owns the row pass over the logits the others stored
+  // ---- phase 3: ticket; the last workgroup of this row block owns the row pass over the logits the others stored
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -311,97 +412,97 @@ __global__ __launch_bounds__(256) void fused_tail_kernel(const TI* __restrict__ 
   }
   __syncthreads();
   if (!*flag) return;
-  // ECE bins of this row block: summed in LDS first (the image-row region is free by now), then at most 3 * (n_bins + 1)
-  // global atomics per row block -- one set of three per ROW on a dozen hot addresses serialised the whole grid
-  // (B = 2048: 41 us of the launch).
-  double* sbins = reinterpret_cast<double*>(smem + 8192);
+  // ECE bins of this row block: summed in LDS first, then at most 3 * (n_bins + 1) global atomics per row block -- one set of
+  // three per ROW on a dozen hot addresses serialised the whole grid (B = 2048: 41 us of the launch).
+  double* sbins = reinterpret_cast<double*>(smem + tail_sbins_off(RB));
   if (bins) {
     for (int t = threadIdx.x; t < 3 * (n_bins + 1); t += 256) sbins[t] = 0.0;
     __syncthreads();
   }
-  // the wave's four rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same butterflies), with
+  // the wave's RPW rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same butterflies), with
   // every load of the pass in flight at once.  C <= 1024: a lane's 16 elements of each row stay in registers between the
-  // argmax and the softmax pass (one trip to L2 / HBM instead of two chains of dependent round trips -- done one row after
-  // the other with rolled loops this pass made the fused launch slower than the three launches it replaces: 43 us against
-  // 25 + 9 + 5 in rocprof).  Larger C: the same arithmetic with the two passes reading memory.
-  const int row0 = m0 + wave * 4;
-  float* lr[4];
-  float best[4], fac[4], mx[4], se[4];
-  int bi[4];
+  // argmax and the softmax pass (one trip to L2 instead of two chains of dependent round trips).  Larger C: the same
+  // arithmetic with the two passes reading memory.
+  {
+    const int row0 = m0 + wave * RPW;
+    float* lr[RPW];
+    float best[RPW], fac[RPW], mx[RPW], se[RPW];
+    int bi[RPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = row0 + q < B ? row0 + q : B - 1;   // clamped rows recompute row B-1 and are not written
-    lr[q] = logits + (int64_t)row * C;
-    best[q] = -INFINITY;
-    bi[q] = 0x7fffffff;
-    se[q] = 0.f;
-  }
-  auto finish_argmax = [&](int q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best[q], o, 64);
-      const int oi = __shfl_xor(bi[q], o, 64);
-      if (ob > best[q] || (ob == best[q] && oi < bi[q])) { best[q] = ob; bi[q] = oi; }
+    for (int q = 0; q < RPW; ++q) {
+      const int row = row0 + q < B ? row0 + q : B - 1;   // clamped rows recompute row B-1 and are not written
+      lr[q] = logits + (int64_t)row * C;
+      best[q] = -INFINITY;
+      bi[q] = 0x7fffffff;
+      se[q] = 0.f;
     }
-    if (bi[q] == 0x7fffffff) bi[q] = 0;
-    fac[q] = dac ? dac[bi[q]] : 1.0f;
-    mx[q] = best[q] * fac[q];
-  };
-  if (C <= 1024) {   // uniform
-    float v[4][16];
+    auto finish_argmax = [&](int q) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q][t] = lane + 64 * t < C ? lr[q][lane + 64 * t] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best[q], o, 64);
+        const int oi = __shfl_xor(bi[q], o, 64);
+        if (ob > best[q] || (ob == best[q] && oi < bi[q])) { best[q] = ob; bi[q] = oi; }
+      }
+      if (bi[q] == 0x7fffffff) bi[q] = 0;
+      fac[q] = dac ? dac[bi[q]] : 1.0f;
+      mx[q] = best[q] * fac[q];
+    };
+    if (C <= 1024) {   // uniform
+      float v[RPW][16];
 #pragma unroll
       for (int t = 0; t < 16; ++t)
-        if (lane + 64 * t < C && v[q][t] > best[q]) { best[q] = v[q][t]; bi[q] = lane + 64 * t; }
-      finish_argmax(q);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (lane + 64 * t < C) {
-          const float x = v[q][t] * fac[q];
-          if (dac && row0 + q < B) lr[q][lane + 64 * t] = x;
+        for (int q = 0; q < RPW; ++q) v[q][t] = lane + 64 * t < C ? lr[q][lane + 64 * t] : 0.f;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (lane + 64 * t < C && v[q][t] > best[q]) { best[q] = v[q][t]; bi[q] = lane + 64 * t; }
+        finish_argmax(q);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          if (lane + 64 * t < C) {
+            const float x = v[q][t] * fac[q];
+            if (dac && row0 + q < B) lr[q][lane + 64 * t] = x;
+            se[q] += __expf(x - mx[q]);
+          }
+        }
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const float x = lr[q][c];
+          if (x > best[q]) { best[q] = x; bi[q] = c; }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) finish_argmax(q);
+      for (int c = lane; c < C; c += 64) {
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+          const float x = lr[q][c] * fac[q];
+          if (dac && row0 + q < B) lr[q][c] = x;
           se[q] += __expf(x - mx[q]);
         }
       }
     }
-  } else {
-    for (int c = lane; c < C; c += 64) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float x = lr[q][c];
-        if (x > best[q]) { best[q] = x; bi[q] = c; }
-      }
-    }
+    for (int q = 0; q < RPW; ++q) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) finish_argmax(q);
-    for (int c = lane; c < C; c += 64) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float x = lr[q][c] * fac[q];
-        if (dac && row0 + q < B) lr[q][c] = x;
-        se[q] += __expf(x - mx[q]);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) se[q] += __shfl_xor(se[q], o, 64);
-    const int row = row0 + q;
-    if (lane == 0 && row < B) {
-      const float cf = 1.0f / se[q];
-      if (conf) conf[row] = cf;
-      if (pred) pred[row] = bi[q];
-      if (bins) {
-        const double x = (double)cf;
-        const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
-        atomicAdd(&sbins[b], 1.0);
-        atomicAdd(&sbins[nb1 + b], x);
-        atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)bi[q]) ? 1.0 : 0.0);
+      for (int o = 32; o > 0; o >>= 1) se[q] += __shfl_xor(se[q], o, 64);
+      const int row = row0 + q;
+      if (lane == 0 && row < B) {
+        const float cf = 1.0f / se[q];
+        if (conf) conf[row] = cf;
+        if (pred) pred[row] = bi[q];
+        if (bins) {
+          const double x = (double)cf;
+          const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
+          atomicAdd(&sbins[b], 1.0);
+          atomicAdd(&sbins[nb1 + b], x);
+          atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)bi[q]) ? 1.0 : 0.0);
+        }
       }
     }
   }
@@ -420,7 +521,7 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
   CLIPMI_REQUIRE(img_n && txt_n && logits, CLIPMI_ERR_ARG, "logits: null pointer (img_n, txt_n and logits are required)");
   CLIPMI_REQUIRE(B > 0 && C > 0 && E > 0 && E % 16 == 0, CLIPMI_ERR_SHAPE, "logits: B=%d C=%d E=%d unsupported (E %% 16 == 0)", B, C, E);
   CLIPMI_REQUIRE((uintptr_t)img_n % 16 == 0 && (uintptr_t)txt_n % 16 == 0, CLIPMI_ERR_ARG, "logits: features must be 16-byte aligned");
-  hipLaunchKernelGGL(cosine_logits_kernel, dim3((B + 15) / 16, (C + 255) / 256), dim3(256), 0, s, img_n, txt_n, scale, logits, B, C, E);
+  hipLaunchKernelGGL(cosine_logits_kernel, dim3((B + 15) / 16, (C + 63) / 64), dim3(256), 0, s, img_n, txt_n, scale, logits, B, C, E);
   int rc = check_launch("cosine_logits_kernel");
   if (rc != CLIPMI_OK) return rc;
   if (dac_conf || conf || pred) rc = launch_calibrate_rows(logits, dac_conf, conf, pred, B, C, s);
@@ -442,8 +543,12 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   CLIPMI_REQUIRE((uintptr_t)img % 16 == 0 && (uintptr_t)txt_n % 16 == 0, CLIPMI_ERR_ARG, "fused_tail: features must be 16-byte aligned");
   CLIPMI_REQUIRE(!bins || (labels && n_bins > 0 && n_bins <= 1024), CLIPMI_ERR_ARG, "fused_tail: ECE bins need labels and 1 <= n_bins <= 1024");
   CLIPMI_REQUIRE(normalize || !img_n_out, CLIPMI_ERR_ARG, "fused_tail: img_n_out only with normalize");
-  const int lds = 16 * (E * 4 + 16) + 16;
-  const bool fits = E % 64 == 0 && lds <= 160 * 1024 && (!bins || 8192 + 3 * (n_bins + 1) * 8 <= 16 * (E * 4 + 16));
+  // LDS: the two split operand images (RB rows x (2 E + 16) bytes each), later overlaid by the logits tile and the ECE bins
+  const int rb = B <= 512 ? 16 : 32;
+  const int lds_ops = 2 * rb * (E * 2 + 16);
+  const int lds_post = tail_sbins_off(rb) + (bins ? 3 * (n_bins + 1) * 8 : 0);
+  const int lds = ((lds_ops > lds_post ? lds_ops : lds_post) + 15) / 16 * 16 + 16;   // + the flag
+  const bool fits = E % 64 == 0 && lds <= 160 * 1024;
   if (options().tail_unfused.load(std::memory_order_relaxed) == 1 || !fits) {
     // the same arithmetic as separate launches (A/B aid; also shapes the fused kernel does not take)
     int rc;
@@ -464,22 +569,28 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   }
   CLIPMI_REQUIRE(workspace && workspace_bytes >= fused_tail_workspace_bytes(B, C), CLIPMI_ERR_WORKSPACE,
                  "fused_tail: workspace too small (%zu < %zu)", workspace_bytes, fused_tail_workspace_bytes(B, C));
-  const dim3 grid((B + 15) / 16, (C + 63) / 64);
+  const dim3 grid((B + rb - 1) / rb, (C + 63) / 64);
   CLIPMI_REQUIRE(grid.y <= 65535, CLIPMI_ERR_SHAPE, "fused_tail: too many classes");
   int* counters = static_cast<int*>(workspace);
   auto go = [&](auto kernel, DeviceOnce& once, auto* typed) {
     ensure_dynamic_lds(kernel, lds, once);
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, typed, txt_n, scale, dac_conf, logits, img_n_out, conf, pred, labels, bins, n_bins,
-                       counters, B, C, E);
+                       counters, B, C, E, lds);
   };
-  static DeviceOnce once[4];
+  static DeviceOnce once[16];
   const half_t* img16 = static_cast<const half_t*>(img_);
+  auto pick = [&](auto norm_tag, auto* typed, int slot) {
+    constexpr bool NRM = decltype(norm_tag)::value;
+    using TI = std::remove_cv_t<std::remove_pointer_t<decltype(typed)>>;
+    if (rb == 32) go(fused_tail_kernel<NRM, TI, 32>, once[slot * 2 + 1], typed);
+    else go(fused_tail_kernel<NRM, TI, 16>, once[slot * 2], typed);
+  };
   if (img_dtype == CLIPMI_F32) {
-    if (normalize) go(fused_tail_kernel<true, float>, once[0], img);
-    else go(fused_tail_kernel<false, float>, once[1], img);
+    if (normalize) pick(std::true_type{}, img, 0);
+    else pick(std::false_type{}, img, 1);
   } else {
-    if (normalize) go(fused_tail_kernel<true, half_t>, once[2], img16);
-    else go(fused_tail_kernel<false, half_t>, once[3], img16);
+    if (normalize) pick(std::true_type{}, img16, 2);
+    else pick(std::false_type{}, img16, 3);
   }
   return check_launch("fused_tail_kernel");
 }
