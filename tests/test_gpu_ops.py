@@ -72,6 +72,41 @@ def test_gemm_tile_variants(ops, clipmi_option, variant, M, N, K, epi):
     test_gemm(ops, M, N, K, epi)
 
 
+def test_gemm_stream_kernel_race_screen(ops, clipmi_option):
+    """The ping-pong persistent GEMM (gemm_stream = 1, the default for multi-round fp16-out GEMMs; gemm.hip gemm_stream_kernel)
+    hands LDS stages between two wave groups that run one phase apart, with counted vmcnt / lgkmcnt waits and LDS-DMA in flight
+    across barriers.  A misplaced wait shows up as a rare wrong tile, so: the image tower's c_fc shape, 60 back-to-back launches
+    on changing operands with an HBM-bound stream queued in front of every third (uneven load).  With the bias epilogue the
+    kernel shares the one-tile-per-workgroup kernel's arithmetic (same K order, same MFMA) and must match it bit for bit; with
+    QuickGELU the two compilations contract the element-wise math differently (a 1-ulp difference on ~3e-5 of the elements), so
+    that arm checks run-to-run identity plus closeness."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 50432, 3072, 768
+    a0 = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    filler = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    bad = 0
+    for it in range(20):
+        a = torch.roll(a0, shifts=it * 37, dims=0)
+        epi = _lib.EPI_BIAS if it % 2 == 0 else _lib.EPI_BIAS_QUICKGELU
+        clipmi_option("gemm_stream", 0)
+        ref = ops.gemm_f16(a, w, bias, epilogue=epi, out_dtype=torch.float16)
+        clipmi_option("gemm_stream", 1)
+        first = None
+        for rep in range(3):
+            if (it + rep) % 3 == 0:
+                filler.add_(1)
+            out = ops.gemm_f16(a, w, bias, epilogue=epi, out_dtype=torch.float16)
+            if epi == _lib.EPI_BIAS:
+                bad += int(not torch.equal(out, ref))
+            else:
+                first = out.clone() if first is None else first
+                ok = torch.equal(out, first) and float((out.float() - ref.float()).abs().max()) <= 2 ** -8 and int((out != ref).sum()) < 1e-4 * out.numel()
+                bad += int(not ok)
+    assert bad == 0, f"{bad} of 60 launches differ"
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from clip_calibration_amd._lib import ClipmiError
     a = torch.zeros(8, 48, dtype=torch.float16, device="cuda")
