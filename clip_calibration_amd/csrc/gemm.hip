@@ -1363,6 +1363,9 @@ __device__ __forceinline__ void lgkm_wait5(f16x8& a, f16x8& b, f16x8& c, f16x8& 
 #ifndef CLIPMI_STREAM_HD
 #define CLIPMI_STREAM_HD 2
 #endif
+#ifndef CLIPMI_STREAM_PREFETCH
+#define CLIPMI_STREAM_PREFETCH 1
+#endif
 using TStream = Tile<256, 256, 2, 4, 2>;
 
 template <int EPI>
@@ -1741,6 +1744,12 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
           held[0][j - HD] = pk[0];
           held[1][j - HD] = pk[1];
         }
+#if CLIPMI_STREAM_PREFETCH == 1   // two pieces behind each of the first four slices: the last one has half the conversion to land
+        if (j == 0) { piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{}); }
+        if (j == 1) { piece(std::integral_constant<int, 2>{}); piece(std::integral_constant<int, 3>{}); }
+        if (j == 2) { piece(std::integral_constant<int, 4>{}); piece(std::integral_constant<int, 5>{}); }
+        if (j == 3) { piece(std::integral_constant<int, 6>{}); piece(std::integral_constant<int, 7>{}); }
+#else
         if (j == 0) piece(std::integral_constant<int, 0>{});
         if (j == 1) piece(std::integral_constant<int, 1>{});
         if (j == 2) piece(std::integral_constant<int, 2>{});
@@ -1749,6 +1758,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         if (j == 5) piece(std::integral_constant<int, 5>{});
         if (j == 6) piece(std::integral_constant<int, 6>{});
         if (j == 7) piece(std::integral_constant<int, 7>{});
+#endif
         __builtin_amdgcn_sched_barrier(0);   // one 16-row slice at a time: the accumulators die as they are converted
       }
     }
