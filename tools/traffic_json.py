@@ -28,7 +28,7 @@ def rows(directory):
 
 
 def classify(rs):
-    """Kernel_Name -> role, from the template arguments gemm_f16_kernel<Tile<..>, EPI, OUT_F32> (EPI 1 bias = in-proj,
+    """Kernel_Name -> role, from the template arguments gemm_f16_kernel<Tile<..>, EPI, OUT_F32> / gemm_stream_kernel<EPI> (EPI 1 bias = in-proj,
     2 QuickGELU = c_fc, 101 / 102 residual fold = out-proj and c_proj alternating)."""
     per = defaultdict(list)
     alt = defaultdict(int)
@@ -39,6 +39,9 @@ def classify(rs):
         grid = int(r.get("Grid_Size", 0) or 0)
         args = name.split(">,")[-1] if ">," in name else ""
         epi = args.split(",")[0].strip() if args else ""
+        if "gemm_stream_kernel<" in name:   # the ping-pong persistent kernel (default for in-proj / c_fc): gemm_stream_kernel<EPI>, one workgroup per CU
+            epi = name.split("gemm_stream_kernel<")[1].split(">")[0].strip()
+            grid = 256 * 1000
         if epi == "1" and grid >= 256 * 1000:
             per["in_proj"].append(float(r["Counter_Value"]))
         elif epi == "2":
