@@ -135,7 +135,9 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
  * clipmi_l2_normalize + clipmi_logits + clipmi_ece_accumulate (the ECE sums of confidences up to the order of their atomics).  E % 64 == 0 and E <= 2048 run fused; other shapes, and option
  * tail_unfused = 1, run the separate launches (which need img_n_out or fp32 normalised input, and conf + pred when bins are given).
  * workspace: clipmi_fused_tail_workspace_bytes(B, C) bytes of device memory that is ZERO before the first launch; every launch
- * leaves it zero again (ticket counters, one int32 per 16 image rows).  Re-zero it after a launch that failed. */
+ * leaves it zero again (ticket counters: room for one int32 per 16 image rows; one per 16- or 32-row block is used).  Re-zero it
+ * after a launch that failed.  Features must be finite with |x| <= 65504 (L2-normalised ones are <= 1): the products run on the
+ * fp16 matrix cores with every fp32 operand split into fp16 hi + lo halves, ~1e-6 absolute on logits of scale 100. */
 size_t clipmi_fused_tail_workspace_bytes(int B, int C);
 int clipmi_fused_tail(const void* img, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins,
