@@ -1329,7 +1329,7 @@ int launch_defer(KArgs k, hipStream_t s) {
 // With 8 waves a wave has 256 registers: 128 accumulators + 64 held outputs + 48 operand fragments fit (the 16-wave
 // geometry has 128 per wave: 64 + 32 held + 24 fragments + addresses do not).  The K-steps that carry a store slice are
 // unrolled (straight-line code: hipcc's waitcnt pass keeps counted lgkmcnt waits), the remaining ones run in a loop.
-// Needs K >= 10 * 64, an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
+// Needs K >= 8 * 64 (K-steps 1 .. 6 carry the held slices of the previous tile, the last K-step issues no DMA), an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
 // ---------------------------------------------------------------------------------------------------------------
 // LDS fragment reads as inline asm (pinned where they are written; hipcc's waitcnt pass does not see them) and the counted
 // waits that name their destinations (cdna_hip_programming.md §5.7, form (ii)).
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     kstep(std::integral_constant<int, 3 < NHELD ? 3 : -1>{}, no, yes, 4);
     kstep(std::integral_constant<int, 4 < NHELD ? 4 : -1>{}, no, yes, 5);
     kstep(std::integral_constant<int, 5 < NHELD ? 5 : -1>{}, no, yes, 6);
-    for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt);   // K >= 10 K-steps (checked by the launcher)
+    for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt);   // K >= 8 K-steps (checked by the launcher)
     kstep(I{}, no, no, nk - 1);
     if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and group 0 waits out group 1's last compute part
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
@@ -2266,7 +2266,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   }
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
     if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && options().gemm_stream.load(std::memory_order_relaxed) == 1 &&
-        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 10 * BK && (!k.ln_stats || ln_rows) &&
+        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows) &&
         (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
       variant = 13;
   }
@@ -2293,7 +2293,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);
     case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
       if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 10 * BK && (!k.ln_stats || ln_rows)) return launch_stream<EPI>(k, ln_rows, s);
+        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows)) return launch_stream<EPI>(k, ln_rows, s);
       }
       return launch_tile<T256w16, EPI, OUT_F32>(k, s);
     case 15:   // deferred-store persistent kernel: fp16-out epilogues on 8-column-aligned outputs only
