@@ -143,7 +143,8 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
 // one, and the four transposed V reads of a 16-key step are issued before that step's exponent work, one step ahead.
 // LDS operations return in order, so the counted lgkmcnt(N) waits below only assume that the N youngest operations are
 // the ones issued after the awaited set; an LDS operation hipcc adds on its own (the cross-half shuffle) makes a wait
-// stricter, never weaker.  Dense single-block form only (vision towers: no causal mask, (NKT-1)*32 < L <= NKT*32).
+// stricter, never weaker.  Dense single-block form only (vision towers: no causal mask), with (NKT-1)*32 < L <= (NKT-1)*32 + 8:
+// the last key tile holds at most 8 live keys (193..200 tokens at NKT = 7).
 // ---------------------------------------------------------------------------------------------------------------
 #define CLIPMI_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define CLIPMI_DS_READ_TR16_B64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -173,7 +174,10 @@ __device__ __forceinline__ void read_v(f16x4 (&dst)[4], const uint32_t (&va)[2])
 }
 
 // ka[ks] / va[dt]: the lane's LDS byte addresses (key tile 0) of its K fragment ks and of its transposed V reads for d-tile dt.
-template <int NKT, int GROUP>
+// SEG: 0 exponent work interleaved with the P.V MFMAs; 1 pure VALU / MFMA segments; 2 segments separated by WORKGROUP BARRIERS --
+// the ping-pong of gemm_stream_kernel: waves 4-6 run one segment behind waves 0-3 (the caller adds the offset barriers), so on a
+// SIMD one query wave is in a matrix segment while its partner is in a VALU segment.  Five barriers inside, per call.
+template <int NKT, int GROUP, int SEG = 0>
 __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const uint32_t (&va)[2], const uint32_t (&qa)[4], int L,
                                                 int hh, f32x16 (&oacc)[2], f32x16& lacc) {
   constexpr float C = 0.125f * LOG2E;
@@ -182,6 +186,13 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
   f16x8 kf[2][4];
   f16x4 vf[2][4];   // [buffer][dt * 2 + (lo | hi)]
   float m_run = NEG_BIG;
+  auto seg_barrier = [&]() {
+    if constexpr (SEG == 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   f16x8 qf[4];      // this wave's 32 query rows (B operand of S^T = K Q^T), read like a K tile: qa = the lane's LDS addresses
   read_k<0>(qf, qa);
   read_k<0>(kf[0], ka);
@@ -207,9 +218,12 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
       if constexpr (KT == NKT - 1) {   // the only tile that can hold keys at or beyond L
+        // L <= (NKT - 1) * 32 + 8 (the caller's contract: 193..200 tokens): registers e >= 4 of this tile are keys >= L in EVERY
+        // lane (key = 32 KT + (e & 3) + 8 (e >> 2) + 4 hh) -- P = 0 exactly, so they get no mask, no max, no exponent, and the
+        // tile's second 16-key step no MFMAs (adding 0 . V leaves the accumulators bit for bit as they are)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = KT * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        for (int e = 0; e < 4; ++e) {
+          const int key = KT * 32 + e + 4 * hh;
           s[T][e] = key >= L ? NEG_BIG : s[T][e];
         }
       }
@@ -222,12 +236,13 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     // the reads that the P.V phase (and the next group's first S tile) open with: behind the exponent work by the time they are needed
     if constexpr (MORE) read_k<G0 + G>(kf[(G0 + G) & 1], ka);
     read_v<G0 * 4096>(vf[0], va);
+    seg_barrier();   // matrix segment (S) -> VALU segment (max, exponent)
     // ---- group max of the raw scores, online rescale (nothing to rescale in the first group)
     float mloc = NEG_BIG;
 #pragma unroll
     for (int t = 0; t < G; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+      for (int e = 0; e < ((G0 + t == NKT - 1) ? 4 : 16); e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = G0 == 0 ? mloc : fmaxf(m_run, mloc);
     if constexpr (G0 > 0) {
@@ -241,14 +256,56 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     const float mc = m_new * C;
     m_run = m_new;
     // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
+    if constexpr (SEG != 0) {
+      // "pure segments": ALL exponent work of the group first (VALU only), then its P.V MFMAs as one block (matrix pipe only,
+      // V fragments streaming one step ahead).  A SIMD's two query waves then tend to sit in opposite kinds of segment -- one
+      // paced by the matrix pipe, one by VALU issue -- instead of each interleaving both at instruction granularity.
+      f16x8 pfa[G][2];
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            pfa[t][ss][j] = (G0 + t == NKT - 1 && 8 * ss + j >= 4) ? (half_t)0.f : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[t][8 * ss + j], C, -mc));
+      __builtin_amdgcn_sched_barrier(0);
+      seg_barrier();   // VALU segment -> matrix segment (P.V, then the next group's S)
+      auto mm_step = [&](auto step_tag) {
+        constexpr int STEP = decltype(step_tag)::value, T = STEP >> 1, SS = STEP & 1, CUR = STEP & 1;
+        constexpr bool LAST = STEP == 2 * G - 1;
+        if constexpr (!LAST) read_v<(G0 + (STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
+        if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+        else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
+          const f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (G0 == 0 && STEP == 0) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pfa[T][SS], zero16, 0, 0, 0);
+          else oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pfa[T][SS], oacc[dt], 0, 0, 0);
+        }
+        if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pfa[T][SS], zero16, 0, 0, 0);
+        else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pfa[T][SS], lacc, 0, 0, 0);
+      };
+      mm_step(std::integral_constant<int, 0>{});
+      mm_step(std::integral_constant<int, 1>{});
+      if constexpr (G > 1) { mm_step(std::integral_constant<int, 2>{}); mm_step(std::integral_constant<int, 3>{}); }
+      if constexpr (G > 2) { mm_step(std::integral_constant<int, 4>{}); mm_step(std::integral_constant<int, 5>{}); }
+      if constexpr (G > 3) { mm_step(std::integral_constant<int, 6>{}); mm_step(std::integral_constant<int, 7>{}); }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!MORE) seg_barrier();   // last matrix segment -> the caller's VALU segment (normalise, store)
+    } else {
     auto pv_step = [&](auto t_tag, auto ss_tag) {
       constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
       constexpr int STEP = T * 2 + SS, CUR = STEP & 1;
-      constexpr bool LAST = STEP == 2 * G - 1;
+      constexpr int NSTEPS = 2 * G - ((G0 + G == NKT) ? 1 : 0);   // the tail tile's second 16-key step is all dead keys: skipped
+      if constexpr (STEP >= NSTEPS) return;
+      constexpr bool LAST = STEP == NSTEPS - 1;
+      constexpr bool TAILT = G0 + T == NKT - 1;
       if constexpr (!LAST) read_v<(G0 + (STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
       f16x8 pf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
+      for (int j = 0; j < 8; ++j)
+        pf[j] = (TAILT && 8 * SS + j >= 4) ? (half_t)0.f : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
       if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
       else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
 #pragma unroll
@@ -269,6 +326,7 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     if constexpr (G > 1) pv_tile(std::integral_constant<int, 1>{});
     if constexpr (G > 2) pv_tile(std::integral_constant<int, 2>{});
     if constexpr (G > 3) pv_tile(std::integral_constant<int, 3>{});
+    }
   };
   group(std::integral_constant<int, 0>{});
   if constexpr (NKT > GROUP) group(std::integral_constant<int, GROUP>{});
@@ -532,7 +590,7 @@ constexpr int VARR = VROWS * 128;            // one operand image
 constexpr int VBUF = 3 * VARR;               // K | V | Q
 constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of the last array
 
-template <int NLOAD, int PRIO, int GROUP = 4, bool PF = true>
+template <int NLOAD, int PRIO, int GROUP = 4, int PF = 1>
 __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                                                int L, int H, int n_items
 #ifdef CLIPMI_TUNING
@@ -582,6 +640,22 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
         CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
       }
     };
+    auto stage_chunk = [&](auto jtag, auto ctag, int it_, int buf) {   // groups g = J (mod NLOAD) with g % 7 == chunk; nothing past the last item
+      constexpr int J = decltype(jtag)::value, CH = decltype(ctag)::value;
+      if (it_ >= n_items) return;   // uniform
+      const int n = it_ / H, h = it_ - n * H;
+      const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
+      char* B = smem + buf * VBUF;
+#pragma unroll
+      for (int g = J; g < VROWS / 8; g += NLOAD) {
+        if (g % 7 != CH) continue;
+        const int kq = lane_row + swk[g & 1];
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + g * 1024, radd(kq + D * 2, g * gstep), 0);                        // K
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + VARR + g * 1024, radd(lane_row + swv + 2 * D * 2, g * gstep), 0);  // V
+        CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
+      }
+    };
     auto run = [&](auto jtag) {
       stage(jtag, item, 0);
       int buf = 0;
@@ -600,7 +674,19 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
         if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
         const int next = item + gridDim.x;
-        if (next < n_items) stage(jtag, next, buf ^ 1);
+        if constexpr (PF == 3) {
+          // ping-pong mode: the query waves cross six more barriers per item (segment boundaries); the loader joins each of them and
+          // issues a seventh of the next item's DMA in every slot (one burst of 75 instructions would hold the first barrier back)
+          stage_chunk(jtag, std::integral_constant<int, 0>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 1>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 2>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 3>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 4>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 5>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
+          stage_chunk(jtag, std::integral_constant<int, 6>{}, next, buf ^ 1);
+        } else {
+          if (next < n_items) stage(jtag, next, buf ^ 1);
+        }
 #ifdef CLIPMI_TUNING
         if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -643,12 +729,13 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
     const char* b = smem + buf * VBUF;
     f32x16 oacc[2];
     f32x16 lacc;
-    if constexpr (PF) {   // fragment reads pinned ahead of their MFMAs (attend_dense_pf)
+    if constexpr (PF != 0) {   // fragment reads pinned ahead of their MFMAs (attend_dense_pf)
       const uint32_t lb = lds_base + (uint32_t)(buf * VBUF);
       const uint32_t ka[4] = {lb + (uint32_t)kro[0], lb + (uint32_t)kro[1], lb + (uint32_t)kro[2], lb + (uint32_t)kro[3]};
       const uint32_t va[2] = {lb + (uint32_t)vro[0], lb + (uint32_t)vro[1]};
       const uint32_t qa[4] = {lb + (uint32_t)qro[0], lb + (uint32_t)qro[1], lb + (uint32_t)qro[2], lb + (uint32_t)qro[3]};
-      attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc);
+      if constexpr (PF == 3) { if (wave >= 4) __builtin_amdgcn_s_barrier(); }   // waves 4-6 start one segment later
+      attend_dense_pf<NKT, GROUP, PF == 3 ? 2 : (PF == 2 ? 1 : 0)>(ka, va, qa, L, hh, oacc, lacc);
     } else {
       f16x8 qf[4];
 #pragma unroll
@@ -672,13 +759,14 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
       const int n = item / H, h = item - n * H;
       store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
     }
+    if constexpr (PF == 3) { if (wave < 4) __builtin_amdgcn_s_barrier(); }   // ... and waves 0-3 wait out the last segment of waves 4-6
 #ifdef CLIPMI_TUNING
     if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   }
 }
 
-template <int NLOAD, int PRIO, int GROUP = 4, bool PF = true>
+template <int NLOAD, int PRIO, int GROUP = 4, int PF = 1>
 int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
   static DeviceOnce attr_once;
   auto fn = attention_vision_kernel<NLOAD, PRIO, GROUP, PF>;
@@ -698,8 +786,10 @@ int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStre
 // kernel without loaders 81-83 us, one loader 74-78 us, two loaders 78 us (74 with raised priority), one loader with all seven key
 // tiles in one softmax group 79.5 us, groups of two 80.3 us.
 int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, int mode, hipStream_t s) {
-  if (mode == 2) return launch_vision_t<2, 0, 4, false>(qkv, out, N, L, H, s);
-  if (mode == 3) return launch_vision_t<1, 0, 4, false>(qkv, out, N, L, H, s);   // compiler-placed fragment reads (A/B aid)
+  if (mode == 2) return launch_vision_t<2, 0, 4, 0>(qkv, out, N, L, H, s);
+  if (mode == 3) return launch_vision_t<1, 0, 4, 0>(qkv, out, N, L, H, s);
+  if (mode == 4) return launch_vision_t<1, 0, 4, 2>(qkv, out, N, L, H, s);   // pinned reads + pure VALU / MFMA segments (A/B aid)
+  if (mode == 5) return launch_vision_t<1, 0, 4, 3>(qkv, out, N, L, H, s);   // ... separated by barriers, waves 4-6 one segment behind (ping-pong)   // compiler-placed fragment reads (A/B aid)
   return launch_vision_t<1, 0>(qkv, out, N, L, H, s);
 }
 

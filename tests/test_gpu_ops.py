@@ -168,7 +168,7 @@ def test_attention(ops, n, l, h, causal, tr, clipmi_option):
     assert err < 4e-3, f"max err {err}"
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n,l,h", [(3, 197, 12), (2, 199, 12), (1, 193, 2), (5, 200, 1), (40, 197, 12)])
 def test_attention_vision_loader_modes(ops, clipmi_option, mode, n, l, h):
     """193..200-token non-causal attention (the image towers at 224 px; clip/model.py:181-183): the persistent kernel
