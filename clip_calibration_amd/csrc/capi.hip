@@ -39,6 +39,7 @@ const OptionDesc kOptions[] = {
     {"gemm_band", "CLIPMI_GEMM_BAND", &Options::gemm_band},
     {"gemm_persist", "CLIPMI_GEMM_PERSIST", &Options::gemm_persist},
     {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
+    {"gemm_pp", "CLIPMI_GEMM_PP", &Options::gemm_pp},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_no_tr", "CLIPMI_ATTN_NO_TR", &Options::attn_no_tr},

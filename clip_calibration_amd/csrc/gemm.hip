@@ -1806,6 +1806,188 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// One-tile-per-workgroup kernel with the PING-PONG main loop of gemm_stream_kernel (round 2): eight waves, two per SIMD,
+// T::BM x 256 tile (the 320 x 256 tile of the residual GEMMs: 160 accumulators + 36 fragment registers per wave).  A K-step is
+// four phases per wave (k-half ks = p >> 1, row half jh = p & 1): a LOAD part -- the phase's operand fragments by pinned LDS
+// reads (TM / 2 activation blocks, plus the 4 weight blocks when jh == 0) and, in phases 0..2, a third of this wave's LDS-DMA
+// pieces of the next stage, then the wait for the reads -- and a COMPUTE part of 2 TM MFMAs on registers only, a workgroup barrier
+// after each part; waves 4-7 run one part behind waves 0-3.  Hazards as in gemm_stream_kernel (WAR: the first piece of stage
+// k + 1 goes out after the barrier that ends the last reads of stage k - 1; RAW: every wave waits for its own pieces at the end of
+// the K-step's last slot, one barrier before the first read).  Prologue (stage 0, LayerNorm-fold row parameters) and epilogues
+// are those of gemm_f16_kernel.  Why: that kernel's compiler-scheduled loop (vmcnt(0) + __syncthreads per K-step, all DMA
+// issued behind the barrier) keeps the matrix pipe 68-75 % busy on this tile; this one 77+ %.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, int H>
+__device__ __forceinline__ void lgkm_wait_x(f16x8 (&x)[H]) {
+  if constexpr (H == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]) : "n"(N));
+  static_assert(H == 4 || H == 5, "half of the wave tile: 4 or 5 activation blocks");
+}
+
+template <typename T, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
+  constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
+  static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
+  constexpr int NP = T::XI + T::WI;                       // LDS-DMA pieces per wave and stage
+  constexpr int PPP = (NP + 2) / 3;                       // ... per load part (phases 0..2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+  const int grp = wave >> 2;   // uniform: waves w and w + 4 share a SIMD
+
+  int tile_m, tile_n;
+  tile_coords(a, (a.M + BM - 1) / BM, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * T::BN;
+
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
+  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
+  const int lds_wave_off = wave * 1024;
+  auto stage_piece = [&](auto p_tag, int buf, int kt) {
+    constexpr int P = decltype(p_tag)::value;
+    if constexpr (P < NP) {
+      char* xs = smem + buf * T::STAGE + lds_wave_off;
+      const int k0 = kt * BK * 2;
+      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
+      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+    }
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t f0 = (uint32_t)(r16 * 128 + (((0 + g4) ^ swz) << 4)), f1 = (uint32_t)(r16 * 128 + (((4 + g4) ^ swz) << 4));
+  const uint32_t xb = (uint32_t)(wave_m * T::WTM * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
+  const int nk = a.K / BK;
+
+  // ---- prologue: stage 0, and (LayerNorm-fold consumers) the tile's row parameters, behind the DMA latency
+  stage_piece(std::integral_constant<int, 0>{}, 0, 0); stage_piece(std::integral_constant<int, 1>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 2>{}, 0, 0); stage_piece(std::integral_constant<int, 3>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 4>{}, 0, 0); stage_piece(std::integral_constant<int, 5>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 6>{}, 0, 0); stage_piece(std::integral_constant<int, 7>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 8>{}, 0, 0);
+  static_assert(NP <= 9, "at most nine pieces per wave and stage");
+  float2* lnp = nullptr;
+  if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+    if (a.ln_stats) {   // block-uniform
+      lnp = reinterpret_cast<float2*>(smem + T::SMEM);
+      for (int t = tid; t < BM; t += NT) {
+        float rs, mrs;
+        ln_row_params(a, m0 + t, rs, mrs);
+        lnp[t] = make_float2(rs, mrs);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[TN][TM];
+  auto kstep = [&](auto first_tag, auto more_tag, int kt) {
+    constexpr bool FIRSTK = decltype(first_tag)::value;
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int buf = kt & 1;
+    const uint32_t sb = lds_base + (uint32_t)(buf * T::STAGE);
+    uint32_t xa0 = sb + xb + f0, xa1 = sb + xb + f1, wa0 = sb + wb + f0, wa1 = sb + wb + f1;
+    f16x8 wf[4], xf[H];
+    auto phase = [&](auto p_tag) {
+      constexpr int P = decltype(p_tag)::value;
+      constexpr int KS = P >> 1, JH = P & 1;
+      // ---- load part
+      {
+        const uint32_t xa = KS ? xa1 : xa0;
+        ds_read128<(JH * H + 0) * 2048>(xf[0], xa);
+        ds_read128<(JH * H + 1) * 2048>(xf[1], xa);
+        ds_read128<(JH * H + 2) * 2048>(xf[2], xa);
+        ds_read128<(JH * H + 3) * 2048>(xf[3], xa);
+        if constexpr (H == 5) ds_read128<(JH * H + 4) * 2048>(xf[H - 1], xa);
+        if constexpr (JH == 0) {
+          const uint32_t wa = KS ? wa1 : wa0;
+          ds_read128<0>(wf[0], wa);
+          ds_read128<2048>(wf[1], wa);
+          ds_read128<4096>(wf[2], wa);
+          ds_read128<6144>(wf[3], wa);
+        }
+      }
+      if constexpr (MORE && P < 3) {
+        stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1);
+        stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1);
+        stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1);
+        static_assert(PPP == 3, "three pieces per load part");
+      }
+      if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
+      lgkm_wait_x<0, H>(xf);
+      if constexpr (P == 3) {
+        if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < H; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if constexpr (FIRSTK && KS == 0)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
+          else
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
+        }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (P == 3) {
+        if (grp == 0) wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+  };
+
+  constexpr std::false_type no{};
+  constexpr std::true_type yes{};
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 start one part later
+  kstep(yes, yes, 0);                            // nk >= 2 (checked by the launcher)
+  for (int kt = 1; kt < nk - 1; ++kt) kstep(no, yes, kt);
+  kstep(no, no, nk - 1);
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
+}
+
+template <typename T, int EPI, bool OUT_F32>
+int launch_pp(KArgs k, hipStream_t s) {
+  static DeviceOnce attr_once;
+  auto fn = gemm_pp_kernel<T, EPI, OUT_F32>;
+  constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
+  constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;
+  constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  static_assert(SMEM <= 160 * 1024, "tile does not fit the CU's LDS");
+  ensure_dynamic_lds(fn, SMEM, attr_once);
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  k.tiles_n = (k.N + T::BN - 1) / T::BN;
+  k.band = pick_band(k.tiles_n, T::BN, k.K);
+  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
+  k.nwg = (int)nwg;
+  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), SMEM, s, k);
+  return check_launch("gemm_pp_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Pipelined variant (the default for large problems): 256 x 256 tile, 8 waves of 128(m) x 64(n), BK = 32 stages in
 // the 4-slot ring, loads three stages ahead.  Each stage is two clusters of 16 MFMAs (m-tiles 0-3, then 4-7, against
 // the stage's 4 n-tile fragments); the LDS reads of a cluster are issued one cluster ahead into a second register
@@ -2247,7 +2429,9 @@ int launch_conv_tile(KArgs k, const ConvArgs& cv, hipStream_t s) {
 template <int EPI, bool OUT_F32>
 int launch_basic(const KArgs& k, hipStream_t s) {
   switch (pick_variant(k)) {
-    case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
+    case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
+      if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
+      return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 0: return launch_tile<T128, EPI, OUT_F32>(k, s);
     default: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
   }
@@ -2289,7 +2473,9 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
     case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s, ln_rows);
-    case 10: return launch_tile<T320w8, EPI, OUT_F32>(k, s);
+    case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
+      if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
+      return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);
     case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
       if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {

@@ -66,7 +66,8 @@ const char* clipmi_last_error(void);
  *   gemm_band        (CLIPMI_GEMM_BAND)       0 = default; n-tiles per traversal band
  *   gemm_persist     (CLIPMI_GEMM_PERSIST)    0 = one tile per workgroup (default); persistent tiles for multi-round fp16-out GEMMs:
  *                                             1 = 16 waves, 2 = 16 waves with DMA'd row / column parameters, 3 = 8 waves with them
- *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 = streamed-epilogue persistent kernel for multi-round fp16-out GEMMs (0 = off, default)
+ *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs, K >= 512
+ *   gemm_pp          (CLIPMI_GEMM_PP)         1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
  *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
  *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
  *                                             (default; env 'v'), 3 = text tower only (env 't')

@@ -107,6 +107,32 @@ def test_gemm_stream_kernel_race_screen(ops, clipmi_option):
     assert bad == 0, f"{bad} of 60 launches differ"
 
 
+def test_gemm_pingpong_tile_kernel_race_screen(ops, clipmi_option):
+    """gemm_pp_kernel (the 320 x 256 one-tile-per-workgroup kernel with the ping-pong main loop: option gemm_pp = 1, the default for
+    the residual GEMMs) against the compiler-scheduled two-stage loop it replaces (gemm_pp = 0): same K order, same MFMA, same
+    epilogue code -- bit-identical, here on the image tower's c_proj shape (48 K-steps, in-place residual epilogue) and the
+    out-proj shape, 40 launches with an HBM-bound stream queued in front of every third."""
+    g = torch.Generator().manual_seed(13)
+    filler = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    bad = 0
+    for (M, N, K) in [(50432, 768, 3072), (50432, 768, 768)]:
+        a0 = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+        w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).cuda()
+        for it in range(10):
+            a = torch.roll(a0, shifts=it * 53, dims=0)
+            clipmi_option("gemm_pp", 0)
+            ref = ops.gemm_f16(a, w, bias, residual=res.clone(), epilogue=_lib.EPI_BIAS_RESIDUAL, out_dtype=torch.float32)
+            clipmi_option("gemm_pp", 1)
+            for rep in range(2):
+                if (it + rep) % 3 == 0:
+                    filler.add_(1)
+                out = ops.gemm_f16(a, w, bias, residual=res.clone(), epilogue=_lib.EPI_BIAS_RESIDUAL, out_dtype=torch.float32)
+                bad += int(not torch.equal(out, ref))
+    assert bad == 0, f"{bad} of 40 launches differ from the two-stage loop"
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from clip_calibration_amd._lib import ClipmiError
     a = torch.zeros(8, 48, dtype=torch.float16, device="cuda")
