@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
         if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(CLIPMI_ABLATE & 32)) __builtin_amdgcn_s_barrier();   // (ablation 32: timing without the load -> compute barriers; results wrong)
       __builtin_amdgcn_sched_barrier(0);
       // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
       __builtin_amdgcn_s_setprio(1);
@@ -2477,6 +2477,9 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
       if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
       return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);
+    case 14:   // 256 x 256, eight waves, ping-pong main loop (A/B aid; the 16-wave two-stage kernel is variant 1)
+      if (k.K >= 2 * BK) return launch_pp<T256w8, EPI, OUT_F32>(k, s);
+      return launch_tile<T256w8, EPI, OUT_F32>(k, s);
     case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
       if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
         if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows)) return launch_stream<EPI>(k, ln_rows, s);
