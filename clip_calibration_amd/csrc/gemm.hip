@@ -1870,6 +1870,13 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   const uint32_t xb = (uint32_t)(wave_m * T::WTM * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
   const int nk = a.K / BK;
 
+#ifdef CLIPMI_TUNING
+  const bool stamp = a.stamps != nullptr && tid == 0;
+  if (stamp) {
+    a.stamps[blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[blockIdx.x * 8 + 5] = (long long)__smid();
+  }
+#endif
   // ---- prologue: stage 0, and (LayerNorm-fold consumers) the tile's row parameters, behind the DMA latency
   stage_piece(std::integral_constant<int, 0>{}, 0, 0); stage_piece(std::integral_constant<int, 1>{}, 0, 0);
   stage_piece(std::integral_constant<int, 2>{}, 0, 0); stage_piece(std::integral_constant<int, 3>{}, 0, 0);
@@ -1890,6 +1897,12 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef CLIPMI_TUNING
+  if (stamp) {
+    a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
 
   f32x4 acc[TN][TM];
   auto kstep = [&](auto first_tag, auto more_tag, int kt) {
@@ -1965,7 +1978,20 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   kstep(no, no, nk - 1);
   if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+#ifdef CLIPMI_TUNING
+  if (stamp) {
+    a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
   epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
+#ifdef CLIPMI_TUNING
+  if (a.stamps != nullptr) {
+    if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp) a.stamps[blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <typename T, int EPI, bool OUT_F32>
