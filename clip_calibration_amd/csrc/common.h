@@ -53,7 +53,9 @@ struct Options {
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
   std::atomic<int> attn_no_tr{0}, attn_no_persist{0}, attn_no_stream{0}, attn_stagger{0};
-  std::atomic<int> attn_loader{1};     // CLIPMI_ATTN_LOADER: 1 = attention_vision_kernel (all operands by LDS-DMA from a loader wave) for 193..200 tokens; 2 = two loader waves; 0 = off
+  std::atomic<int> attn_loader{1};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 1 (default) = attention_vision_kernel (all operands by LDS-DMA
+                                       // from a loader wave, fragment reads pinned by inline asm); 0 = persistent kernel; A/B aids with the same bits:
+                                       // 2 two loader waves, 3 compiler-placed reads, 4 pure VALU / MFMA segments, 5 segments + barriers (ping-pong)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
 };
 Options& options();
