@@ -1824,7 +1824,7 @@ __device__ __forceinline__ void lgkm_wait_x(f16x8 (&x)[H]) {
   static_assert(H == 4 || H == 5, "half of the wave tile: 4 or 5 activation blocks");
 }
 
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, bool WIDE = false>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
   static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
@@ -1853,15 +1853,18 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
     return r;
   };
   const int lds_wave_off = wave * 1024;
-  auto stage_piece = [&](auto p_tag, int buf, int kt) {
+  auto stage_piece = [&](auto p_tag, int buf, int kt, auto partner_tag) {
     constexpr int P = decltype(p_tag)::value;
+    constexpr bool PARTNER = decltype(partner_tag)::value;   // the piece of wave + 4 (its rows lie 32 further: (tid + 256) >> 3; same chunk swizzle)
     if constexpr (P < NP) {
-      char* xs = smem + buf * T::STAGE + lds_wave_off;
+      char* xs = smem + buf * T::STAGE + lds_wave_off + (PARTNER ? 4 * 1024 : 0);
       const int k0 = kt * BK * 2;
-      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
-      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep + (PARTNER ? xstep / 2 : 0)), k0);
+      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep + (PARTNER ? wstep / 2 : 0)), k0);
     }
   };
+  constexpr std::false_type own{};
+  constexpr std::true_type partner{};
 
   const int r16 = lane & 15, g4 = lane >> 4;
   const int swz = (r16 >> 1) & 7;
@@ -1878,11 +1881,11 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   }
 #endif
   // ---- prologue: stage 0, and (LayerNorm-fold consumers) the tile's row parameters, behind the DMA latency
-  stage_piece(std::integral_constant<int, 0>{}, 0, 0); stage_piece(std::integral_constant<int, 1>{}, 0, 0);
-  stage_piece(std::integral_constant<int, 2>{}, 0, 0); stage_piece(std::integral_constant<int, 3>{}, 0, 0);
-  stage_piece(std::integral_constant<int, 4>{}, 0, 0); stage_piece(std::integral_constant<int, 5>{}, 0, 0);
-  stage_piece(std::integral_constant<int, 6>{}, 0, 0); stage_piece(std::integral_constant<int, 7>{}, 0, 0);
-  stage_piece(std::integral_constant<int, 8>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 0>{}, 0, 0, own); stage_piece(std::integral_constant<int, 1>{}, 0, 0, own);
+  stage_piece(std::integral_constant<int, 2>{}, 0, 0, own); stage_piece(std::integral_constant<int, 3>{}, 0, 0, own);
+  stage_piece(std::integral_constant<int, 4>{}, 0, 0, own); stage_piece(std::integral_constant<int, 5>{}, 0, 0, own);
+  stage_piece(std::integral_constant<int, 6>{}, 0, 0, own); stage_piece(std::integral_constant<int, 7>{}, 0, 0, own);
+  stage_piece(std::integral_constant<int, 8>{}, 0, 0, own);
   static_assert(NP <= 9, "at most nine pieces per wave and stage");
   float2* lnp = nullptr;
   if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
@@ -1905,6 +1908,16 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 #endif
 
   f32x4 acc[TN][TM];
+#ifdef CLIPMI_TUNING
+  // part timers (diagnostic build): lane 0 of waves 0 and 4 sums the shader-clock time of its load parts (issue -> fragments in
+  // registers), of the wait at the barrier behind them, of its compute parts and of the wait at the barrier behind those;
+  // written to stamps[(4096 + blockIdx) * 8 + 4 * group + {0,1,2,3}] (tools/gemm_stamps.py prints the medians)
+  long long tm_load = 0, tm_b1 = 0, tm_comp = 0, tm_b2 = 0;
+  const bool timer = a.stamps != nullptr && lane == 0 && (wave & 3) == 0;
+#define PP_T() (timer ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
+#else
+#define PP_T() 0ll
+#endif
   auto kstep = [&](auto first_tag, auto more_tag, int kt) {
     constexpr bool FIRSTK = decltype(first_tag)::value;
     constexpr bool MORE = decltype(more_tag)::value;
@@ -1916,6 +1929,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       constexpr int P = decltype(p_tag)::value;
       constexpr int KS = P >> 1, JH = P & 1;
       // ---- load part
+      [[maybe_unused]] const long long t0 = PP_T();
       {
         const uint32_t xa = KS ? xa1 : xa0;
         ds_read128<(JH * H + 0) * 2048>(xf[0], xa);
@@ -1932,9 +1946,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
         }
       }
       if constexpr (MORE && P < 3) {
-        stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1);
-        stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1);
-        stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1);
+        stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1, own);
+        stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1, own);
+        stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1, own);
         static_assert(PPP == 3, "three pieces per load part");
       }
       if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
@@ -1942,9 +1956,11 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       if constexpr (P == 3) {
         if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
       }
+      [[maybe_unused]] const long long t1 = PP_T();
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(CLIPMI_ABLATE & 32)) __builtin_amdgcn_s_barrier();   // (ablation 32: timing without the load -> compute barriers; results wrong)
       __builtin_amdgcn_sched_barrier(0);
+      [[maybe_unused]] const long long t2 = PP_T();
       // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1960,14 +1976,84 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       if constexpr (P == 3) {
         if (grp == 0) wait_vmcnt<0>();
       }
+      [[maybe_unused]] const long long t3 = PP_T();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef CLIPMI_TUNING
+      if (timer) {
+        const long long t4 = (long long)__builtin_amdgcn_s_memtime();
+        tm_load += t1 - t0; tm_b1 += t2 - t1; tm_comp += t3 - t2; tm_b2 += t4 - t3;
+      }
+#endif
+    };
+    // WIDE: two phases per K-step (one per k-half, all TM activation blocks): half the barriers -- part timers put a barrier at
+    // ~130 cycles, eight per K-step against 2 560 cycles of MFMAs on the 320-row tile.  The next stage's pieces must all be out
+    // by the third of the four slots, so the groups share them unevenly: waves 0-3 issue six of their own in their first load
+    // part and their last three plus their partner's last three in the second; waves 4-7 six of their own in their first.
+    auto wide_phase = [&](auto p_tag) {
+      constexpr int KS = decltype(p_tag)::value;
+      f16x8 xw[TM];
+      {
+        const uint32_t xa = KS ? xa1 : xa0, wa = KS ? wa1 : wa0;
+        ds_read128<0>(wf[0], wa);
+        ds_read128<2048>(wf[1], wa);
+        ds_read128<4096>(wf[2], wa);
+        ds_read128<6144>(wf[3], wa);
+        ds_read128<0 * 2048>(xw[0], xa); ds_read128<1 * 2048>(xw[1], xa); ds_read128<2 * 2048>(xw[2], xa); ds_read128<3 * 2048>(xw[3], xa);
+        ds_read128<4 * 2048>(xw[4], xa); ds_read128<5 * 2048>(xw[5], xa); ds_read128<6 * 2048>(xw[6], xa); ds_read128<7 * 2048>(xw[7], xa);
+        if constexpr (TM == 10) { ds_read128<8 * 2048>(xw[8], xa); ds_read128<9 * 2048>(xw[TM - 1], xa); }
+      }
+      if constexpr (MORE) {
+        if constexpr (KS == 0) {   // both groups: own pieces 0..5
+          stage_piece(std::integral_constant<int, 0>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 1>{}, buf ^ 1, kt + 1, own);
+          stage_piece(std::integral_constant<int, 2>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 3>{}, buf ^ 1, kt + 1, own);
+          stage_piece(std::integral_constant<int, 4>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 5>{}, buf ^ 1, kt + 1, own);
+        } else if (grp == 0) {     // waves 0-3: own 6..8 and the partner's 6..8
+          stage_piece(std::integral_constant<int, 6>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 7>{}, buf ^ 1, kt + 1, own);
+          stage_piece(std::integral_constant<int, 8>{}, buf ^ 1, kt + 1, own);
+          stage_piece(std::integral_constant<int, 6>{}, buf ^ 1, kt + 1, partner); stage_piece(std::integral_constant<int, 7>{}, buf ^ 1, kt + 1, partner);
+          stage_piece(std::integral_constant<int, 8>{}, buf ^ 1, kt + 1, partner);
+        }
+      }
+      lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
+      lgkm_wait4<0>(xw[0], xw[1], xw[2], xw[3]);
+      lgkm_wait4<0>(xw[4], xw[5], xw[6], xw[7]);
+      if constexpr (TM == 10) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[8]), "+v"(xw[TM - 1]));
+      if constexpr (KS == 1) {
+        if (grp == 1) wait_vmcnt<0>();   // this wave's pieces (issued three slots ago) have landed
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if constexpr (FIRSTK && KS == 0)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
+          else
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
+        }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (KS == 1) {
+        if (grp == 0) wait_vmcnt<0>();
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    phase(std::integral_constant<int, 0>{});
-    phase(std::integral_constant<int, 1>{});
-    phase(std::integral_constant<int, 2>{});
-    phase(std::integral_constant<int, 3>{});
+    if constexpr (WIDE) {
+      static_assert(!WIDE || (NP == 9 || NP == 8), "piece plan of the wide phases");
+      wide_phase(std::integral_constant<int, 0>{});
+      wide_phase(std::integral_constant<int, 1>{});
+    } else {
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+      phase(std::integral_constant<int, 3>{});
+    }
   };
 
   constexpr std::false_type no{};
@@ -1983,7 +2069,12 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
     a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
     a.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
   }
+  if (timer && blockIdx.x < 4096) {
+    long long* tp = a.stamps + (4096 + blockIdx.x) * 8 + 4 * grp;
+    tp[0] = tm_load; tp[1] = tm_b1; tp[2] = tm_comp; tp[3] = tm_b2;
+  }
 #endif
+#undef PP_T
   epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
 #ifdef CLIPMI_TUNING
   if (a.stamps != nullptr) {
@@ -1994,10 +2085,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 #endif
 }
 
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, bool WIDE = false>
 int launch_pp(KArgs k, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = gemm_pp_kernel<T, EPI, OUT_F32>;
+  auto fn = gemm_pp_kernel<T, EPI, OUT_F32, WIDE>;
   constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
   constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;
   constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
@@ -2456,6 +2547,7 @@ template <int EPI, bool OUT_F32>
 int launch_basic(const KArgs& k, hipStream_t s) {
   switch (pick_variant(k)) {
     case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
+      if (options().gemm_pp.load(std::memory_order_relaxed) == 2 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32, true>(k, s);   // two wide phases per K-step
       if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
       return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 0: return launch_tile<T128, EPI, OUT_F32>(k, s);
@@ -2500,6 +2592,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
     case 8: return launch_pipe<EPI, OUT_F32>(k, s);
     case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s, ln_rows);
     case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
+      if (options().gemm_pp.load(std::memory_order_relaxed) == 2 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32, true>(k, s);   // two wide phases per K-step
       if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
       return launch_tile<T320w8, EPI, OUT_F32>(k, s);
     case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);

@@ -124,8 +124,8 @@ def test_gemm_pingpong_tile_kernel_race_screen(ops, clipmi_option):
             a = torch.roll(a0, shifts=it * 53, dims=0)
             clipmi_option("gemm_pp", 0)
             ref = ops.gemm_f16(a, w, bias, residual=res.clone(), epilogue=_lib.EPI_BIAS_RESIDUAL, out_dtype=torch.float32)
-            clipmi_option("gemm_pp", 1)
             for rep in range(2):
+                clipmi_option("gemm_pp", 1 + rep)   # 1: four phases per K-step, 2: two wide phases
                 if (it + rep) % 3 == 0:
                     filler.add_(1)
                 out = ops.gemm_f16(a, w, bias, residual=res.clone(), epilogue=_lib.EPI_BIAS_RESIDUAL, out_dtype=torch.float32)

@@ -87,6 +87,15 @@ for name, step, variant in CASES:
         print(f"   prefetch + epilogue issue med {np.median(epi_i):5.2f} us  p90 {np.percentile(epi_i,90):5.2f}")
         print(f"   epilogue end -> next tile start med {np.median(gaps):5.2f} us")
         continue
+    raw = stamps.cpu().numpy().reshape(-1, 8)
+    parts = raw[4096:4096 + 4096]
+    parts = parts[parts[:, 0] > 0]
+    if len(parts):   # gemm_pp_kernel's part timers (shader cycles summed over the K loop; group 0 = wave 0, group 1 = wave 4)
+        nk = {"out_proj": 12, "c_proj": 48}.get(name.split()[0], 12) * 4
+        for g in (0, 1):
+            p4 = parts[:, 4 * g:4 * g + 4].astype(np.float64) / nk
+            print(f"   group {g} per phase (cycles): load part {np.median(p4[:,0]):.0f}  wait at barrier {np.median(p4[:,1]):.0f}  "
+                  f"compute part {np.median(p4[:,2]):.0f}  wait at barrier {np.median(p4[:,3]):.0f}")
     pro, main, epi_i, drain = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3]
     print(f"{name}: {len(t)} workgroups, kernel span {t[:,4].max():.1f} us (hipEvents {ms*1e3:.1f} us)")
     print(f"   prologue  med {np.median(pro):5.2f} us  p90 {np.percentile(pro,90):5.2f}")
