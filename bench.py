@@ -374,6 +374,17 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             tail_ms = e0.elapsed_time(e1) / n_tail
+            # Optional mode, NOT part of `value` (every timed step above computes every row of every block): the last block's
+            # out-proj / MLP on the class rows only -- the only rows ln_post reads.  Reported with its feature difference.
+            from clip_calibration_amd import _lib
+            with _lib.option("cls_only_last_block", 1):
+                feats_cls = model.image_features_f32(images).clone()
+                cls_ms = timed_ms(lambda: model.image_features_f32(images), 10)
+            fn_, cn_ = torch.nn.functional.normalize(feats, dim=1), torch.nn.functional.normalize(feats_cls, dim=1)
+            out["class_rows_only_last_block"] = {
+                "option": "cls_only_last_block=1 (off by default and in every number above)", "tower_ms": cls_ms,
+                "tower_ms_every_row": out["roofline"]["tower"]["ms"], "images_per_s_tower_only": B / (cls_ms * 1e-3),
+                "max_abs_cosine_diff_vs_every_row": float((1.0 - (fn_ * cn_).sum(1)).abs().max())}
         out["tail"] = {"what": "ONE launch (fused_tail_kernel): L2-normalise + scale*img@txt^T" + (" + DAC row scale" if coop else "") +
                                " + softmax top-1 (conf, pred) + ECE bin accumulation" +
                                (" [preceded by the fp16 normalise kernel" + (" and the all-gather]" if world > 1 else "]") if f16_exchange else ""),

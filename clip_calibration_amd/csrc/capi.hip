@@ -40,6 +40,7 @@ const OptionDesc kOptions[] = {
     {"gemm_persist", "CLIPMI_GEMM_PERSIST", &Options::gemm_persist},
     {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
     {"gemm_pp", "CLIPMI_GEMM_PP", &Options::gemm_pp},
+    {"cls_only_last_block", "CLIPMI_CLS_ONLY_LAST_BLOCK", &Options::cls_only_last_block},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_no_tr", "CLIPMI_ATTN_NO_TR", &Options::attn_no_tr},
@@ -181,9 +182,18 @@ int check_block(const clipmi_block_weights& b) {
 // folded == true: on entry AND on exit w.xn holds fp16(xres) and w.stats the *parts row-sum partials of xres (written
 // by the residual epilogues); ln_1 / ln_2 are applied inside the in-proj / c_fc GEMM epilogues.
 // folded == false: separate LayerNorm kernels (launched with steps 0 and 3).
+// cls_only (image tower, LAST block, option cls_only_last_block): only the class token's row of every sequence leaves the
+// tower (clip/model.py:419: ln_post(x[:, 0, :])), so steps 2..4 of the last block -- out-proj, c_fc, c_proj and their LayerNorms
+// -- run on the n_seq class rows alone: the same GEMMs with M = n_seq and row stride L * D on the token-major buffers (the
+// in-projection and the attention stay whole: every token is a key).  Same arithmetic per element; 1/12 of the MLP flops of
+// a 12-layer tower are never issued.  Off by default: bench.py's headline number always runs every row.
 int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded,
-                   int* parts, hipStream_t s, bool f16res) {
-  const int M = n_seq * L, H = D / 64;
+                   int* parts, hipStream_t s, bool f16res, bool cls_only = false) {
+  const int H = D / 64;
+  const bool cls = cls_only && step >= 2;
+  const int M = cls ? n_seq : n_seq * L;              // rows of this step's GEMM
+  const int64_t rowD = cls ? (int64_t)L * D : D;      // distance between consecutive rows in the [n_seq * L, D] buffers
+  const int64_t Mfull = (int64_t)n_seq * L;
   int rc;
   GemmArgs a{};
   switch (step) {
@@ -194,7 +204,7 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       } else {
         a.W = (const half_t*)b.w_qkv_f; a.bias = b.c_qkv; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_qkv; a.ln_dim = D;
         a.ln_eps = 1e-5f;
-        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * M;   // the last partial slot is free
+        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * Mfull;   // the last partial slot is free
       }
       a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
@@ -202,34 +212,34 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
     case 1:
       return launch_attention(w.qkv, w.att, n_seq, L, H, causal, s);
     case 2:
-      a.A = w.att; a.lda = D; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
-      a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+      a.A = w.att; a.lda = rowD; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
+      a.ldo = rowD; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
       if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
       return launch_gemm(a, s);
     case 3:
       if (!folded) {
-        if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+        if ((rc = launch_layernorm(w.xres, CLIPMI_F32, rowD, nullptr, b.ln2_g, b.ln2_b, w.xn, CLIPMI_F16, rowD, M, D, 1e-5f, s))) return rc;
         a.W = (const half_t*)b.w_fc; a.bias = b.b_fc;
       } else {
         a.W = (const half_t*)b.w_fc_f; a.bias = b.c_fc; a.ln_stats = w.stats; a.ln_parts = *parts; a.ln_g = b.g_fc; a.ln_dim = D;
         a.ln_eps = 1e-5f;
-        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * M;
+        if (*parts < LN_MAX_PARTS) a.ln_rows = w.stats + (size_t)2 * (LN_MAX_PARTS - 1) * Mfull;
       }
-      a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
+      a.A = w.xn; a.lda = rowD; a.ldw = D; a.out = w.hid; a.ldo = 4 * D;
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 4 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS_QUICKGELU;
       return launch_gemm(a, s);
     default:
       a.A = w.hid; a.lda = 4 * D; a.W = (const half_t*)b.w_proj; a.ldw = 4 * D; a.bias = b.b_proj; a.residual = w.xres; a.out = w.xres;
-      a.ldo = D; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+      a.ldo = rowD; a.out_dtype = CLIPMI_F32; a.M = M; a.N = D; a.K = 4 * D; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
       if (folded) { a.x16 = w.xn; a.stats_out = w.stats; a.parts_out = parts; a.residual_f16 = f16res; }
       return launch_gemm(a, s);
   }
 }
 
 int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
-              hipStream_t s, bool f16res = false) {
+              hipStream_t s, bool f16res = false, bool cls_only = false) {
   for (int step = 0; step < 5; ++step) {
-    const int rc = run_block_step(step, b, w, n_seq, L, D, causal, folded, parts, s, f16res);
+    const int rc = run_block_step(step, b, w, n_seq, L, D, causal, folded, parts, s, f16res, cls_only);
     if (rc) return rc;
   }
   return CLIPMI_OK;
@@ -581,7 +591,8 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
       if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
     }
-    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res))) return rc;
+    const bool cls_only = i == g.vision_layers - 1 && options().cls_only_last_block.load(std::memory_order_relaxed) == 1;
+    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res, cls_only))) return rc;
   }
   // ln_post on the class token only, then @ proj (clip/model.py:419-422)
   half_t* cls_rows = f16res ? w.att : w.xn;

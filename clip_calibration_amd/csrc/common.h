@@ -50,6 +50,8 @@ struct Options {
   std::atomic<int> gemm_stream{1};     // CLIPMI_GEMM_STREAM: 1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs
                                        // with K >= 512 (in-proj / c_fc: -5..-9 % per launch, -4 % per image-tower step, four boxes); 0 = one tile per workgroup
   std::atomic<int> gemm_pp{1};         // CLIPMI_GEMM_PP: 1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
+  std::atomic<int> cls_only_last_block{0};   // CLIPMI_CLS_ONLY_LAST_BLOCK: 1 = the image tower's last block runs out-proj / MLP on the class rows only
+                                             // (identical features; not the default: the headline benchmark computes every row)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
   std::atomic<int> attn_no_tr{0}, attn_no_persist{0}, attn_no_stream{0}, attn_stagger{0};

@@ -68,6 +68,9 @@ const char* clipmi_last_error(void);
  *                                             1 = 16 waves, 2 = 16 waves with DMA'd row / column parameters, 3 = 8 waves with them
  *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs, K >= 512
  *   gemm_pp          (CLIPMI_GEMM_PP)         1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
+ *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block
+ *                    runs out-proj, c_fc, c_proj (and ln_2) on the class rows only -- the rows ln_post reads (clip/model.py:419) -- as
+ *                    GEMMs with M = batch and row stride L * D; same per-element arithmetic, features equal to 2e-7 in cosine
  *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
  *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
  *                                             (default; env 'v'), 3 = text tower only (env 't')

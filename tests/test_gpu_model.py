@@ -321,6 +321,36 @@ def test_vit_large_towers_vs_oracle(gname, batch):
     assert np.abs(cos - _cos(ref_i, ref_t)).max() < COS_TOL
 
 
+@pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70)])
+@pytest.mark.parametrize("fold,f16", [(1, 2), (1, 0), (0, 0)])
+def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
+    """Option cls_only_last_block: the image tower's last block runs out-proj / c_fc / c_proj (and their LayerNorms) on the class
+    rows alone -- the only rows ln_post reads (clip/model.py:419) -- as the same GEMMs with M = batch and row stride L * D.  The
+    features must equal the every-row computation up to the GEMM kernels' tile choice (same per-element arithmetic), in every
+    precision mode, and match the oracle like the default path."""
+    clipmi_option("ln_fold", fold)
+    clipmi_option("residual_f16", f16)
+    sd, model = _build(gname)
+    images = syn.synthetic_images(batch, gname, seed=5).cuda()
+    with torch.no_grad():
+        clipmi_option("cls_only_last_block", 0)
+        full = model.image_features_f32(images).clone()
+        clipmi_option("cls_only_last_block", 1)
+        cls = model.image_features_f32(images).clone()
+        cls2 = model.image_features_f32(images)
+    assert torch.equal(cls, cls2)
+    a, b = full.cpu().numpy(), cls.cpu().numpy()
+    assert np.isfinite(b).all()
+    scale = np.abs(a).max()
+    assert np.abs(a - b).max() <= 2e-3 * scale, f"class-rows-only features differ: {np.abs(a - b).max()} vs scale {scale}"
+    an, bn = a / np.linalg.norm(a, axis=1, keepdims=True), b / np.linalg.norm(b, axis=1, keepdims=True)
+    assert np.abs((an * bn).sum(1) - 1.0).max() < 2e-6
+    if batch <= 8:
+        with torch.no_grad():
+            ref = orc.encode_image(sd, images.cpu()).numpy()
+        _feat_close(b, ref, "class-rows-only last block")
+
+
 @pytest.mark.parametrize("gname", ["tiny", "ViT-B/16"])
 def test_layernorm_fold_path(clipmi_option, gname):
     """Default path: ln_1 / ln_2 applied inside the GEMM epilogues (gamma folded into the weights, mean / rstd from
