@@ -1,0 +1,113 @@
+// Power-cap probe: which MFMA shape gives more flop per joule?  Register-only loops (no LDS, no memory) on random fp16 operands,
+// every CU busy with WAVES waves, long enough for the package power controller to settle.  Prints TFLOP/s and the in-kernel clock.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_power.hip -o /tmp/mfma_power && /tmp/mfma_power
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+// MODE 0: 16x16x32 f16, 16 accumulator tiles (4x4 operands, the GEMM's wave tile).  MODE 1: 32x32x16 f16, 4 accumulator tiles (2x2 operands):
+// the same 64x64 wave tile, the same flops per operand set, half the operand register reads per flop.
+// NOPS: number of distinct operand sets rotated through (register-resident), so that operand values change between MFMAs like in a K loop.
+template <int MODE>
+__global__ __launch_bounds__(512) void probe(const f16x8* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* clk) {
+  const int lane = threadIdx.x;
+  f16x8 a[2][4], b[2][4];
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 4; ++i) {
+      a[s][i] = src[(size_t)(s * 8 + i) * 512 + lane];
+      b[s][i] = src[(size_t)(s * 8 + 4 + i) * 512 + lane];
+    }
+  unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  if constexpr (MODE != 1) {
+    // issue order of the 16 MFMAs of an operand set (operand 0 = "A" = srcA of the instruction, operand 1 = "B" = srcB):
+    //   MODE 0: A held for four MFMAs, B changes every MFMA      MODE 2: B held, A changes every MFMA
+    //   MODE 3: both change every MFMA (diagonal walk)            MODE 4: like 0 with two operand sets alternating every MFMA pair
+    f32x4 acc[4][4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            constexpr int dummy = 0; (void)dummy;
+            const int i = MODE == 0 ? u : MODE == 2 ? v : (u + v) & 3;
+            const int j = MODE == 0 ? v : MODE == 2 ? u : v;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+    }
+    float r = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    dst[blockIdx.x * 512 + lane] = r;
+  } else {
+    f32x16 acc[2][2] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)        // two K = 16 halves of the same K = 32 slice: operands a[s][2*kk + i]
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][2 * kk + i], b[s][2 * kk + j], acc[i][j], 0, 0, 0);
+    }
+    float r = 0;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) r += acc[i][j][e];
+    dst[blockIdx.x * 512 + lane] = r;
+  }
+  unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && lane == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+int main(int argc, char** argv) {
+  const int waves = argc > 1 ? atoi(argv[1]) : 8;          // waves per workgroup (one workgroup per CU)
+  const int iters = argc > 2 ? atoi(argv[2]) : 20000;
+  const int zero = argc > 3 ? atoi(argv[3]) : 0;
+  std::vector<_Float16> h(16 * 512 * 8);
+  srand(1);
+  for (auto& v : h) {   // Box-Muller normal, like the activations / weights of the bench
+    float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX;
+    v = zero ? (_Float16)0.f : (_Float16)(0.25f * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2));
+  }
+  f16x8* src; float* dst; unsigned long long* clk;
+  CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&dst, 256 * 512 * 4)); CK(hipMalloc(&clk, 16));
+  CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&](int mode) {
+    switch (mode) {
+      case 0: probe<0><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 1: probe<1><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 2: probe<2><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      default: probe<3><<<256, waves * 64>>>(src, dst, iters, clk); break;
+    }
+  };
+  static const char* names[] = {"16x16x32 A held x4", "32x32x16", "16x16x32 B held x4", "16x16x32 both change"};
+  for (int mode = 0; mode < 4; ++mode)
+    for (int rep = 0; rep < 2; ++rep) {
+      // flops per wave per iteration: 2 operand sets x (64 x 64 x 32) MACs x 2
+      const double flop = 2.0 * 2 * 64 * 64 * 32 * (double)iters * waves * 256;
+      for (int l = 0; l < 6; ++l) {   // warm the power controller
+        launch(mode);
+      }
+      CK(hipEventRecord(e0));
+      const int L = 6;
+      for (int l = 0; l < L; ++l) {
+        launch(mode);
+      }
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned long long c[2]; CK(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
+      printf("%s waves/CU %d %s: %.3f ms per launch, %.1f TFLOP/s, in-kernel clock %.0f MHz\n", names[mode], waves,
+             zero ? "zeros" : "randn", ms / L, flop / (ms / L * 1e-3) / 1e12, (double)c[0] / ((double)c[1] / 100.0));
+    }
+  return 0;
+}
