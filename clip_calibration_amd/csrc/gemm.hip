@@ -35,6 +35,7 @@ struct KArgs {
   const float* pos; int patches; int tokens;
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
+  int mix;       // gemm_pp_kernel, mixed tile heights: 0 = every tile BM rows; n > 0 = n - 1 tall (BM) m-tiles per XCD, the rest BM - 32
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   half_t* x16; float* stats_out;
 #ifdef CLIPMI_TUNING
@@ -106,6 +107,27 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int tiles_m, int& ti
   const int gw = rem < a.band ? rem : a.band;
   tile_m = within / gw;
   tile_n = b * a.band + (within - tile_m * gw);
+}
+
+// Mixed tile heights (gemm_pp_kernel, a.mix > 0; band == tiles_n, so logical ids walk m slow / n fast).  A launch of BM-row tiles
+// whose last round is part empty -- 474 tiles of 320 x 256 on 256 CUs for the image tower's residual GEMMs: every CU that runs two
+// tiles works through 640 rows while 38 CUs idle for a round -- is cut into MORE tiles of two heights instead: m-tiles of BM - 32 rows,
+// plus just enough of BM rows to cover M, chosen so that the whole grid still fits the same number of rounds.  The tall tiles are
+// the first a.mix - 1 m-tiles of every XCD's range of logical ids, i.e. they are all dispatched in the first round (blockIdx
+// order, 32 CUs per XCD), so no CU gets two of them: the critical path is BM + (rounds - 1)(BM - 32) rows instead of rounds * BM.
+// Every output element is still one workgroup's K-ordered sum: results are bit-identical to the uniform grid.
+__device__ __forceinline__ void mixed_tile_rows(const KArgs& a, int bm, int tile_m, int& m0, bool& tall) {
+  const int q = a.nwg >> 3, r = a.nwg & 7, n_tall = a.mix - 1;
+  int before = 0;
+  tall = false;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;   // first logical id of XCD x (tile_coords)
+    const int d = tile_m - (start + a.tiles_n - 1) / a.tiles_n;          // m-tiles past the first whole m-tile of that range
+    before += d <= 0 ? 0 : (d < n_tall ? d : n_tall);
+    tall = tall || (d >= 0 && d < n_tall);
+  }
+  m0 = (bm - 32) * tile_m + 32 * before;
 }
 
 // fp16 outputs: each wave transposes its tile through a private LDS patch (32 rows x 64 cols at a time) so that the
@@ -322,14 +344,17 @@ __device__ __forceinline__ void wait_chunk(int c) {   // c is a constant after u
 
 template <typename T>
 __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int tile_n,
-                                                             int wave_m, int wave_n, int lane, int wave, char* smem) {
+                                                             int wave_m, int wave_n, int lane, int wave, char* smem, int nb = T::TM) {
+  // nb: live 16-row blocks per wave (T::TM, or T::TM - 1 in the short tiles of a mixed-height grid: the wave's rows then start
+  // at wave_m * nb * 16, its last block holds nothing, and the rows behind it belong to the next wave or tile -- never touched)
   using F = FoldDma<T>;
   constexpr int TM = T::TM, TN = T::TN, NCH = F::NCH, RD = F::RD, CHB = F::CHB;
   static_assert(T::WTN == 64 && TM % 2 == 0 && TN == 4, "fold epilogue assumes 64-column wave tiles");
   const int r16 = lane & 15, g4 = lane >> 4;
   char* region = smem + wave * (RD * CHB);
   float2* red = reinterpret_cast<float2*>(smem + F::RED_OFF);   // [WGN][BM]
-  const int col0 = n0 + wave_n * 64, row0 = m0 + wave_m * T::WTM;   // wave-uniform
+  const int wrow = wave_m * nb * 16;
+  const int col0 = n0 + wave_n * 64, row0 = m0 + wrow;   // wave-uniform
   f32x4 bias[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -365,8 +390,9 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      const int ml = wave_m * T::WTM + (c * 2 + jj) * 16 + r16;
+      const int ml = wrow + (c * 2 + jj) * 16 + r16;
       const int m = m0 + ml;
+      const bool live = c * 2 + jj < nb;   // wave-uniform
       float rsum = 0.f, rsq = 0.f;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -374,7 +400,7 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
         char* p = reg + eoff[jj] + (((2 * i + (g4 >> 1)) ^ esw) << 4);
         const f16x4 r = *reinterpret_cast<const f16x4*>(p);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < a.M && n < a.N) {
+        if (m < a.M && n < a.N && live) {
           v = acc[i][c * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
@@ -385,7 +411,7 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
       }
       rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
       rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
-      if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
+      if (g4 == 0 && live) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
     }
     // same wave, LDS in order: the reads below see the writes above
 #pragma unroll
@@ -394,13 +420,13 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
       const f16x8 val = *reinterpret_cast<const f16x8*>(reg + rl * 128 + dslot * 16);
       const int m = row0 + c * 32 + rl;
       const int n_st = col0 + ((dslot ^ ((rl >> 1) & 7)) << 3);
-      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      if (m < a.M && n_st < a.N && c * 2 + (t >> 1) < nb) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (c + RD < NCH) dma_chunk(c + RD);   // its region was read (lgkmcnt drained for the stores above) a moment ago
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < T::BM; t += T::NT) {
+  for (int t = threadIdx.x; t < T::WGM * nb * 16; t += T::NT) {
     const int m = m0 + t;
     if (m < a.M) {
       float sx = 0.f, sq = 0.f;
@@ -421,9 +447,9 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 
 template <typename T, int EPI, bool OUT_F32, bool DMA_RES = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
-                                         int lane, int wave, char* smem, const float2* lnp = nullptr) {
+                                         int lane, int wave, char* smem, const float2* lnp = nullptr, int nb = T::TM) {
   if constexpr (EPI == EPI_RESIDUAL_FOLD16 && DMA_RES) {
-    epilogue_residual_fold16_dma<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
+    epilogue_residual_fold16_dma<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem, nb);
     return;
   }
   if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) {
@@ -1837,9 +1863,20 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
   const int grp = wave >> 2;   // uniform: waves w and w + 4 share a SIMD
 
+  // mixed tile heights (mixed_tile_rows): only the fp16-stream residual epilogue of the 320-row tile knows about short tiles
+  constexpr bool MIX = EPI == EPI_RESIDUAL_FOLD16 && H == 5 && !WIDE;
   int tile_m, tile_n;
-  tile_coords(a, (a.M + BM - 1) / BM, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * T::BN;
+  tile_coords(a, a.nwg / a.tiles_n, tile_m, tile_n);
+  int m0 = tile_m * BM;
+  bool tall = true;   // workgroup-uniform (kernel arguments and blockIdx only)
+  if constexpr (MIX) {
+    if (a.mix > 0) {
+      mixed_tile_rows(a, BM, tile_m, m0, tall);
+      if (m0 >= a.M) return;   // spare tile of the last round
+    }
+  }
+  const int nb = tall ? TM : TM - 1;   // live 16-row blocks per wave: the wave's rows start at wave_m * nb * 16
+  const int n0 = tile_n * T::BN;
 
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
@@ -1870,7 +1907,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   const int swz = (r16 >> 1) & 7;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t f0 = (uint32_t)(r16 * 128 + (((0 + g4) ^ swz) << 4)), f1 = (uint32_t)(r16 * 128 + (((4 + g4) ^ swz) << 4));
-  const uint32_t xb = (uint32_t)(wave_m * T::WTM * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
+  const uint32_t xb = (uint32_t)(wave_m * nb * 16 * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
   const int nk = a.K / BK;
 
 #ifdef CLIPMI_TUNING
@@ -1936,7 +1973,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
         ds_read128<(JH * H + 1) * 2048>(xf[1], xa);
         ds_read128<(JH * H + 2) * 2048>(xf[2], xa);
         ds_read128<(JH * H + 3) * 2048>(xf[3], xa);
-        if constexpr (H == 5) ds_read128<(JH * H + 4) * 2048>(xf[H - 1], xa);
+        if constexpr (H == 5) {
+          if (!MIX || JH == 0 || tall) ds_read128<(JH * H + 4) * 2048>(xf[H - 1], xa);   // a short tile has no tenth block
+        }
         if constexpr (JH == 0) {
           const uint32_t wa = KS ? wa1 : wa0;
           ds_read128<0>(wf[0], wa);
@@ -1964,7 +2003,8 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < H; ++j)
+      for (int j = 0; j < H; ++j) {
+        if (MIX && JH == 1 && j == H - 1 && !tall) break;   // short tile: block TM - 1 does not exist (uniform branch)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           if constexpr (FIRSTK && KS == 0)
@@ -1972,6 +2012,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
           else
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
         }
+      }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (P == 3) {
         if (grp == 0) wait_vmcnt<0>();
@@ -2075,7 +2116,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   }
 #endif
 #undef PP_T
-  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
+  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp, MIX ? nb : TM);
 #ifdef CLIPMI_TUNING
   if (a.stamps != nullptr) {
     if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -2094,9 +2135,25 @@ int launch_pp(KArgs k, hipStream_t s) {
   constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   static_assert(SMEM <= 160 * 1024, "tile does not fit the CU's LDS");
   ensure_dynamic_lds(fn, SMEM, attr_once);
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
+  int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
+  k.mix = 0;
+  if constexpr (EPI == EPI_RESIDUAL_FOLD16 && T::BM == 320 && !WIDE) {
+    // Mixed tile heights (mixed_tile_rows): as many m-tiles as the launch's rounds hold, 288 rows each, plus the 320-row ones
+    // needed to cover M -- at most (32 CUs - tiles_n + 1) / tiles_n per XCD, so that all of them start in the first round.
+    const int n_cu = device_cus(), tn = k.tiles_n;
+    const int rounds = (int)(((int64_t)tiles_m * tn + n_cu - 1) / n_cu);
+    if (options().gemm_mix.load(std::memory_order_relaxed) == 1 && rounds >= 2 && n_cu % 8 == 0 && k.band == tn) {
+      const int64_t fit = (int64_t)rounds * n_cu / tn;                       // m-tiles that fit the same number of rounds
+      const int64_t need = (int64_t)k.M - (int64_t)(T::BM - 32) * fit;       // rows the tall tiles must add
+      const int n_tall = need <= 0 ? 0 : (int)((need + 32 * 8 - 1) / (32 * 8));   // per XCD
+      if (fit < (1 << 24) && fit >= tiles_m && n_tall * tn + tn - 1 <= n_cu / 8 && (int64_t)(n_tall + 2) * tn <= fit * tn / 8) {
+        k.mix = n_tall + 1;
+        tiles_m = n_tall == 0 ? (k.M + (T::BM - 32) - 1) / (T::BM - 32) : (int)fit;   // all short: no spare tiles needed
+      }
+    }
+  }
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
@@ -2649,7 +2706,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   CLIPMI_REQUIRE((!a.x16 && !a.stats_out) || (a.x16 && a.stats_out && a.parts_out && a.epilogue == CLIPMI_EPI_BIAS_RESIDUAL &&
                                               a.N % 8 == 0 && a.ldo % 8 == 0),
                  CLIPMI_ERR_ARG, "gemm: x16/stats_out/parts_out come together, only with BIAS_RESIDUAL and N %% 8 == 0");
-  k.tiles_n = 0; k.nwg = 0;
+  k.tiles_n = 0; k.nwg = 0; k.mix = 0;
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:

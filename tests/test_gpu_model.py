@@ -321,6 +321,25 @@ def test_vit_large_towers_vs_oracle(gname, batch):
     assert np.abs(cos - _cos(ref_i, ref_t)).max() < COS_TOL
 
 
+@pytest.mark.parametrize("batch", [256, 300, 160, 131])
+def test_mixed_tile_heights_bit_identical(clipmi_option, batch):
+    """Option gemm_mix (off by default: it measured no faster): the fp16-stream residual GEMMs (out-proj, c_proj) run 288- and 320-row tiles in one grid when
+    the uniform 320-row grid leaves its last round part empty.  Only the partition of the rows over workgroups changes -- every
+    output element and every LayerNorm row partial is the same K-ordered / column-ordered sum -- so the image features must be
+    bit-identical: batch 256 (6 tall m-tiles per XCD, 510 tiles in 2 rounds), 300 and 160 (all tiles short), 131 (M = 25807: 1.9
+    rounds of 320-row tiles -> 90 short m-tiles), twice each to screen for a race on the rows between neighbouring tiles."""
+    sd, model = _build("ViT-B/16")
+    images = syn.synthetic_images(batch, "ViT-B/16", seed=9).cuda()
+    with torch.no_grad():
+        clipmi_option("gemm_mix", 0)
+        ref = model.image_features_f32(images).clone()
+        clipmi_option("gemm_mix", 1)
+        a = model.image_features_f32(images).clone()
+        b = model.image_features_f32(images).clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+
+
 @pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70)])
 @pytest.mark.parametrize("fold,f16", [(1, 2), (1, 0), (0, 0)])
 def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
