@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-      Vec4<TO>::store(yr + c * 4, o);
+      if (y) Vec4<TO>::store(yr + c * 4, o);   // y == nullptr: only the fp16 copy and the row sums are wanted (fp16 residual stream)
       if (y16) {   // producer side of the LayerNorm fold (gemm.hip): fp16 copy + row sums of the OUTPUT
         Vec4<half_t>::store(y16 + (int64_t)row * out_stride + c * 4, o);
         os += (o[0] + o[1]) + (o[2] + o[3]);
@@ -114,7 +114,7 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
                      const float* beta, void* y, int y_dtype, int64_t out_stride, int rows, int D, float eps,
                      hipStream_t s, half_t* y16, float* stats_out) {
   if (rows == 0) return CLIPMI_OK;
-  CLIPMI_REQUIRE(x && gamma && beta && y, CLIPMI_ERR_ARG, "layernorm: null pointer");
+  CLIPMI_REQUIRE(x && gamma && beta && (y || y16), CLIPMI_ERR_ARG, "layernorm: null pointer");
   CLIPMI_REQUIRE((!y16 && !stats_out) || (y16 && stats_out), CLIPMI_ERR_ARG, "layernorm: y16 and stats_out come together");
   CLIPMI_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, CLIPMI_ERR_SHAPE,
                  "layernorm: rows=%d D=%d unsupported (D %% 4 == 0, D <= 4096)", rows, D);
