@@ -16,6 +16,51 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MODE 0: 16x16x32 f16, 16 accumulator tiles (4x4 operands, the GEMM's wave tile).  MODE 1: 32x32x16 f16, 4 accumulator tiles (2x2 operands):
 // the same 64x64 wave tile, the same flops per operand set, half the operand register reads per flop.
 // NOPS: number of distinct operand sets rotated through (register-resident), so that operand values change between MFMAs like in a K loop.
+// probe_lds<R>: the 16x16x32 loop of MODE 0 with R ds_read_b128 per 32 MFMAs refreshing the operand registers from LDS (same values:
+// the LDS image is the operand set itself) -- the GEMM main loops read 12 per 32 MFMAs (8 waves of 128 x 64 per 256 x 256 tile).
+template <int R>
+__global__ __launch_bounds__(512) void probe_lds(const f16x8* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* clk) {
+  __shared__ f16x8 img[16 * 512];
+  const int lane = threadIdx.x;
+  for (int i = 0; i < 16; ++i) img[i * 512 + lane] = src[(size_t)i * 512 + lane];
+  __syncthreads();
+  f16x8 a[2][4], b[2][4];
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 4; ++i) {
+      a[s][i] = img[(s * 8 + i) * 512 + lane];
+      b[s][i] = img[(s * 8 + 4 + i) * 512 + lane];
+    }
+  unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  f32x4 acc[4][4] = {};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][u], b[s][v], acc[u][v], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // refresh operands of the OTHER set (used 16+ MFMAs from now): R / 8 reads after each group of four MFMAs
+#pragma unroll
+        for (int q = 0; q < R / 8; ++q) {
+          const int idx = (u * (R / 8) + q) & 7;
+          f16x8* dstp = idx < 4 ? &a[s ^ 1][idx] : &b[s ^ 1][idx - 4];
+          const int slot = (s ^ 1) * 8 + idx;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(*dstp) : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(img + slot * 512 + lane)));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  float r = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  dst[blockIdx.x * 512 + lane] = r;
+  unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && lane == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512) void probe(const f16x8* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* clk) {
   const int lane = threadIdx.x;
@@ -87,11 +132,15 @@ int main(int argc, char** argv) {
       case 0: probe<0><<<256, waves * 64>>>(src, dst, iters, clk); break;
       case 1: probe<1><<<256, waves * 64>>>(src, dst, iters, clk); break;
       case 2: probe<2><<<256, waves * 64>>>(src, dst, iters, clk); break;
-      default: probe<3><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 3: probe<3><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 4: probe_lds<8><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 5: probe_lds<16><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      default: probe_lds<32><<<256, waves * 64>>>(src, dst, iters, clk); break;
     }
   };
-  static const char* names[] = {"16x16x32 A held x4", "32x32x16", "16x16x32 B held x4", "16x16x32 both change"};
-  for (int mode = 0; mode < 4; ++mode)
+  static const char* names[] = {"16x16x32 A held x4", "32x32x16", "16x16x32 B held x4", "16x16x32 both change", "16x16x32 + 8 ds_read_b128 / 32 MFMA",
+                                "16x16x32 + 16 ds_read_b128 / 32 MFMA", "16x16x32 + 32 ds_read_b128 / 32 MFMA"};
+  for (int mode = 0; mode < 7; ++mode)
     for (int rep = 0; rep < 2; ++rep) {
       // flops per wave per iteration: 2 operand sets x (64 x 64 x 32) MACs x 2
       const double flop = 2.0 * 2 * 64 * 64 * 32 * (double)iters * waves * 256;
