@@ -44,22 +44,44 @@ class EmbeddingExchange:
         self._comm = None
         self.backend = "torch"
         if backend in ("rccl", "auto") and self.device.type == "cuda":
-            try:
-                uid = [bytes(_lib.COMM_ID_BYTES)]
-                if self.rank == 0:
+            # Every rank must take the same branch: a rank that raised before ncclCommInitRank would leave the others waiting in it,
+            # and one that fell back alone would wait in a different collective.  So rank 0 broadcasts an EMPTY id when it cannot
+            # make one, and the ranks agree (min over a CPU flag) on whether every communicator came up.
+            reason, handle = "", None
+            uid = [b""]
+            if self.rank == 0:
+                try:
                     buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
                     _lib.check(_lib.lib.clipmi_comm_unique_id(buf), "clipmi_comm_unique_id")
                     uid = [buf.raw]
-                if self.world > 1:
-                    dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                handle = C.c_void_p()
-                with torch.cuda.device(self.device):
-                    _lib.check(_lib.lib.clipmi_comm_create(uid[0], self.world, self.rank, C.byref(handle)), "clipmi_comm_create")
+                except (_lib.ClipmiError, RuntimeError, AttributeError, OSError) as e:
+                    reason = str(e)
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                           device=torch.device("cpu"))
+            if uid[0]:
+                try:
+                    handle = C.c_void_p()
+                    with torch.cuda.device(self.device):
+                        _lib.check(_lib.lib.clipmi_comm_create(uid[0], self.world, self.rank, C.byref(handle)), "clipmi_comm_create")
+                except (_lib.ClipmiError, RuntimeError, AttributeError, OSError) as e:
+                    reason, handle = str(e), None
+            else:
+                reason = reason or "rank 0 could not create an RCCL unique id"
+            ok = handle is not None
+            if self.world > 1:
+                flag = torch.tensor([int(ok)], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if ok and int(flag.item()) == 0:
+                    reason = "another rank could not build its communicator"
+                    _lib.lib.clipmi_comm_destroy(handle)
+                    ok = False
+            if ok:
                 self._comm, self.backend = handle, "rccl"
-            except (_lib.ClipmiError, RuntimeError) as e:
-                if backend == "rccl":
-                    raise
-                print(f"[clip_calibration_amd] RCCL communicator unavailable ({e}); using torch.distributed", flush=True)
+            elif backend == "rccl":
+                raise RuntimeError(f"RCCL communicator unavailable: {reason}")
+            else:
+                print(f"[clip_calibration_amd] RCCL communicator unavailable ({reason}); using torch.distributed", flush=True)
 
     @property
     def rccl_ranks(self) -> Optional[int]:

@@ -340,6 +340,23 @@ def test_mixed_tile_heights_bit_identical(clipmi_option, batch):
     assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
 
 
+@pytest.mark.parametrize("n_prompts", [1000, 700])
+def test_mixed_tile_heights_text_tower(clipmi_option, n_prompts):
+    """gemm_mix on the text tower's shapes (fp16 residual stream switched on for it: residual_f16 = 1): N = 512 is two column
+    tiles, M = 77 000 gives 13 tall m-tiles per XCD among 256, M = 53 900 an all-short grid -- bit-identical text features."""
+    clipmi_option("residual_f16", 1)
+    sd, model = _build("ViT-B/16")
+    ids = syn.synthetic_token_ids(n_prompts, "ViT-B/16", seed=4).cuda()
+    with torch.no_grad():
+        clipmi_option("gemm_mix", 0)
+        ref = model.text_features_f32(ids).clone()
+        clipmi_option("gemm_mix", 1)
+        a = model.text_features_f32(ids).clone()
+        b = model.text_features_f32(ids).clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+
+
 @pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70)])
 @pytest.mark.parametrize("fold,f16", [(1, 2), (1, 0), (0, 0)])
 def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
