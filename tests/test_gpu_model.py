@@ -562,6 +562,39 @@ def test_cocoop_vs_oracle_with_dac_larger_batch():
     assert np.abs(imf.cpu().numpy() @ r_f.numpy().T - (r_f @ r_f.t()).numpy()).max() < COS_TOL
 
 
+def test_cocoop_text_stream_f16_at_depth():
+    """CoCoOp runs its text tower -- the hot path there -- on the fp16 residual stream (text_stream_f16, default on; the
+    reference's GPU precision, clip/model.py:186-187).  At ViT-B/16 depth: against the fp32-stream setting and against the
+    oracle, in cosine-logit terms; a process-wide residual_f16 = 0 is respected (bit-identical to text_stream_f16 = False)."""
+    from clip_calibration_amd import _lib
+    from clip_calibration_amd.trainers import CoCoOpCLIP
+    sd, model = _build("ViT-B/16")
+    B, C = 3, 24
+    ids = syn.synthetic_token_ids(C, "ViT-B/16", seed=41, n_ctx_placeholders=4)
+    images = syn.synthetic_images(B, "ViT-B/16", seed=41)
+    outs = {}
+    for f16 in (True, False):
+        co = CoCoOpCLIP(model, ids, n_ctx=4, prompts_per_call=48, seed=5, text_stream_f16=f16)
+        with torch.no_grad():
+            for p in co.prompt_learner.meta_net.parameters():
+                p.copy_((torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.05).to(p))
+        outs[f16] = co(images.cuda())[0].cpu().numpy() / co.scale
+        if f16:
+            pl = {k: v.detach().float().cpu() for k, v in co.prompt_learner.state_dict().items()}
+            with _lib.option("residual_f16", 0):
+                fp32_everywhere = co(images.cuda())[0].cpu().numpy() / co.scale
+            with _lib.option("residual_f16", 0):
+                co.text_stream_f16 = False
+                assert np.array_equal(co(images.cuda())[0].cpu().numpy() / co.scale, fp32_everywhere)
+    assert _lib.get_option("residual_f16") == 2                                  # restored
+    assert np.abs(outs[True] - outs[False]).max() < COS_TOL / 2
+    assert np.abs(outs[True] - outs[False]).max() > 0                            # the switch does switch
+    with torch.no_grad():
+        r_logits, _, _ = orc.cocoop_forward(sd, pl, images, ids)
+    ref = r_logits.numpy() / float(sd["logit_scale"].exp())
+    assert np.abs(outs[True] - ref).max() < COS_TOL and np.abs(outs[False] - ref).max() < COS_TOL
+
+
 def test_promptsrc_and_vpt_mirrors():
     """PromptSRC eval forward = CoOp splice through an IVLP-design CLIP (promptsrc.py:186-214); VPT = fixed hand-written
     text embeddings + a VPT-design image tower (vpt.py:94-116).  Oracle with the model's own prompt tokens."""
