@@ -41,6 +41,7 @@ const OptionDesc kOptions[] = {
     {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
     {"gemm_pp", "CLIPMI_GEMM_PP", &Options::gemm_pp},
     {"gemm_mix", "CLIPMI_GEMM_MIX", &Options::gemm_mix},
+    {"ln_inline", "CLIPMI_LN_INLINE", &Options::ln_inline},
     {"cls_only_last_block", "CLIPMI_CLS_ONLY_LAST_BLOCK", &Options::cls_only_last_block},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},

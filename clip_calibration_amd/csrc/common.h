@@ -50,6 +50,8 @@ struct Options {
   std::atomic<int> gemm_stream{1};     // CLIPMI_GEMM_STREAM: 1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs
                                        // with K >= 512 (in-proj / c_fc: -5..-9 % per launch, -4 % per image-tower step, four boxes); 0 = one tile per workgroup
   std::atomic<int> gemm_pp{1};         // CLIPMI_GEMM_PP: 1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
+  std::atomic<int> ln_inline{1};       // CLIPMI_LN_INLINE: 1 (default) = gemm_stream_kernel finalises the LayerNorm row partials in its epilogue (no ln_finalize_kernel
+                                       // launch in front of the folded in-proj / c_fc GEMMs); 0 = one ln_finalize_kernel launch per folded GEMM
   std::atomic<int> gemm_mix{0};        // CLIPMI_GEMM_MIX: 1 = mixed tile heights (288 / 320 rows) in gemm_pp_kernel's fp16-stream residual GEMMs when the uniform
                                        // grid leaves its last round part empty (same bits; measured -0.5 % per launch only: the chip is power-bound, not
                                        // CU-bound); 0 (default) = uniform 320-row tiles

@@ -57,6 +57,16 @@ struct KArgs {
 // The consumer adds the partials in order and forms the variance E[x^2] - mean^2 in double.  g is summed from the
 // fp16-rounded folded weights the MFMA actually multiplies, so the mean term cancels as it does inside a LayerNorm.
 // ---------------------------------------------------------------------------------------------------------------
+// explicit fused multiply-adds: the same bits wherever this is inlined (ln_finalize_kernel, the tile prologues, the streamed
+// kernel's epilogue), whatever the surrounding code lets the compiler contract
+__device__ __forceinline__ void ln_params_from_sums(const KArgs& a, double s, double ss, float& rstd, float& mu_rstd) {
+  const double mean = s * (double)a.ln_inv_d;
+  double var = __builtin_fma(ss, (double)a.ln_inv_d, -(mean * mean));
+  var = var > 0.0 ? var : 0.0;
+  rstd = rsqrtf((float)var + a.ln_eps);
+  mu_rstd = (float)mean * rstd;
+}
+
 __device__ __forceinline__ void ln_row_params(const KArgs& a, int m, float& rstd, float& mu_rstd) {
   const int mm = m < a.M ? m : a.M - 1;
   double s = 0.0, ss = 0.0;
@@ -65,11 +75,7 @@ __device__ __forceinline__ void ln_row_params(const KArgs& a, int m, float& rstd
     s += (double)st.x;
     ss += (double)st.y;
   }
-  const double mean = s * (double)a.ln_inv_d;
-  double var = ss * (double)a.ln_inv_d - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  rstd = rsqrtf((float)var + a.ln_eps);
-  mu_rstd = (float)mean * rstd;
+  ln_params_from_sums(a, s, ss, rstd, mu_rstd);
 }
 
 // Tile configuration: BM x BN workgroup tile (m = activation rows, n = weight rows), WGM x WGN waves.
@@ -1393,19 +1399,33 @@ __device__ __forceinline__ void lgkm_wait5(f16x8& a, f16x8& b, f16x8& c, f16x8& 
 #define CLIPMI_STREAM_PREFETCH 1
 #endif
 using TStream = Tile<256, 256, 2, 4, 2>;
+constexpr int STREAM_RAW_PARTS = 4;   // row-partial slots of gemm_stream_kernel's LDS table (D <= 1024 with 256-column producer tiles)
+// the streamed kernel can finalise the LayerNorm row partials itself (RAW mode) unless there are too many or the option says no;
+// without a scratch row for ln_finalize_kernel it must
+inline bool stream_raw_ok(const KArgs& k, const float2* ln_rows) {
+  if (k.ln_parts > STREAM_RAW_PARTS) return false;
+  return ln_rows == nullptr || options().ln_inline.load(std::memory_order_relaxed) == 1;
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
   using T = TStream;
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;   // TM = 8, TN = 4
-  constexpr int LNP_OFF = T::SMEM, COLP_OFF = LNP_OFF + 2 * BM * 8;             // 2 x [BM] (rstd, mean*rstd) | 2 x ([BN] bias | [BN] g)
+  // LDS behind the stages: 2 x (row parameters of a tile) | 2 x ([BN] bias | [BN] g).  Row parameters are either the finalised
+  // (rstd, mean * rstd) pairs of ln_finalize_kernel (ln_rows != nullptr) or -- RAW mode, ln_rows == nullptr with a.ln_stats set, up
+  // to STREAM_RAW_PARTS partials -- the producer's (sum, sumsq) row partials themselves, finalised in the epilogue with the
+  // arithmetic of ln_row_params: the launch of ln_finalize_kernel in front of every folded GEMM (4.8 us + a launch gap, 24 per
+  // image-tower step) goes away for ~100 instructions per wave and tile.
+  constexpr int LNP_PAR = STREAM_RAW_PARTS * BM * 8;
+  constexpr int LNP_OFF = T::SMEM, COLP_OFF = LNP_OFF + 2 * LNP_PAR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const bool fold = ln_rows != nullptr;   // kernel argument: uniform
+  const bool raw = ln_rows == nullptr && a.ln_stats != nullptr;   // kernel arguments: uniform
+  const bool fold = ln_rows != nullptr || raw;
 
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
@@ -1461,10 +1481,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   // row / column parameters of a tile -> LDS by DMA, one 1 KiB piece per wave (waves 0-3); rows / columns outside the
   // matrix lie outside the descriptors and read as zero.  They ride on the same vmcnt wait as the tile's first stage.
   auto params = [&](int row0, int col0, int which) {
-    char* lnp = smem + LNP_OFF + which * (BM * 8);
+    char* lnp = smem + LNP_OFF + which * LNP_PAR;
     char* colp = smem + COLP_OFF + which * (2 * BN * 4);
     if (wave < 2) {
-      if (fold) {
+      if (raw) {
+        for (int p = 0; p < a.ln_parts; ++p) {   // [parts][M] float2: 2 KiB of each partial belong to this tile's rows
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_stats + 2 * ((int64_t)p * a.M + row0), (int64_t)(a.M - row0) * 8);
+          CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + p * (BM * 8) + wave * 1024, (wave * 64 + lane) * 16, 0);
+        }
+      } else if (fold) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows + row0, (int64_t)(a.M - row0) * 8);
         CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, (wave * 64 + lane) * 16, 0);
       }
@@ -1482,7 +1507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   };
   // constant parts of the parameter tables (no fold: rstd = 1, mean * rstd = 0, g = 0; no bias: 0), both parities
   for (int t = tid; t < 2 * BM; t += NT)
-    if (!fold) reinterpret_cast<float2*>(smem + LNP_OFF)[t] = make_float2(1.f, 0.f);
+    if (!fold) reinterpret_cast<float2*>(smem + LNP_OFF + (t / BM) * LNP_PAR)[t % BM] = make_float2(1.f, 0.f);
   for (int t = tid; t < 2 * 2 * BN; t += NT) {
     const bool is_g = (t / BN) & 1;
     if (is_g ? !fold : EPI == CLIPMI_EPI_NONE) reinterpret_cast<float*>(smem + COLP_OFF)[t] = 0.f;
@@ -1672,6 +1697,21 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
     }
 #endif
+    // RAW mode: the tile's row partials have landed (the wait and barrier above): thread t owns row t, reduces its partials with
+    // the arithmetic of ln_row_params and leaves (rstd, mean * rstd) in slot 0 of the table, in place.  Read in the epilogue, a
+    // whole K loop of workgroup barriers later.  Rows past M read as zeros and are never stored.
+    if (raw && tid < BM) {
+      float2* rp = reinterpret_cast<float2*>(smem + LNP_OFF + par * LNP_PAR) + tid;
+      double ps = 0.0, pss = 0.0;
+      for (int p = 0; p < a.ln_parts; ++p) {
+        const float2 st = rp[p * BM];
+        ps += (double)st.x;
+        pss += (double)st.y;
+      }
+      float rs, mrs;
+      ln_params_from_sums(a, ps, pss, rs, mrs);
+      rp[0] = make_float2(rs, mrs);
+    }
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
     using I = std::integral_constant<int, -1>;
@@ -1723,7 +1763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       int le = lane;
       asm volatile("" : "+v"(le));   // keeps the lane-derived offsets below out of the K loop's live ranges
       const int er16 = le & 15, eg4 = le >> 4;
-      const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM;
+      const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF + par * LNP_PAR);
       const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
       f32x4 bb[TN], gg[TN];
       float2 pr[TM];
@@ -1808,7 +1848,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 template <int EPI>
 int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
   using T = TStream;
-  constexpr int SMEM = T::SMEM + 2 * T::BM * 8 + 2 * 2 * T::BN * 4;
+  constexpr int SMEM = T::SMEM + 2 * STREAM_RAW_PARTS * T::BM * 8 + 2 * 2 * T::BN * 4;
   static_assert(SMEM <= 160 * 1024, "stream kernel LDS");
   static DeviceOnce attr_once;
   auto fn = gemm_stream_kernel<EPI>;
@@ -1821,13 +1861,16 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   CLIPMI_REQUIRE(257 * k.ldo * 2 < (1ll << 31), CLIPMI_ERR_SHAPE, "gemm: output rows too long for the 32-bit tile offsets of the streamed epilogue");
   k.nwg = (int)nwg;
-  if (k.ln_stats) {   // the row partials -> (rstd, mean * rstd), once per GEMM
+  // RAW mode (default): the kernel finalises the row partials itself; otherwise (more partials than its LDS table holds, or
+  // option ln_inline = 0) they are reduced to (rstd, mean * rstd) once per GEMM by ln_finalize_kernel
+  const bool raw = k.ln_stats && stream_raw_ok(k, ln_rows);
+  if (k.ln_stats && !raw) {
     hipLaunchKernelGGL(ln_finalize_kernel, dim3((k.M + 255) / 256), dim3(256), 0, s, k, ln_rows);
     const int rc = check_launch("ln_finalize_kernel");
     if (rc) return rc;
   }
   const int grid = k.nwg < n_cu ? k.nwg : n_cu;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k, static_cast<const float2*>(k.ln_stats ? ln_rows : nullptr));
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k, static_cast<const float2*>(k.ln_stats && !raw ? ln_rows : nullptr));
   return check_launch("gemm_stream_kernel");
 }
 
@@ -2625,7 +2668,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   }
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
     if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && options().gemm_stream.load(std::memory_order_relaxed) == 1 &&
-        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows) &&
+        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
         (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
       variant = 13;
   }
@@ -2658,7 +2701,8 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
       return launch_tile<T256w8, EPI, OUT_F32>(k, s);
     case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
       if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows)) return launch_stream<EPI>(k, ln_rows, s);
+        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS))
+          return launch_stream<EPI>(k, ln_rows, s);
       }
       return launch_tile<T256w16, EPI, OUT_F32>(k, s);
     case 15:   // deferred-store persistent kernel: fp16-out epilogues on 8-column-aligned outputs only

@@ -68,6 +68,8 @@ const char* clipmi_last_error(void);
  *                                             1 = 16 waves, 2 = 16 waves with DMA'd row / column parameters, 3 = 8 waves with them
  *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs, K >= 512
  *   gemm_pp          (CLIPMI_GEMM_PP)         1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
+ *   ln_inline        (CLIPMI_LN_INLINE)       1 (default) = the streamed GEMM kernel reduces the LayerNorm row partials of its tile itself (no
+ *                                             ln_finalize_kernel launch per folded GEMM; same bits); 0 = one such launch per folded GEMM
  *   gemm_mix         (CLIPMI_GEMM_MIX)        0 (default) = uniform 320-row tiles in the residual GEMMs; 1 = 288- and 320-row tiles in one grid when the
  *                                             uniform grid's last round is part empty (bit-identical results; A/B aid, no faster on a power-bound chip)
  *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block

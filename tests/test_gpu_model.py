@@ -340,6 +340,25 @@ def test_mixed_tile_heights_bit_identical(clipmi_option, batch):
     assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
 
 
+@pytest.mark.parametrize("gname,batch", [("ViT-B/16", 256), ("ViT-B/16", 131), ("ViT-L/14@336px", 40)])
+def test_layernorm_partials_finalised_in_kernel(clipmi_option, gname, batch):
+    """Option ln_inline (default 1): gemm_stream_kernel reduces the LayerNorm row partials of its tile itself (thread t owns row t,
+    ln_row_params' arithmetic, in place in LDS) instead of reading what one ln_finalize_kernel launch per folded GEMM prepared.
+    Same sums in the same order -> bit-identical image features; ViT-L is the four-partial case (width 1024)."""
+    if gname not in syn.GEOMETRIES:
+        pytest.skip(f"no synthetic geometry {gname}")
+    sd, model = _build(gname)
+    images = syn.synthetic_images(batch, gname, seed=12).cuda()
+    with torch.no_grad():
+        clipmi_option("ln_inline", 0)
+        ref = model.image_features_f32(images).clone()
+        clipmi_option("ln_inline", 1)
+        a = model.image_features_f32(images).clone()
+        b = model.image_features_f32(images).clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+
+
 @pytest.mark.parametrize("n_prompts", [1000, 700])
 def test_mixed_tile_heights_text_tower(clipmi_option, n_prompts):
     """gemm_mix on the text tower's shapes (fp16 residual stream switched on for it: residual_f16 = 1): N = 512 is two column
