@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +54,36 @@ __global__ __launch_bounds__(512) void probe_lds(const f16x8* __restrict__ src, 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+  }
+  float r = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  dst[blockIdx.x * 512 + lane] = r;
+  unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && lane == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+// bf16 operands (the same normal values rounded to bfloat16: 8 x 8-bit significand products instead of 11 x 11), MODE 0's issue order
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512) void probe_bf16(const bf16x8* __restrict__ src, float* __restrict__ dst, int iters, unsigned long long* clk) {
+  const int lane = threadIdx.x;
+  bf16x8 a[2][4], b[2][4];
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 4; ++i) {
+      a[s][i] = src[(size_t)(s * 8 + i) * 512 + lane];
+      b[s][i] = src[(size_t)(s * 8 + 4 + i) * 512 + lane];
+    }
+  unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  f32x4 acc[4][4] = {};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][u], b[s][v], acc[u][v], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
   }
   float r = 0;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
@@ -126,6 +157,15 @@ int main(int argc, char** argv) {
   f16x8* src; float* dst; unsigned long long* clk;
   CK(hipMalloc(&src, h.size() * 2)); CK(hipMalloc(&dst, 256 * 512 * 4)); CK(hipMalloc(&clk, 16));
   CK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  std::vector<unsigned short> hb(h.size());   // the same values as bfloat16 (round to nearest even on the fp32 bits)
+  for (size_t i = 0; i < h.size(); ++i) {
+    float f = (float)h[i];
+    unsigned u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    hb[i] = (unsigned short)(u >> 16);
+  }
+  bf16x8* srcb; CK(hipMalloc(&srcb, hb.size() * 2));
+  CK(hipMemcpy(srcb, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&](int mode) {
     switch (mode) {
@@ -135,12 +175,13 @@ int main(int argc, char** argv) {
       case 3: probe<3><<<256, waves * 64>>>(src, dst, iters, clk); break;
       case 4: probe_lds<8><<<256, waves * 64>>>(src, dst, iters, clk); break;
       case 5: probe_lds<16><<<256, waves * 64>>>(src, dst, iters, clk); break;
-      default: probe_lds<32><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      case 6: probe_lds<32><<<256, waves * 64>>>(src, dst, iters, clk); break;
+      default: probe_bf16<<<256, waves * 64>>>(srcb, dst, iters, clk); break;
     }
   };
   static const char* names[] = {"16x16x32 A held x4", "32x32x16", "16x16x32 B held x4", "16x16x32 both change", "16x16x32 + 8 ds_read_b128 / 32 MFMA",
-                                "16x16x32 + 16 ds_read_b128 / 32 MFMA", "16x16x32 + 32 ds_read_b128 / 32 MFMA"};
-  for (int mode = 0; mode < 7; ++mode)
+                                "16x16x32 + 16 ds_read_b128 / 32 MFMA", "16x16x32 + 32 ds_read_b128 / 32 MFMA", "16x16x32 bf16"};
+  for (int mode = 0; mode < 8; ++mode)
     for (int rep = 0; rep < 2; ++rep) {
       // flops per wave per iteration: 2 operand sets x (64 x 64 x 32) MACs x 2
       const double flop = 2.0 * 2 * 64 * 64 * 32 * (double)iters * waves * 256;
