@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLIPMI_LIBRARY") or os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
 COMM_ID_BYTES = 128
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_BIAS_RESIDUAL, EPI_BIAS_RELU, EPI_BIAS_RESIDUAL16_RELU = 0, 1, 2, 3, 4, 5
+CALL_DEFAULT, CALL_STREAM_F32, CALL_STREAM_F16 = 0, 1, 2   # per-call flags of the tower calls (include/clipmi.h)
 
 
 class ClipmiError(RuntimeError):
@@ -63,7 +64,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_vp, _i, _i64, _f, _sz, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint
 
 _SIGNATURES = {
     "clipmi_abi_version": (C.c_int, []),
@@ -72,6 +73,7 @@ _SIGNATURES = {
     "clipmi_set_option": (_i, [C.c_char_p, _i]),
     "clipmi_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "clipmi_gemm_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_gemm_residual_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, C.POINTER(_i), _i, _i, _i, _vp]),
     "clipmi_layernorm": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp]),
     "clipmi_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
@@ -107,10 +109,12 @@ _SIGNATURES = {
     "clipmi_set_text_weights": (_i, [_vp, C.POINTER(TextWeights)]),
     "clipmi_vision_workspace_bytes": (_sz, [_vp, _i, _i]),
     "clipmi_text_workspace_bytes": (_sz, [_vp, _i]),
-    "clipmi_encode_image": (_i, [_vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _vp]),
-    "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _vp]),
-    "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _vp]),
-    "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "clipmi_model_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "clipmi_model_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
+    "clipmi_encode_image": (_i, [_vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
+    "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _u, _vp]),
+    "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
+    "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _u, _vp]),
     "clipmi_profile_block": (_i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
 }
 
@@ -136,7 +140,8 @@ def check(rc: int, what: str) -> None:
 
 
 def set_option(name: str, value: int) -> None:
-    """Process-wide runtime switch (include/clipmi.h, clipmi_set_option)."""
+    """Process-wide runtime switch (include/clipmi.h, clipmi_set_option): tests and A/B tools only -- product code selects
+    precision per model (CLIP.set_option) or per call (flags), never through this."""
     check(lib.clipmi_set_option(name.encode(), int(value)), "clipmi_set_option")
 
 
@@ -162,11 +167,11 @@ class option:
         return False
 
 
-_VARIANT_LETTERS = {"a": 10, "b": 11, "c": 12, "s": 13, "f": 15}
+_VARIANT_LETTERS = {"a": 10, "s": 13, "r": 16}
 
 
 def gemm_variant_id(v) -> int:
-    """'0'..'9' / 'a' 'b' 'c' 'f' (the historical CLIPMI_GEMM_VARIANT spellings) or an int -> option value; None -> -1."""
+    """'0' '1' / 'a' 's' 'r' (the CLIPMI_GEMM_VARIANT spellings) or an int -> option value; None -> -1."""
     if v is None:
         return -1
     if isinstance(v, int):

@@ -38,7 +38,7 @@ __device__ __forceinline__ f16x4 tr_read(const char* p) {
 // the fp16 pack.  Masking code exists only in tiles that can contain a dead key (wave-uniform test); fully dead
 // causal tiles are skipped.  Row sums come out of the matrix pipe: a third "V^T" tile of all ones accumulates
 // sum_k P[k][q] in lacc alongside O, from the same fp16-rounded P that multiplies V.
-template <int NKT, int GROUP, bool TR, int DENSE = 0>
+template <int NKT, int GROUP, int DENSE = 0>
 __device__ __forceinline__ void attend_block(const char* const (&kread)[4], const char* const (&vread)[2], const f16x8 (&qf)[4],
                                              int kb0, int L, int causal, int q0, int q, int hh, float& m_run,
                                              f32x16 (&oacc)[2], f32x16& lacc) {
@@ -112,14 +112,8 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
           for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[t][8 * ss + j], C, -mc));
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            f16x4 lo, hi;
-            if constexpr (TR) {
-              lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
-              hi = tr_read(vread[dt] + kt * 4096 + ss * 2048 + 1024);
-            } else {
-              lo = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32);
-              hi = *reinterpret_cast<const f16x4*>(vread[dt] + kt * 64 + ss * 32 + 16);
-            }
+            const f16x4 lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
+            const f16x4 hi = tr_read(vread[dt] + kt * 4096 + ss * 2048 + 1024);
             const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
           }
@@ -174,10 +168,9 @@ __device__ __forceinline__ void read_v(f16x4 (&dst)[4], const uint32_t (&va)[2])
 }
 
 // ka[ks] / va[dt]: the lane's LDS byte addresses (key tile 0) of its K fragment ks and of its transposed V reads for d-tile dt.
-// SEG: 0 exponent work interleaved with the P.V MFMAs; 1 pure VALU / MFMA segments; 2 segments separated by WORKGROUP BARRIERS --
-// the ping-pong of gemm_stream_kernel: waves 4-6 run one segment behind waves 0-3 (the caller adds the offset barriers), so on a
-// SIMD one query wave is in a matrix segment while its partner is in a VALU segment.  Five barriers inside, per call.
-template <int NKT, int GROUP, int SEG = 0>
+// (Measured and removed in round 3, same bits: all exponent work of a group before its P.V MFMAs as one block, and those
+// segments separated by workgroup barriers with waves 4-6 one segment behind -- profiles/r02_attention_segments_ab.txt.)
+template <int NKT, int GROUP>
 __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const uint32_t (&va)[2], const uint32_t (&qa)[4], int L,
                                                 int hh, f32x16 (&oacc)[2], f32x16& lacc) {
   constexpr float C = 0.125f * LOG2E;
@@ -186,13 +179,6 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
   f16x8 kf[2][4];
   f16x4 vf[2][4];   // [buffer][dt * 2 + (lo | hi)]
   float m_run = NEG_BIG;
-  auto seg_barrier = [&]() {
-    if constexpr (SEG == 2) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
   f16x8 qf[4];      // this wave's 32 query rows (B operand of S^T = K Q^T), read like a K tile: qa = the lane's LDS addresses
   read_k<0>(qf, qa);
   read_k<0>(kf[0], ka);
@@ -236,7 +222,6 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     // the reads that the P.V phase (and the next group's first S tile) open with: behind the exponent work by the time they are needed
     if constexpr (MORE) read_k<G0 + G>(kf[(G0 + G) & 1], ka);
     read_v<G0 * 4096>(vf[0], va);
-    seg_barrier();   // matrix segment (S) -> VALU segment (max, exponent)
     // ---- group max of the raw scores, online rescale (nothing to rescale in the first group)
     float mloc = NEG_BIG;
 #pragma unroll
@@ -256,44 +241,6 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     const float mc = m_new * C;
     m_run = m_new;
     // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
-    if constexpr (SEG != 0) {
-      // "pure segments": ALL exponent work of the group first (VALU only), then its P.V MFMAs as one block (matrix pipe only,
-      // V fragments streaming one step ahead).  A SIMD's two query waves then tend to sit in opposite kinds of segment -- one
-      // paced by the matrix pipe, one by VALU issue -- instead of each interleaving both at instruction granularity.
-      f16x8 pfa[G][2];
-#pragma unroll
-      for (int t = 0; t < G; ++t)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            pfa[t][ss][j] = (G0 + t == NKT - 1 && 8 * ss + j >= 4) ? (half_t)0.f : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[t][8 * ss + j], C, -mc));
-      __builtin_amdgcn_sched_barrier(0);
-      seg_barrier();   // VALU segment -> matrix segment (P.V, then the next group's S)
-      auto mm_step = [&](auto step_tag) {
-        constexpr int STEP = decltype(step_tag)::value, T = STEP >> 1, SS = STEP & 1, CUR = STEP & 1;
-        constexpr bool LAST = STEP == 2 * G - 1;
-        if constexpr (!LAST) read_v<(G0 + (STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
-        if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
-        else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
-          const f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          if (G0 == 0 && STEP == 0) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pfa[T][SS], zero16, 0, 0, 0);
-          else oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pfa[T][SS], oacc[dt], 0, 0, 0);
-        }
-        if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pfa[T][SS], zero16, 0, 0, 0);
-        else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pfa[T][SS], lacc, 0, 0, 0);
-      };
-      mm_step(std::integral_constant<int, 0>{});
-      mm_step(std::integral_constant<int, 1>{});
-      if constexpr (G > 1) { mm_step(std::integral_constant<int, 2>{}); mm_step(std::integral_constant<int, 3>{}); }
-      if constexpr (G > 2) { mm_step(std::integral_constant<int, 4>{}); mm_step(std::integral_constant<int, 5>{}); }
-      if constexpr (G > 3) { mm_step(std::integral_constant<int, 6>{}); mm_step(std::integral_constant<int, 7>{}); }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!MORE) seg_barrier();   // last matrix segment -> the caller's VALU segment (normalise, store)
-    } else {
     auto pv_step = [&](auto t_tag, auto ss_tag) {
       constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
       constexpr int STEP = T * 2 + SS, CUR = STEP & 1;
@@ -326,7 +273,6 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     if constexpr (G > 1) pv_tile(std::integral_constant<int, 1>{});
     if constexpr (G > 2) pv_tile(std::integral_constant<int, 2>{});
     if constexpr (G > 3) pv_tile(std::integral_constant<int, 3>{});
-    }
   };
   group(std::integral_constant<int, 0>{});
   if constexpr (NKT > GROUP) group(std::integral_constant<int, GROUP>{});
@@ -362,103 +308,6 @@ __device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2],
   }
 }
 
-template <int NKT, int GROUP, bool TR>
-__global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                           int L, int H, int causal, int nkb) {
-  constexpr int KEYS = NKT * 32;
-  constexpr int KS_BYTES = KEYS * 128;
-  constexpr int VT_STRIDE = NKT * 64 + 8;  // bytes per d-row of the transposed image (non-TR path)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;
-  char* Vs = smem + KS_BYTES;
-
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31, hh = lane >> 5;
-  const int D = H * 64;
-  const int64_t ld = 3 * (int64_t)D;
-  const int n = blockIdx.x / H, h = blockIdx.x - n * H;
-  const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
-  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
-
-  const int q0 = (blockIdx.y * (nthr >> 6) + wave) * 32;
-  const bool active = q0 < L;  // wave-uniform
-  const int q = q0 + r32;
-  const int qc = q < L ? q : L - 1;
-
-  f16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(base + (int64_t)qc * ld + ks * 16 + hh * 8);
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-  float m_run = NEG_BIG;
-  f32x16 lacc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-
-  // lane-constant LDS read bases; everything else is an immediate offset
-  const int kswz = (r32 >> 1) & 7;
-  const char* kread_[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kread_[ks] = Ks + r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
-  const char* vread_[2];
-  if constexpr (TR) {
-    // ds_read_b64_tr_b16: per 16-lane group a block of 4 rows (keys k0..k0+3) x 16 columns (d0..d0+15); lane 4q+p
-    // of the group supplies the address of row q, columns 4p..4p+3 and receives column (lane&15) of the 4 rows.
-    // k0 = kt*32 + ss*16 + hh*4 (+8), d0 = dt*32 + ((lane>>4)&1)*16.  V swizzle: 16-B chunk ^= ((row>>1)&1)<<2,
-    // and (row>>1)&1 == (q>>1)&1 because k0 % 4 == 0.
-    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
-    const int fq = (qq >> 1) & 1;
-    const int lane_base = hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
-    vread_[0] = Vs + lane_base + fq * 64;          // dt = 0: chunk bit 2 = 0 ^ fq
-    vread_[1] = Vs + lane_base + (1 - fq) * 64;    // dt = 1: chunk bit 2 = 1 ^ fq
-  } else {
-    vread_[0] = Vs + r32 * VT_STRIDE + hh * 8;
-    vread_[1] = Vs + (32 + r32) * VT_STRIDE + hh * 8;
-  }
-  const char* const kread[4] = {kread_[0], kread_[1], kread_[2], kread_[3]};
-  const char* const vread[2] = {vread_[0], vread_[1]};
-
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int kb0 = kb * KEYS;
-    if (kb > 0) __syncthreads();  // everyone finished reading the previous block
-    // ---- stage K (and V) : slot p = row*8 + c' holds data chunk c' ^ swizzle(row)
-    const int nwaves = nthr >> 6;
-    for (int it = wave; it < KEYS / 8; it += nwaves) {  // one wave-instruction = 8 rows x 128 B; `it` is scalar
-      const int pw = it * 64;                           // wave-uniform slot base
-      const int p = pw + lane;
-      const int row = p >> 3, cs = p & 7;
-      const int key = kb0 + row;                      // rows >= L are outside the descriptor: they read as zero
-      const int koff = (key * (int)ld + D) * 2;
-      CLIPMI_BUFFER_LOAD_LDS16(rs, Ks + pw * 16, koff + ((cs ^ ((row >> 1) & 7)) << 4), 0);
-      if constexpr (TR) {
-        CLIPMI_BUFFER_LOAD_LDS16(rs, Vs + pw * 16, koff + D * 2 + ((cs ^ (((row >> 1) & 1) << 2)) << 4), 0);
-      } else {
-        const int kc = key < L ? key : L - 1;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (int64_t)kc * ld + 2 * D + cs * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<half_t*>(Vs + (cs * 8 + e) * VT_STRIDE + row * 2) = v[e];
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    if (active) {
-      if (!causal && kb0 + KEYS <= L)   // block-uniform: full block -> straight-line code
-        attend_block<NKT, GROUP, TR, 3>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
-      else
-        attend_block<NKT, GROUP, TR, 0>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
-    }
-  }
-
-  if (active && q < L) store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent variant for sequences that fit one key block (L <= NKT*32; every CLIP tower at 224 px and the text
 // tower): one workgroup per CU walks the (sequence, head) items; K/V of item i+1 are DMA'd into the second half of a
@@ -468,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const half_t* __restr
 // ---------------------------------------------------------------------------------------------------------------
 template <int NKT, int GROUP, int DENSE>
 __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                                   int L, int H, int causal, int n_items, int stagger) {
+                                                                   int L, int H, int causal, int n_items) {
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V
@@ -539,9 +388,6 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
       stage(next, buf ^ 1);
       load_q(next, qn);
     }
-    if (stagger > 0 && wave >= 4) {   // waves w and w+4 share a SIMD: run them half a phase apart (MFMA beside VALU)
-      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(4);
-    }
     if (active) {
       const char* b = smem + buf * BUF;
       const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
@@ -555,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
       f32x16 lacc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-      attend_block<NKT, GROUP, true, DENSE>(kread, vread, qf, 0, L, causal, q0, q, hh, m_run, oacc, lacc);
+      attend_block<NKT, GROUP, DENSE>(kread, vread, qf, 0, L, causal, q0, q, hh, m_run, oacc, lacc);
       if (q < L) {
         const int n = item / H, h = item - n * H;
         store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
@@ -590,14 +436,12 @@ constexpr int VARR = VROWS * 128;            // one operand image
 constexpr int VBUF = 3 * VARR;               // K | V | Q
 constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of the last array
 
-template <int NLOAD, int PRIO, int GROUP = 4, int PF = 1>
-__global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
-                                                                                               int L, int H, int n_items
+__global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items
 #ifdef CLIPMI_TUNING
-                                                                                               , long long* stamps   // diagnostic build: [item][wave 0..7 (7 = loader)][8]
+                                                                  , long long* stamps   // diagnostic build: [item][wave 0..7 (7 = loader)][8]
 #endif
-                                                                                               ) {
-  constexpr int NKT = 7, NT = 448 + 64 * NLOAD;
+                                                                  ) {
+  constexpr int NKT = 7, NT = 512, GROUP = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -612,10 +456,9 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
   if (item >= n_items) return;
 
   if (wave >= 7) {
-    // ---- loader wave(s): ALL DMA of item (i + 1) while the query waves work on item i -- 25 groups of 8 rows x 128 B per
-    // operand, loader j takes the groups g = j (mod NLOAD).  Per-lane source offsets are precomputed (a group's swizzle
-    // depends on its parity only), so a DMA costs one v_add + the M0 update + the instruction itself.
-    if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+    // ---- loader wave: ALL DMA of item (i + 1) while the query waves work on item i -- 25 groups of 8 rows x 128 B per
+    // operand.  Per-lane source offsets are precomputed (a group's swizzle depends on its parity only), so a DMA costs one
+    // v_add + the M0 update + the instruction itself.  (Two loader waves, raised loader priority: measured equal, removed.)
     const int lr = lane >> 3, cs = lane & 7;
     const int swv = (cs ^ (((lr >> 1) & 1) << 2)) << 4;                                        // V: chunk ^ (((row >> 1) & 1) << 2)
     const int swk[2] = {(cs ^ (lr >> 1)) << 4, (cs ^ (4 + (lr >> 1))) << 4};                    // K, Q: chunk ^ ((row >> 1) & 7), by group parity
@@ -626,74 +469,41 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
       return r;
     };
-    auto stage = [&](auto jtag, int it_, int buf) {   // J = which loader this is: every group index below is a constant
-      constexpr int J = decltype(jtag)::value;
+    auto stage = [&](int it_, int buf) {
       const int n = it_ / H, h = it_ - n * H;
       const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);   // rows >= L: outside, read as zero
       char* B = smem + buf * VBUF;
 #pragma unroll
-      for (int g = J; g < VROWS / 8; g += NLOAD) {
+      for (int g = 0; g < VROWS / 8; ++g) {
         const int kq = lane_row + swk[g & 1];
         CLIPMI_BUFFER_LOAD_LDS16(rs, B + g * 1024, radd(kq + D * 2, g * gstep), 0);                        // K
         CLIPMI_BUFFER_LOAD_LDS16(rs, B + VARR + g * 1024, radd(lane_row + swv + 2 * D * 2, g * gstep), 0);  // V
         CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
       }
     };
-    auto stage_chunk = [&](auto jtag, auto ctag, int it_, int buf) {   // groups g = J (mod NLOAD) with g % 7 == chunk; nothing past the last item
-      constexpr int J = decltype(jtag)::value, CH = decltype(ctag)::value;
-      if (it_ >= n_items) return;   // uniform
-      const int n = it_ / H, h = it_ - n * H;
-      const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);
-      char* B = smem + buf * VBUF;
-#pragma unroll
-      for (int g = J; g < VROWS / 8; g += NLOAD) {
-        if (g % 7 != CH) continue;
-        const int kq = lane_row + swk[g & 1];
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + g * 1024, radd(kq + D * 2, g * gstep), 0);                        // K
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + VARR + g * 1024, radd(lane_row + swv + 2 * D * 2, g * gstep), 0);  // V
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
-      }
-    };
-    auto run = [&](auto jtag) {
-      stage(jtag, item, 0);
-      int buf = 0;
-      for (; item < n_items; item += gridDim.x, buf ^= 1) {
+    stage(item, 0);
+    int buf = 0;
+    for (; item < n_items; item += gridDim.x, buf ^= 1) {
 #ifdef CLIPMI_TUNING
-        const bool stamp = stamps != nullptr && lane == 0 && wave == 7;
-        long long* sp = stamps + ((size_t)item * 8 + 7) * 8;
-        if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
+      const bool stamp = stamps != nullptr && lane == 0;
+      long long* sp = stamps + ((size_t)item * 8 + 7) * 8;
+      if (stamp) sp[0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's operands have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's operands have landed
 #ifdef CLIPMI_TUNING
-        if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-        __builtin_amdgcn_s_barrier();                       // ... and every query wave is done with the other buffer
+      __builtin_amdgcn_s_barrier();                       // ... and every query wave is done with the other buffer
 #ifdef CLIPMI_TUNING
-        if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-        const int next = item + gridDim.x;
-        if constexpr (PF == 3) {
-          // ping-pong mode: the query waves cross six more barriers per item (segment boundaries); the loader joins each of them and
-          // issues a seventh of the next item's DMA in every slot (one burst of 75 instructions would hold the first barrier back)
-          stage_chunk(jtag, std::integral_constant<int, 0>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 1>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 2>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 3>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 4>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 5>{}, next, buf ^ 1); __builtin_amdgcn_s_barrier();
-          stage_chunk(jtag, std::integral_constant<int, 6>{}, next, buf ^ 1);
-        } else {
-          if (next < n_items) stage(jtag, next, buf ^ 1);
-        }
+      const int next = item + gridDim.x;
+      if (next < n_items) stage(next, buf ^ 1);
 #ifdef CLIPMI_TUNING
-        if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-      }
-    };
-    if (NLOAD == 1 || wave == 7) run(std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, NLOAD - 1>{});
+    }
     return;
   }
 
@@ -726,30 +536,14 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
 #ifdef CLIPMI_TUNING
     if (stamp) sp[1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    const char* b = smem + buf * VBUF;
     f32x16 oacc[2];
     f32x16 lacc;
-    if constexpr (PF != 0) {   // fragment reads pinned ahead of their MFMAs (attend_dense_pf)
+    {   // fragment reads pinned ahead of their MFMAs (attend_dense_pf)
       const uint32_t lb = lds_base + (uint32_t)(buf * VBUF);
       const uint32_t ka[4] = {lb + (uint32_t)kro[0], lb + (uint32_t)kro[1], lb + (uint32_t)kro[2], lb + (uint32_t)kro[3]};
       const uint32_t va[2] = {lb + (uint32_t)vro[0], lb + (uint32_t)vro[1]};
       const uint32_t qa[4] = {lb + (uint32_t)qro[0], lb + (uint32_t)qro[1], lb + (uint32_t)qro[2], lb + (uint32_t)qro[3]};
-      if constexpr (PF == 3) { if (wave >= 4) __builtin_amdgcn_s_barrier(); }   // waves 4-6 start one segment later
-      attend_dense_pf<NKT, GROUP, PF == 3 ? 2 : (PF == 2 ? 1 : 0)>(ka, va, qa, L, hh, oacc, lacc);
-    } else {
-      f16x8 qf[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(b + qro[ks]);
-      const char* const kread[4] = {b + kro[0], b + kro[1], b + kro[2], b + kro[3]};
-      const char* const vread[2] = {b + vro[0], b + vro[1]};
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-      float m_run = NEG_BIG;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-      attend_block<NKT, GROUP, true, 1>(kread, vread, qf, 0, L, 0, q0, q, hh, m_run, oacc, lacc);
+      attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc);
     }
 #ifdef CLIPMI_TUNING
     asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[1][15]), "v"(lacc[0]));
@@ -759,38 +553,28 @@ __global__ __launch_bounds__(448 + 64 * NLOAD, NLOAD == 1 ? 2 : 3) void attentio
       const int n = item / H, h = item - n * H;
       store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
     }
-    if constexpr (PF == 3) { if (wave < 4) __builtin_amdgcn_s_barrier(); }   // ... and waves 0-3 wait out the last segment of waves 4-6
 #ifdef CLIPMI_TUNING
     if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   }
 }
 
-template <int NLOAD, int PRIO, int GROUP = 4, int PF = 1>
-int launch_vision_t(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
+// Measured on MI355X, B = 256 (tools/block_ab2.py, profiles/r02_attention_ab.txt): persistent kernel without a loader wave
+// 81-83 us, this kernel 74-78 us; two loader waves, compiler-placed fragment reads and the segmented forms were A/B arms of
+// round 2 (same bits, not faster) and are gone.
+int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = attention_vision_kernel<NLOAD, PRIO, GROUP, PF>;
+  auto fn = attention_vision_kernel;
   ensure_dynamic_lds(fn, VSMEM, attr_once);
   const int n_cu = device_cus();
   const int n_items = N * H;
   const int grid = n_items < n_cu ? n_items : n_cu;
 #ifdef CLIPMI_TUNING
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(448 + 64 * NLOAD), VSMEM, s, qkv, out, L, H, n_items, g_tuning_stamps.load(std::memory_order_relaxed));
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), VSMEM, s, qkv, out, L, H, n_items, g_tuning_stamps.load(std::memory_order_relaxed));
 #else
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(448 + 64 * NLOAD), VSMEM, s, qkv, out, L, H, n_items);   // 7 query waves + the loaders
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), VSMEM, s, qkv, out, L, H, n_items);   // 7 query waves + the loader
 #endif
   return check_launch("attention_vision_kernel");
-}
-
-// mode 1 (default): one loader wave; 2: two loader waves (A/B aid).  Measured on MI355X, B = 256 (tools/block_ab2.py): persistent
-// kernel without loaders 81-83 us, one loader 74-78 us, two loaders 78 us (74 with raised priority), one loader with all seven key
-// tiles in one softmax group 79.5 us, groups of two 80.3 us.
-int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, int mode, hipStream_t s) {
-  if (mode == 2) return launch_vision_t<2, 0, 4, 0>(qkv, out, N, L, H, s);
-  if (mode == 3) return launch_vision_t<1, 0, 4, 0>(qkv, out, N, L, H, s);
-  if (mode == 4) return launch_vision_t<1, 0, 4, 2>(qkv, out, N, L, H, s);   // pinned reads + pure VALU / MFMA segments (A/B aid)
-  if (mode == 5) return launch_vision_t<1, 0, 4, 3>(qkv, out, N, L, H, s);   // ... separated by barriers, waves 4-6 one segment behind (ping-pong)   // compiler-placed fragment reads (A/B aid)
-  return launch_vision_t<1, 0>(qkv, out, N, L, H, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -871,9 +655,9 @@ __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const half_t* 
       const char* const vread[2] = {b + vro[0], b + vro[1]};
       const int kb0 = kb * KEYS;
       if (!causal && kb0 + KEYS <= L)   // block-uniform: full block -> straight-line code
-        attend_block<NKT, NKT, true, 3>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+        attend_block<NKT, NKT, 3>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
       else
-        attend_block<NKT, NKT, true, 0>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
+        attend_block<NKT, NKT, 0>(kread, vread, qf, kb0, L, causal, q0, q, hh, m_run, oacc, lacc);
     }
   }
   if (active && q < L) store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
@@ -905,29 +689,11 @@ int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int caus
   const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
   const int n_items = N * H;
   const int grid = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items, options().attn_stagger.load(std::memory_order_relaxed));
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, n_items);
   return check_launch("attention_persist_kernel");
 }
 
-template <int NKT, int GROUP, bool TR>
-int launch_t(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
-  constexpr int KEYS = NKT * 32;
-  constexpr int SMEM = KEYS * 128 + (TR ? KEYS * 128 : 64 * (NKT * 64 + 8));
-  static DeviceOnce attr_once;
-  auto fn = attention_kernel<NKT, GROUP, TR>;
-  ensure_dynamic_lds(fn, SMEM, attr_once);
-  const int nqt = (L + 31) / 32;
-  const int nw = nqt < 4 ? 4 : (nqt > 8 ? 8 : nqt);
-  const int qsplit = (nqt + nw - 1) / nw;
-  const int nkb = (L + KEYS - 1) / KEYS;
-  hipLaunchKernelGGL(fn, dim3(N * H, qsplit), dim3(nw * 64), SMEM, s, qkv, out, L, H, causal, nkb);
-  return check_launch("attention_kernel");
-}
-
 }  // namespace
-
-// CLIPMI_ATTN_NO_TR=1 selects the register-transposed V image instead of ds_read_b64_tr_b16 (A/B + bring-up aid).
-static bool use_tr() { return options().attn_no_tr.load(std::memory_order_relaxed) != 1; }
 
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   if (N == 0) return CLIPMI_OK;
@@ -935,28 +701,21 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   CLIPMI_REQUIRE(N > 0 && L > 0 && H > 0, CLIPMI_ERR_SHAPE, "attention: bad shape N=%d L=%d H=%d", N, L, H);
   CLIPMI_REQUIRE((int64_t)N * H < (1ll << 31), CLIPMI_ERR_SHAPE, "attention: grid too large");
   CLIPMI_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, CLIPMI_ERR_ARG, "attention: unaligned pointer");
-  const bool tr = use_tr();
-  if (tr && options().attn_no_persist.load(std::memory_order_relaxed) != 1) {
-    if (L <= 96) {
-      if (causal && L > 64) return launch_persist<3, 3, 2>(qkv, out, N, L, H, causal, s);
-      return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);
-    }
-    if (L <= 224) {
-      if (!causal && L > 192) {
-        // 193..200 tokens: every operand by DMA from a loader wave (attention_vision_kernel); wider rows do not fit the LDS
-        const int lm = options().attn_loader.load(std::memory_order_relaxed);   // 1: one loader wave (default), 2: two
-        if (L <= VROWS && lm >= 1) return launch_vision(qkv, out, N, L, H, lm, s);
-        return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
-      }
-      return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
-    }
-    // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks 73 us against 81 us for the single-buffer kernel;
-    // 577 tokens (ViT-L/14@336) with 224-key blocks 205 us against 210 us (that shape is bound by softmax / MFMA issue)
-    if (options().attn_no_stream.load(std::memory_order_relaxed) != 1)   // A/B aid
-      return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
+  if (L <= 96) {
+    if (causal && L > 64) return launch_persist<3, 3, 2>(qkv, out, N, L, H, causal, s);
+    return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);
   }
-  if (L <= 96) return tr ? launch_t<3, 3, true>(qkv, out, N, L, H, causal, s) : launch_t<3, 3, false>(qkv, out, N, L, H, causal, s);
-  return tr ? launch_t<7, 4, true>(qkv, out, N, L, H, causal, s) : launch_t<7, 4, false>(qkv, out, N, L, H, causal, s);
+  if (L <= 224) {
+    if (!causal && L > 192) {
+      // 193..200 tokens: every operand by DMA from a loader wave (attention_vision_kernel); wider rows do not fit the LDS.
+      // Option attn_loader = 0 keeps the persistent kernel (same bits: the bit-identity reference of the tests).
+      if (L <= VROWS && options().attn_loader.load(std::memory_order_relaxed) != 0) return launch_vision(qkv, out, N, L, H, s);
+      return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
+    }
+    return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
+  }
+  // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks, 577 tokens (ViT-L/14@336) with 224-key blocks
+  return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
 }
 
 }  // namespace clipmi

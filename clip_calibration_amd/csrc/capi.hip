@@ -37,27 +37,20 @@ struct OptionDesc { const char* name; const char* env; std::atomic<int> Options:
 const OptionDesc kOptions[] = {
     {"gemm_variant", "CLIPMI_GEMM_VARIANT", &Options::gemm_variant},
     {"gemm_band", "CLIPMI_GEMM_BAND", &Options::gemm_band},
-    {"gemm_persist", "CLIPMI_GEMM_PERSIST", &Options::gemm_persist},
     {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
-    {"gemm_pp", "CLIPMI_GEMM_PP", &Options::gemm_pp},
-    {"gemm_mix", "CLIPMI_GEMM_MIX", &Options::gemm_mix},
-    {"ln_inline", "CLIPMI_LN_INLINE", &Options::ln_inline},
+    {"gemm_rstream", "CLIPMI_GEMM_RSTREAM", &Options::gemm_rstream},
     {"cls_only_last_block", "CLIPMI_CLS_ONLY_LAST_BLOCK", &Options::cls_only_last_block},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
-    {"attn_no_tr", "CLIPMI_ATTN_NO_TR", &Options::attn_no_tr},
-    {"attn_no_persist", "CLIPMI_ATTN_NO_PERSIST", &Options::attn_no_persist},
-    {"attn_no_stream", "CLIPMI_ATTN_NO_STREAM", &Options::attn_no_stream},
-    {"attn_stagger", "CLIPMI_ATTN_STAGGER", &Options::attn_stagger},
     {"attn_loader", "CLIPMI_ATTN_LOADER", &Options::attn_loader},
     {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
 };
 
 // environment spelling -> option value: decimal integers, plus the historical letters of two switches
-// (CLIPMI_GEMM_VARIANT a/b/c/f = 10/11/12/15, CLIPMI_RESIDUAL_F16 v/t = 2/3)
+// (CLIPMI_GEMM_VARIANT a/s/r = 10/13/16, CLIPMI_RESIDUAL_F16 v/t = 2/3)
 int parse_option(const char* name, const char* text) {
   if (!strcmp(name, "gemm_variant")) {
-    switch (text[0]) { case 'a': return 10; case 'b': return 11; case 'c': return 12; case 's': return 13; case 'f': return 15; default: break; }
+    switch (text[0]) { case 'a': return 10; case 's': return 13; case 'r': return 16; default: break; }
   }
   if (!strcmp(name, "residual_f16")) {
     switch (text[0]) { case 'v': return 2; case 't': return 3; default: break; }
@@ -119,6 +112,11 @@ using namespace clipmi;
 struct clipmi_model {
   clipmi_geometry g;
   bool has_vision = false, has_text = false;
+  // per-handle settings (clipmi_model_set_option): -1 = follow the process-wide default of the same name
+  std::atomic<int> opt_residual_f16{-1}, opt_ln_fold{-1}, opt_cls_only{-1};
+  int residual_mode() const { const int v = opt_residual_f16.load(std::memory_order_relaxed); return v >= 0 ? v : options().residual_f16.load(std::memory_order_relaxed); }
+  int ln_fold() const { const int v = opt_ln_fold.load(std::memory_order_relaxed); return v >= 0 ? v : options().ln_fold.load(std::memory_order_relaxed); }
+  int cls_only() const { const int v = opt_cls_only.load(std::memory_order_relaxed); return v >= 0 ? v : options().cls_only_last_block.load(std::memory_order_relaxed); }
   clipmi_vision_weights vw;
   clipmi_text_weights tw;
   std::vector<clipmi_block_weights> vblocks, tblocks;
@@ -247,13 +245,12 @@ int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L,
   return CLIPMI_OK;
 }
 
-// ln_1 / ln_2 are applied inside the GEMM epilogues whenever the folded operands are bound (CLIPMI_LN_FOLD=0 switches
-// back to the separate LayerNorm kernels).  Per residual block at B = 256 (profiles/r01_ln_fold.txt): the two LayerNorm
-// launches (2 x 39 us) disappear; the consumers pay +5-6 us each (row parameters are formed once per tile in the kernel
-// prologue) and the residual producers +13 us each (the fp16 shadow of the stream is another 77 MB in their store
-// burst): net -41 us per block, +3 % end to end.
-bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
-  if (options().ln_fold.load(std::memory_order_relaxed) == 0) return false;
+// ln_1 / ln_2 are applied inside the GEMM epilogues whenever the folded operands are bound (option ln_fold = 0, process-wide or
+// per handle, switches back to the separate LayerNorm kernels).  Per residual block at B = 256 (profiles/r01_ln_fold.txt): the two
+// LayerNorm launches (2 x 39 us) disappear; the consumers pay +5-6 us each and the residual producers +13 us each (the fp16
+// shadow of the stream is another 77 MB in their store burst): net -41 us per block, +3 % end to end.
+bool fold_enabled(const clipmi_model* m, const std::vector<clipmi_block_weights>& blocks) {
+  if (m->ln_fold() == 0) return false;
   for (const auto& b : blocks)
     if (!b.w_qkv_f) return false;
   return !blocks.empty();
@@ -265,10 +262,27 @@ bool fold_enabled(const std::vector<clipmi_block_weights>& blocks) {
 //                GEMMs of a block move 154 MB each instead of 387 MB (+10 % end to end at B = 256); against the fp32
 //                stream the image-side cosine error goes 3.1e-5 -> 8.7e-5 (tests/precision_modes.py), tolerance 1e-3;
 //   text tower:  fp32 with an fp16 shadow -- its features are computed once per class list and reused for every image.
-// option residual_f16 (env CLIPMI_RESIDUAL_F16) = 0 (fp32 everywhere) | 2 / v (default) | 3 / t | 1 (both towers fp16).
-bool residual_f16_enabled(bool folded, bool vision) {
+// Resolution order: the call's flags (CLIPMI_CALL_STREAM_F32 / _F16), then the handle's residual_f16 setting, then the
+// process-wide option (env CLIPMI_RESIDUAL_F16) = 0 (fp32 everywhere) | 2 / v (default) | 3 / t | 1 (both towers fp16).
+// *rc_out: CLIPMI_ERR_STATE when the call demands the fp16 stream but the fold is off (no fp16 operand copy to carry it).
+bool residual_f16_enabled(const clipmi_model* m, bool folded, bool vision, unsigned flags, int* rc_out) {
+  *rc_out = CLIPMI_OK;
+  const unsigned prec = flags & (CLIPMI_CALL_STREAM_F32 | CLIPMI_CALL_STREAM_F16);
+  if (prec == (CLIPMI_CALL_STREAM_F32 | CLIPMI_CALL_STREAM_F16) || (flags & ~(CLIPMI_CALL_STREAM_F32 | CLIPMI_CALL_STREAM_F16))) {
+    set_error("tower call: bad flags 0x%x", flags);
+    *rc_out = CLIPMI_ERR_ARG;
+    return false;
+  }
+  if (prec == CLIPMI_CALL_STREAM_F32) return false;
+  if (prec == CLIPMI_CALL_STREAM_F16) {
+    if (!folded) {
+      set_error("tower call: CLIPMI_CALL_STREAM_F16 needs the LayerNorm-folded operands and ln_fold != 0");
+      *rc_out = CLIPMI_ERR_STATE;
+    }
+    return folded;
+  }
   if (!folded) return false;
-  const int mode = options().residual_f16.load(std::memory_order_relaxed);
+  const int mode = m->residual_mode();
   return mode == 1 || (vision ? mode == 2 : mode == 3);
 }
 
@@ -282,10 +296,8 @@ int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
 }
 
 // text blocks on w.xres (already holds embeddings + pos)
-int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, hipStream_t s) {
+int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, bool folded, bool f16res, hipStream_t s) {
   const int L = m->g.context_length, D = m->g.text_width;
-  const bool folded = fold_enabled(m->tblocks);
-  const bool f16res = residual_f16_enabled(folded, false);
   int rc, parts = 1;
   if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, 1, C, L, D, 0, L, s))) return rc;   // input rows of block 0
   for (int i = 0; i < m->g.text_layers; ++i) {
@@ -299,10 +311,9 @@ int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_promp
 }
 
 // ln_final on the EOT rows + text_projection (clip/model.py:607-611)
-int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, hipStream_t s) {
+int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, bool f16res, hipStream_t s) {
   const int D = m->g.text_width, E = m->g.embed_dim;
   int rc;
-  const bool f16res = residual_f16_enabled(fold_enabled(m->tblocks), false);
   half_t* rows = f16res ? w.att : w.xn;   // fp16 stream mode: w.xn IS the stream, the gathered rows go to the idle attention buffer
   if (f16res) rc = launch_layernorm(w.xn, CLIPMI_F16, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, rows, CLIPMI_F16, D, C, D, 1e-5f, s);
   else rc = launch_layernorm(w.xres, CLIPMI_F32, D, w.idx + C, m->tw.ln_final_g, m->tw.ln_final_b, rows, CLIPMI_F16, D, C, D, 1e-5f, s);
@@ -313,9 +324,16 @@ int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, hipStrea
   return launch_gemm(a, s);
 }
 
-int text_prologue(clipmi_model* m, int n_prompts, const clipmi_prompt_hook* hook, void* ws, size_t ws_bytes, TowerWs* w) {
+int text_prologue(clipmi_model* m, int n_prompts, const clipmi_prompt_hook* hook, void* ws, size_t ws_bytes, unsigned flags, TowerWs* w,
+                  bool* folded, bool* f16res) {
   CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "null model");
   CLIPMI_REQUIRE(m->has_text, CLIPMI_ERR_STATE, "text weights not bound (clipmi_set_text_weights)");
+  {
+    int prc;
+    *folded = fold_enabled(m, m->tblocks);
+    *f16res = residual_f16_enabled(m, *folded, false, flags, &prc);
+    if (prc) return prc;
+  }
   CLIPMI_REQUIRE(n_prompts >= 0, CLIPMI_ERR_SHAPE, "n_prompts=%d", n_prompts);
   CLIPMI_REQUIRE((int64_t)n_prompts * m->g.context_length < (1ll << 31), CLIPMI_ERR_SHAPE, "too many prompt tokens");
   int rc = check_hook(hook, m->g.text_layers, false);
@@ -490,6 +508,21 @@ int clipmi_ece_accumulate(const float* conf, const int32_t* pred, const int64_t*
   return launch_ece_accumulate(conf, pred, labels, n, bins, n_bins, (hipStream_t)stream);
 }
 
+// The fp16-stream residual GEMM of a block as an operator (out-proj / c_proj of the image tower, clip/model.py:186-187):
+// x16[m,n] = fp16(x16[m,n] + A[m,:] . W[n,:] + bias[n]) in place, plus the per-row (sum, sum of squares) partials of the ROUNDED
+// values, one pair per 256-column tile: stats[(t * M + m) * 2 ..].  *parts (host) receives the number of column tiles.
+int clipmi_gemm_residual_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* x16, int64_t ldx,
+                             float* stats, int* parts, int M, int N, int K, clipmi_stream_t stream) {
+  CLIPMI_REQUIRE(parts, CLIPMI_ERR_ARG, "gemm_residual_f16: null parts pointer");
+  *parts = 0;
+  if (M == 0) return CLIPMI_OK;
+  GemmArgs a{};
+  a.A = (const half_t*)A; a.lda = lda; a.W = (const half_t*)W; a.ldw = ldw; a.bias = bias; a.ldo = ldx; a.out_dtype = CLIPMI_F32;
+  a.M = M; a.N = N; a.K = K; a.epilogue = CLIPMI_EPI_BIAS_RESIDUAL;
+  a.x16 = (half_t*)x16; a.stats_out = stats; a.parts_out = parts; a.residual_f16 = true;
+  return launch_gemm(a, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- model level
 int clipmi_create(const clipmi_geometry* geom, clipmi_model** out) {
   CLIPMI_REQUIRE(geom && out, CLIPMI_ERR_ARG, "create: null pointer");
@@ -510,6 +543,28 @@ int clipmi_create(const clipmi_geometry* geom, clipmi_model** out) {
 
 int clipmi_destroy(clipmi_model* m) {
   delete m;
+  return CLIPMI_OK;
+}
+
+int clipmi_model_set_option(clipmi_model* m, const char* name, int value) {
+  CLIPMI_REQUIRE(m && name, CLIPMI_ERR_ARG, "model_set_option: null pointer");
+  std::atomic<int>* f = !strcmp(name, "residual_f16") ? &m->opt_residual_f16 : !strcmp(name, "ln_fold") ? &m->opt_ln_fold
+                        : !strcmp(name, "cls_only_last_block") ? &m->opt_cls_only : nullptr;
+  CLIPMI_REQUIRE(f, CLIPMI_ERR_ARG, "model_set_option: unknown option '%s' (residual_f16, ln_fold, cls_only_last_block)", name);
+  CLIPMI_REQUIRE(value >= -1 && value <= (f == &m->opt_residual_f16 ? 3 : 1), CLIPMI_ERR_ARG, "model_set_option: %s = %d out of range", name, value);
+  f->store(value, std::memory_order_relaxed);
+  return CLIPMI_OK;
+}
+
+int clipmi_model_get_option(const clipmi_model* m, const char* name, int* value) {
+  CLIPMI_REQUIRE(m && name && value, CLIPMI_ERR_ARG, "model_get_option: null pointer");
+  if (!strcmp(name, "residual_f16")) *value = m->residual_mode();
+  else if (!strcmp(name, "ln_fold")) *value = m->ln_fold();
+  else if (!strcmp(name, "cls_only_last_block")) *value = m->cls_only();
+  else {
+    set_error("model_get_option: unknown option '%s'", name);
+    return CLIPMI_ERR_ARG;
+  }
   return CLIPMI_OK;
 }
 
@@ -554,7 +609,7 @@ size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
 }
 
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
-                        void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+                        void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
   CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "encode_image: null model");
   CLIPMI_REQUIRE(m->has_vision, CLIPMI_ERR_STATE, "vision weights not bound (clipmi_set_vision_weights)");
   CLIPMI_REQUIRE(batch >= 0, CLIPMI_ERR_SHAPE, "encode_image: batch=%d", batch);
@@ -582,8 +637,9 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
   if ((rc = launch_cls_and_ctx_rows(x0, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, batch, L0,
                                     n_ctx, D, s)))
     return rc;
-  const bool folded = fold_enabled(m->vblocks);
-  const bool f16res = residual_f16_enabled(folded, true);
+  const bool folded = fold_enabled(m, m->vblocks);
+  const bool f16res = residual_f16_enabled(m, folded, true, flags, &rc);
+  if (rc) return rc;
   int parts = 1;
   // fp16 residual stream: nothing reads the fp32 copy of ln_pre's output (the blocks work on w.xn) -- 155 MB less to write at batch 256
   if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, f16res ? nullptr : w.xres, CLIPMI_F32, D, batch * L, D,
@@ -594,7 +650,7 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
       if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
     }
-    const bool cls_only = i == g.vision_layers - 1 && options().cls_only_last_block.load(std::memory_order_relaxed) == 1;
+    const bool cls_only = i == g.vision_layers - 1 && m->cls_only() == 1;
     if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res, cls_only))) return rc;
   }
   // ln_post on the class token only, then @ proj (clip/model.py:419-422)
@@ -609,24 +665,27 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
 }
 
 int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, const clipmi_prompt_hook* hook,
-                       void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+                       void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
   TowerWs w;
-  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, &w);
+  bool folded, f16res;
+  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x && y, CLIPMI_ERR_ARG, "text_blocks: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int L = m->g.context_length, D = m->g.text_width;
   if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, D, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, hook, s))) return rc;
-  if (residual_f16_enabled(fold_enabled(m->tblocks), false)) return launch_cast_f16(w.xn, y, dtype, (int64_t)n_prompts * L * D, s);
+  if ((rc = run_text_blocks(m, w, n_prompts, hook, folded, f16res, s))) return rc;
+  if (f16res) return launch_cast_f16(w.xn, y, dtype, (int64_t)n_prompts * L * D, s);
   return launch_cast_f32(w.xres, y, dtype, (int64_t)n_prompts * L * D, s);
 }
 
 int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
-                        const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes, clipmi_stream_t stream) {
+                        const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes, unsigned flags,
+                        clipmi_stream_t stream) {
   TowerWs w;
-  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, &w);
+  bool folded, f16res;
+  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(prompts && eot && out, CLIPMI_ERR_ARG, "text_encoder: null pointer");
@@ -634,14 +693,15 @@ int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const i
   const int L = m->g.context_length, D = m->g.text_width;
   if ((rc = launch_add_pos(prompts, dtype, m->tw.positional_embedding, w.xres, n_prompts, L, D, s))) return rc;
   if ((rc = launch_eot_rows(eot, w.idx + n_prompts, n_prompts, L, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, hook, s))) return rc;
-  return run_text_tail(m, w, n_prompts, out, s);
+  if ((rc = run_text_blocks(m, w, n_prompts, hook, folded, f16res, s))) return rc;
+  return run_text_tail(m, w, n_prompts, out, f16res, s);
 }
 
 int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace, size_t workspace_bytes,
-                       clipmi_stream_t stream) {
+                       unsigned flags, clipmi_stream_t stream) {
   TowerWs w;
-  int rc = text_prologue(m, n_prompts, nullptr, workspace, workspace_bytes, &w);
+  bool folded, f16res;
+  int rc = text_prologue(m, n_prompts, nullptr, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(ids && out, CLIPMI_ERR_ARG, "encode_text: null pointer");
@@ -651,8 +711,8 @@ int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float
                                 m->g.vocab_size, s)))
     return rc;
   if ((rc = launch_eot_rows(w.idx, w.idx + n_prompts, n_prompts, L, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, nullptr, s))) return rc;
-  return run_text_tail(m, w, n_prompts, out, s);
+  if ((rc = run_text_blocks(m, w, n_prompts, nullptr, folded, f16res, s))) return rc;
+  return run_text_tail(m, w, n_prompts, out, f16res, s);
 }
 
 int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* workspace, size_t workspace_bytes, float* ms_out,
@@ -665,8 +725,9 @@ int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* 
   const TowerWs w = carve(workspace, (int64_t)batch * L, D, batch, m->col_bytes(batch));
   CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "profile: workspace too small");
   const clipmi_block_weights& b = m->vblocks[0];
-  const bool folded = fold_enabled(m->vblocks);
-  const bool f16res = residual_f16_enabled(folded, true);
+  const bool folded = fold_enabled(m, m->vblocks);
+  int prc;
+  const bool f16res = residual_f16_enabled(m, folded, true, 0u, &prc);
   // the row partials a residual GEMM of this shape leaves behind (what the consumers read in the tower)
   int parts = (D + 255) / 256 > LN_MAX_PARTS ? LN_MAX_PARTS : (D + 255) / 256;
   hipEvent_t e0, e1;

@@ -43,28 +43,22 @@ int check_launch(const char* what);  // hipGetLastError -> CLIPMI_ERR_HIP
 // read ONCE, the first time any option is looked at; nothing on a launch path calls getenv.  Plain atomics: a switch
 // may be flipped between launches from any thread.
 struct Options {
-  std::atomic<int> gemm_variant{-1};   // CLIPMI_GEMM_VARIANT: -1 = cost model, else the forced tile configuration (test / tuning aid)
+  std::atomic<int> gemm_variant{-1};   // CLIPMI_GEMM_VARIANT: -1 = default dispatch; 0 / 1 / 10 / 13 / 16 force one kernel family where the shape allows it (test aid)
   std::atomic<int> gemm_band{0};       // CLIPMI_GEMM_BAND: 0 = default traversal band
-  std::atomic<int> gemm_persist{0};    // CLIPMI_GEMM_PERSIST: 1 = persistent 16-wave tile (parameters computed per tile), 2 / 3 = persistent
-                                       // 16- / 8-wave tile with DMA'd parameters (ln_finalize_kernel); measured equal to the default (power cap)
   std::atomic<int> gemm_stream{1};     // CLIPMI_GEMM_STREAM: 1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs
-                                       // with K >= 512 (in-proj / c_fc: -5..-9 % per launch, -4 % per image-tower step, four boxes); 0 = one tile per workgroup
-  std::atomic<int> gemm_pp{1};         // CLIPMI_GEMM_PP: 1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
-  std::atomic<int> ln_inline{1};       // CLIPMI_LN_INLINE: 1 (default) = gemm_stream_kernel finalises the LayerNorm row partials in its epilogue (no ln_finalize_kernel
-                                       // launch in front of the folded in-proj / c_fc GEMMs); 0 = one ln_finalize_kernel launch per folded GEMM
-  std::atomic<int> gemm_mix{0};        // CLIPMI_GEMM_MIX: 1 = mixed tile heights (288 / 320 rows) in gemm_pp_kernel's fp16-stream residual GEMMs when the uniform
-                                       // grid leaves its last round part empty (same bits; measured -0.5 % per launch only: the chip is power-bound, not
-                                       // CU-bound); 0 (default) = uniform 320-row tiles
+                                       // with K >= 512 (in-proj / c_fc); 0 = one tile per workgroup (the bit-identity reference of the race screen)
+  std::atomic<int> gemm_rstream{1};    // CLIPMI_GEMM_RSTREAM: 1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
+                                       // residual GEMMs (out-proj / c_proj); 0 = one 320 x 256 tile per workgroup (same bits)
   std::atomic<int> cls_only_last_block{0};   // CLIPMI_CLS_ONLY_LAST_BLOCK: 1 = the image tower's last block runs out-proj / MLP on the class rows only
                                              // (identical features; not the default: the headline benchmark computes every row)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
-  std::atomic<int> attn_no_tr{0}, attn_no_persist{0}, attn_no_stream{0}, attn_stagger{0};
   std::atomic<int> attn_loader{1};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 1 (default) = attention_vision_kernel (all operands by LDS-DMA
-                                       // from a loader wave, fragment reads pinned by inline asm); 0 = persistent kernel; A/B aids with the same bits:
-                                       // 2 two loader waves, 3 compiler-placed reads, 4 pure VALU / MFMA segments, 5 segments + barriers (ping-pong)
+                                       // from a loader wave, fragment reads pinned by inline asm); 0 = persistent kernel (same bits)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
 };
+// cls_only_last_block, ln_fold and residual_f16 are DEFAULTS: a model handle may override them (clipmi_model_set_option) and a
+// tower call may override the stream precision (flags) -- nothing on a launch path writes to this struct.
 Options& options();
 
 #ifdef CLIPMI_TUNING

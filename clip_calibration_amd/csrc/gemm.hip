@@ -35,7 +35,6 @@ struct KArgs {
   const float* pos; int patches; int tokens;
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
-  int mix;       // gemm_pp_kernel, mixed tile heights: 0 = every tile BM rows; n > 0 = n - 1 tall (BM) m-tiles per XCD, the rest BM - 32
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   half_t* x16; float* stats_out;
 #ifdef CLIPMI_TUNING
@@ -115,54 +114,28 @@ __device__ __forceinline__ void tile_coords(const KArgs& a, int tiles_m, int& ti
   tile_n = b * a.band + (within - tile_m * gw);
 }
 
-// Mixed tile heights (gemm_pp_kernel, a.mix > 0; band == tiles_n, so logical ids walk m slow / n fast).  A launch of BM-row tiles
-// whose last round is part empty -- 474 tiles of 320 x 256 on 256 CUs for the image tower's residual GEMMs: every CU that runs two
-// tiles works through 640 rows while 38 CUs idle for a round -- is cut into MORE tiles of two heights instead: m-tiles of BM - 32 rows,
-// plus just enough of BM rows to cover M, chosen so that the whole grid still fits the same number of rounds.  The tall tiles are
-// the first a.mix - 1 m-tiles of every XCD's range of logical ids, i.e. they are all dispatched in the first round (blockIdx
-// order, 32 CUs per XCD), so no CU gets two of them: the critical path is BM + (rounds - 1)(BM - 32) rows instead of rounds * BM.
-// Every output element is still one workgroup's K-ordered sum: results are bit-identical to the uniform grid.
-__device__ __forceinline__ void mixed_tile_rows(const KArgs& a, int bm, int tile_m, int& m0, bool& tall) {
-  const int q = a.nwg >> 3, r = a.nwg & 7, n_tall = a.mix - 1;
-  int before = 0;
-  tall = false;
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;   // first logical id of XCD x (tile_coords)
-    const int d = tile_m - (start + a.tiles_n - 1) / a.tiles_n;          // m-tiles past the first whole m-tile of that range
-    before += d <= 0 ? 0 : (d < n_tall ? d : n_tall);
-    tall = tall || (d >= 0 && d < n_tall);
-  }
-  m0 = (bm - 32) * tile_m + 32 * before;
-}
-
 // fp16 outputs: each wave transposes its tile through a private LDS patch (32 rows x 64 cols at a time) so that the
 // global stores are 16 B per lane and 128 contiguous bytes per row, instead of 8-byte pieces of 32-byte row segments.
 // The caller must have passed a workgroup barrier after the last main-loop LDS read.
-// COLP_LDS: bias and the fold's g vector are read from an LDS copy of the tile's columns (colp: [BN] bias | [BN] g) at
-// each use instead of being held in 8 * TN registers across the whole epilogue (persistent 16-wave kernel: 128-VGPR cap).
-template <typename T, int EPI, int CH, bool COLP_LDS = false>
+template <typename T, int EPI, int CH>
 __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
-                                                    int wave_n, int lane, char* patch, const float2* lnp = nullptr,
-                                                    const float* colp = nullptr) {
+                                                    int wave_n, int lane, char* patch, const float2* lnp = nullptr) {
   constexpr int TM = T::TM, TN = T::TN;
   static_assert(T::WTN % 64 == 0 && TM % CH == 0 && (CH == 1 || CH == 2), "staged epilogue works on 64-column slices of the wave tile");
   constexpr int NH = T::WTN / 64;        // 64-column slices per wave tile (1 for the 64-wide wave tiles, 2 for 128)
   constexpr int ROWB = 64 * 2 + 16;      // 144 B: 16-B aligned rows, 2-way (cheap) bank conflicts on the 8-B writes
   const int r16 = lane & 15, g4 = lane >> 4;
-  f32x4 bias[COLP_LDS ? 1 : TN], lng[COLP_LDS ? 1 : TN];
+  f32x4 bias[TN], lng[TN];
   const bool fold = a.ln_stats != nullptr;   // wave-uniform
-  if constexpr (!COLP_LDS) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (EPI != CLIPMI_EPI_NONE) {
-        const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
-        if (n < a.N) {
-          bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
-          if (fold) lng[i] = *reinterpret_cast<const f32x4*>(a.ln_g + n);
-        }
+  for (int i = 0; i < TN; ++i) {
+    bias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI != CLIPMI_EPI_NONE) {
+      const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
+      if (n < a.N) {
+        bias[i] = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (fold) lng[i] = *reinterpret_cast<const f32x4*>(a.ln_g + n);
       }
     }
   }
@@ -189,15 +162,7 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = h * 4 + ii;
-          f32x4 v;
-          if constexpr (COLP_LDS) {
-            const int nl = wave_n * T::WTN + i * 16 + g4 * 4;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + T::BN + nl);
-            v = acc[i][jc * CH + jj] * rs + (bb - mrs * gg);
-          } else {
-            v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
-          }
+          f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
@@ -228,6 +193,14 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
       }
     }
   }
+}
+
+// Row partials of the LayerNorm fold, one lane's four consecutive values of a row: explicit fused multiply-adds, so that every
+// kernel that produces them (the three fold epilogues below and gemm_rstream_kernel) rounds alike whatever the surrounding code
+// lets the compiler contract -- the persistent kernel is tested bit for bit against the one-tile-per-workgroup kernels.
+__device__ __forceinline__ void fold_row_sums(const f32x4& v, float& rsum, float& rsq) {
+  rsum += (v[0] + v[1]) + (v[2] + v[3]);
+  rsq += __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
 }
 
 // Producer side of the LayerNorm fold: BIAS_RESIDUAL epilogue that, besides the fp32 read-modify-write of the residual
@@ -278,8 +251,7 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
             v = acc[i][jc * 2 + jj] + bias[i] + *reinterpret_cast<const f32x4*>(a.residual + (int64_t)m * a.ldo + n);
             *reinterpret_cast<f32x4*>(out + (int64_t)m * a.ldo + n) = v;
           }
-          rsum += (v[0] + v[1]) + (v[2] + v[3]);
-          rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          fold_row_sums(v, rsum, rsq);
         }
         *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
             f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -350,16 +322,14 @@ __device__ __forceinline__ void wait_chunk(int c) {   // c is a constant after u
 
 template <typename T>
 __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int tile_n,
-                                                             int wave_m, int wave_n, int lane, int wave, char* smem, int nb = T::TM) {
-  // nb: live 16-row blocks per wave (T::TM, or T::TM - 1 in the short tiles of a mixed-height grid: the wave's rows then start
-  // at wave_m * nb * 16, its last block holds nothing, and the rows behind it belong to the next wave or tile -- never touched)
+                                                             int wave_m, int wave_n, int lane, int wave, char* smem) {
   using F = FoldDma<T>;
   constexpr int TM = T::TM, TN = T::TN, NCH = F::NCH, RD = F::RD, CHB = F::CHB;
   static_assert(T::WTN == 64 && TM % 2 == 0 && TN == 4, "fold epilogue assumes 64-column wave tiles");
   const int r16 = lane & 15, g4 = lane >> 4;
   char* region = smem + wave * (RD * CHB);
   float2* red = reinterpret_cast<float2*>(smem + F::RED_OFF);   // [WGN][BM]
-  const int wrow = wave_m * nb * 16;
+  const int wrow = wave_m * T::WTM;
   const int col0 = n0 + wave_n * 64, row0 = m0 + wrow;   // wave-uniform
   f32x4 bias[TN];
 #pragma unroll
@@ -398,7 +368,6 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
     for (int jj = 0; jj < 2; ++jj) {
       const int ml = wrow + (c * 2 + jj) * 16 + r16;
       const int m = m0 + ml;
-      const bool live = c * 2 + jj < nb;   // wave-uniform
       float rsum = 0.f, rsq = 0.f;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -406,18 +375,17 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
         char* p = reg + eoff[jj] + (((2 * i + (g4 >> 1)) ^ esw) << 4);
         const f16x4 r = *reinterpret_cast<const f16x4*>(p);
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < a.M && n < a.N && live) {
+        if (m < a.M && n < a.N) {
           v = acc[i][c * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
-          rsum += (v[0] + v[1]) + (v[2] + v[3]);
-          rsq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          fold_row_sums(v, rsum, rsq);
         }
         *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       }
       rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
       rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
-      if (g4 == 0 && live) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
+      if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
     }
     // same wave, LDS in order: the reads below see the writes above
 #pragma unroll
@@ -426,13 +394,13 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
       const f16x8 val = *reinterpret_cast<const f16x8*>(reg + rl * 128 + dslot * 16);
       const int m = row0 + c * 32 + rl;
       const int n_st = col0 + ((dslot ^ ((rl >> 1) & 7)) << 3);
-      if (m < a.M && n_st < a.N && c * 2 + (t >> 1) < nb) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (c + RD < NCH) dma_chunk(c + RD);   // its region was read (lgkmcnt drained for the stores above) a moment ago
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < T::WGM * nb * 16; t += T::NT) {
+  for (int t = threadIdx.x; t < T::BM; t += T::NT) {
     const int m = m0 + t;
     if (m < a.M) {
       float sx = 0.f, sq = 0.f;
@@ -453,9 +421,9 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 
 template <typename T, int EPI, bool OUT_F32, bool DMA_RES = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
-                                         int lane, int wave, char* smem, const float2* lnp = nullptr, int nb = T::TM) {
+                                         int lane, int wave, char* smem, const float2* lnp = nullptr) {
   if constexpr (EPI == EPI_RESIDUAL_FOLD16 && DMA_RES) {
-    epilogue_residual_fold16_dma<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem, nb);
+    epilogue_residual_fold16_dma<T>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
     return;
   }
   if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) {
@@ -732,112 +700,6 @@ int launch_tile(KArgs k, hipStream_t s) {
   return check_launch("gemm_f16_kernel");
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Ring variant: BK = 32 stages in a 4-slot LDS ring, loads issued THREE stages ahead and retired with a counted
-// s_waitcnt vmcnt(N) + raw s_barrier (cdna_hip_programming.md §5 "Pipelining across barriers"): the L2->LDS stream
-// never drains.  LDS rows are 64 B (4 chunks); chunk c of row r is stored at c ^ G[(r>>2)&3], G = {0,2,3,1}, which
-// makes the 16-row x 64-B ds_read_b128 fragment reads conflict-free for all four 16-lane groups.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, int NS_>
-struct Ring {
-  static constexpr int BKR = 32, NS = NS_;
-  static constexpr int XB = T::BM * 64, WB = T::BN * 64, STAGE = XB + WB, SMEM = NS * STAGE;
-  static constexpr int XI = T::BM * 4 / T::NT, WI = T::BN * 4 / T::NT, G = XI + WI;
-  static_assert((T::BM * 4) % T::NT == 0 && (T::BN * 4) % T::NT == 0 && (T::NT / 4) % 16 == 0, "bad ring tile");
-};
-
-__device__ __forceinline__ int ring_swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
-template <typename T, int NS, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(T::NT, T::OCC) void gemm_ring_kernel(const KArgs a) {
-  using R = Ring<T, NS>;
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
-
-  int tile_m, tile_n;
-  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // staging: instruction i, thread t -> LDS slot p = i*NT + t = row (p>>2), stored chunk (p&3); source chunk = stored ^ swz(row)
-  const int srow = tid >> 2;
-  const int schunk = (tid & 3) ^ ring_swz(srow);
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int xoff[R::XI], woff[R::WI];
-#pragma unroll
-  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
-#pragma unroll
-  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
-  const int lds_wave_off = wave * 1024;
-  auto stage = [&](int kt) {
-    char* xs = smem + (kt % R::NS) * R::STAGE + lds_wave_off;
-    char* ws = xs + R::XB;
-    const int k0 = kt * R::BKR * 2;
-#pragma unroll
-    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
-#pragma unroll
-    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
-  };
-
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
-  const int xbase = wave_m * T::WTM * 64 + foff;
-  const int wbase = R::XB + wave_n * T::WTN * 64 + foff;
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / R::BKR;
-  constexpr int PD = NS - 1;            // prefetch distance (stages in flight beyond the one being computed: PD - 1)
-#pragma unroll
-  for (int p = 0; p < PD; ++p)
-    if (p < nk) stage(p);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = nk - 1 - kt;      // stages issued after kt that may stay in flight (at most PD - 1)
-    if (PD >= 3 && ahead >= 2) wait_vmcnt<2 * R::G>();
-    else if (ahead >= 1) wait_vmcnt<R::G>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();       // stage kt visible to all waves; slot (kt+PD)%NS no longer read by anyone
-    if (kt + PD < nk) stage(kt + PD);
-    const char* st = smem + (kt % R::NS) * R::STAGE;
-    f16x8 xf[TM], wf[TN];
-#pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 1024);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 1024);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
-}
-
-template <typename T, int NS, int EPI, bool OUT_F32>
-int launch_ring(KArgs k, hipStream_t s) {
-  using R = Ring<T, NS>;
-  static DeviceOnce attr_once;
-  auto fn = gemm_ring_kernel<T, NS, EPI, OUT_F32>;
-  ensure_dynamic_lds(fn, R::SMEM, attr_once);
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
-  k.tiles_n = (k.N + T::BN - 1) / T::BN;
-  k.band = pick_band(k.tiles_n, T::BN, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
-  return check_launch("gemm_ring_kernel");
-}
 
 // (rstd, mean * rstd) of every row from the producer's row partials: ln_row_params once per row and GEMM
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2* __restrict__ rows) {
@@ -846,495 +708,6 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2*
   float rs, mrs;
   ln_row_params(a, m, rs, mrs);
   rows[m] = make_float2(rs, mrs);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent variant of the 2-stage kernel: one workgroup per CU walks its tiles (same XCD-aware order, virtual block
-// id = blockIdx + k * gridDim).  After the last K-step of a tile the first stage of the NEXT tile is DMA'd into the
-// free LDS buffer before the epilogue starts, so the operand latency of a tile's first stage and the drain of the
-// previous tile's stores overlap instead of adding to every tile (K = 768 tiles are only 12 K-steps long).  The fp16
-// epilogue patch lives behind the two stage buffers (16-row chunks keep it at 2.25 KiB per wave).
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(T::NT, T::OCC) void gemm_persist_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
-  constexpr int ROWB = T::WTN * 2 + 16;
-  constexpr bool PATCH_ALIASED = T::SMEM + T::NW * 16 * ROWB > 160 * 1024;
-  static_assert(T::NW * 16 * ROWB <= T::STAGE, "epilogue patches must fit one stage buffer");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
-  const int tiles_m = (a.M + BM - 1) / BM;
-
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  int xoff[T::XI], woff[T::WI];
-#pragma unroll
-  for (int i = 0; i < T::XI; ++i) xoff[i] = ((i * (NT / 8) + srow) * (int)a.lda + schunk * 8) * 2;
-#pragma unroll
-  for (int i = 0; i < T::WI; ++i) woff[i] = ((i * (NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
-  const int lds_wave_off = wave * 1024;
-
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int swz = (r16 >> 1) & 7;
-  int foff[2];
-  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
-  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
-  const int xbase = wave_m * T::WTM * 128;
-  const int wbase = T::XBYTES + wave_n * T::WTN * 128;
-  const int nk = a.K / BK;   // even? not required: buffer of the last step is (nk-1)&1, the prefetch goes to buffer 0
-                             // only when that is free, i.e. nk even or after the trailing barrier (always true below)
-
-  auto coords = [&](int vb, int& m0, int& n0) {
-    const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    const int per_band = tiles_m * a.band;
-    const int b = wg / per_band;
-    const int within = wg - b * per_band;
-    const int rem = a.tiles_n - b * a.band;
-    const int gw = rem < a.band ? rem : a.band;
-    const int tm = within / gw;
-    m0 = tm * BM;
-    n0 = (b * a.band + (within - tm * gw)) * BN;
-  };
-  // per-thread source offsets rebuilt from one base per operand (see gemm_f16_kernel): at the 128-VGPR cap of 16 waves
-  // the eight of them were spilled and reloaded from scratch inside the K loop
-  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
-  auto row_off = [](int base, int add) {
-    int r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
-    return r;
-  };
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
-    char* xs = smem + buf * T::STAGE + lds_wave_off;
-    char* ws = xs + T::XBYTES;
-    const int k0 = kt * BK * 2;
-#pragma unroll
-    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff[0], i * xstep), k0);
-#pragma unroll
-    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff[0], i * wstep), k0);
-  };
-
-  int vb = blockIdx.x;
-  int m0, n0;
-  coords(vb, m0, n0);
-  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int first_buf = 0;
-  stage(xrs, wrs, first_buf, 0);
-  // LayerNorm-fold consumer: (rstd, mean*rstd) of a tile's rows in LDS, double buffered by tile parity -- tile i+1's
-  // are written while tile i's epilogue may still read its own
-  constexpr int LNP_OFF = (PATCH_ALIASED ? T::SMEM : T::SMEM + T::NW * 16 * ROWB);
-  constexpr bool CONSUMER = EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU;
-  constexpr int COLP_OFF = LNP_OFF + 2 * BM * (int)sizeof(float2);   // then 2 x ([BN] bias | [BN] g)
-  constexpr bool COLP = EPI != CLIPMI_EPI_NONE && !OUT_F32 && EPI != EPI_PATCH_POS;
-  int par = 0;
-  auto row_params = [&](int row0, int col0, int which) {
-    if constexpr (CONSUMER && COLP) {
-      if (ln_rows) {   // kernel argument: uniform
-        // Row parameters finalised once per GEMM (ln_finalize_kernel) + the column parameters: straight into LDS by DMA, one
-        // 1 KiB piece per wave.  Computing them here with ordinary loads put a vmcnt(0) -- i.e. the whole 64 KB prefetch of
-        // the next tile's first stage -- and 256 chains of fp64 arithmetic between two tiles (phase stamps: 3.8 us per c_fc tile).
-        constexpr int PL = BM * 8 / 1024, PC = BN * 4 / 1024;
-        static_assert(PL + 2 * PC <= T::NW && (BM * 8) % 1024 == 0 && (BN * 4) % 1024 == 0, "one DMA piece per wave");
-        char* lnp = smem + LNP_OFF + which * (BM * 8);
-        char* colp = smem + COLP_OFF + which * (2 * BN * 4);
-        if (wave < PL) {
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows + row0, (int64_t)(a.M - row0) * 8);
-          CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, (wave * 64 + lane) * 16, 0);
-        } else if (wave < PL + PC) {
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bias + col0, (int64_t)(a.N - col0) * 4);
-          CLIPMI_BUFFER_LOAD_LDS16(rs, colp + (wave - PL) * 1024, ((wave - PL) * 64 + lane) * 16, 0);
-        } else if (wave < PL + 2 * PC) {
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_g + col0, (int64_t)(a.N - col0) * 4);
-          CLIPMI_BUFFER_LOAD_LDS16(rs, colp + BN * 4 + (wave - PL - PC) * 1024, ((wave - PL - PC) * 64 + lane) * 16, 0);
-        }
-        return;
-      }
-    }
-    if constexpr (CONSUMER) {
-      if (a.ln_stats) {   // block-uniform
-        float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
-        for (int t = tid; t < BM; t += NT) {
-          float rs, mrs;
-          ln_row_params(a, row0 + t, rs, mrs);
-          dst[t] = make_float2(rs, mrs);
-        }
-      }
-    }
-    if constexpr (COLP) {
-      float* dst = reinterpret_cast<float*>(smem + COLP_OFF) + which * 2 * BN;
-      for (int t = tid; t < BN; t += NT) {
-        const int n = col0 + t;
-        dst[t] = n < a.N ? a.bias[n] : 0.f;
-        dst[BN + t] = (n < a.N && a.ln_stats) ? a.ln_g[n] : 0.f;
-      }
-    }
-  };
-  row_params(m0, n0, 0);
-
-#ifdef CLIPMI_TUNING
-  const bool stamp = a.stamps != nullptr && tid == 0;
-#endif
-  while (true) {
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef CLIPMI_TUNING
-    if (stamp) {
-      a.stamps[vb * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
-      a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
-    }
-#endif
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = (first_buf + kt) & 1;
-      // stage kt was issued before everything still outstanding except (first iteration only) the previous tile's
-      // epilogue stores; vmcnt(0) also drains those -- they were issued a full prefetch latency ago
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-#ifdef CLIPMI_TUNING
-      if (stamp && kt == 0) {
-        a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-        a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
-      }
-#endif
-      if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
-      const char* st = smem + buf * T::STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        // weight fragments one tile ahead instead of all TN at once: 24 live fragment registers instead of 32 -- at the
-        // 128-VGPR cap of a 16-wave workgroup the difference is a scratch reload inside this loop
-        f16x8 xf[TM], wcur, wnext;
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
-        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          wcur = wnext;
-        }
-      }
-    }
-    const int last_buf = (first_buf + nk - 1) & 1;
-    const int cm0 = m0, cn0 = n0;
-    [[maybe_unused]] const int cvb = vb;
-#ifdef CLIPMI_TUNING
-    if (stamp) {
-      a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-      a.stamps[cvb * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
-    }
-#endif
-    const int nvb = vb + gridDim.x;
-    const bool has_next = nvb < a.nwg;
-    if (has_next) {
-      // the buffer that is NOT the last one read is free (its reads finished before the last barrier)
-      vb = nvb;
-      coords(vb, m0, n0);
-      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-      first_buf = last_buf ^ 1;
-      stage(xrs, wrs, first_buf, 0);
-      row_params(m0, n0, par ^ 1);
-    }
-    const float2* lnp = (CONSUMER && a.ln_stats) ? reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM : nullptr;
-    const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
-    par ^= 1;
-    // the epilogue's lane-derived address constants are loop invariants of the tile loop: hipcc hoists them out, runs out of
-    // registers in the K loop and spills them -- and every reload waits vmcnt(0), i.e. for the next tile's prefetch.
-    // An opaque copy of the lane id makes them recomputed (a handful of VALU) per tile instead.
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
-      if ((a.N & 7) == 0 && (a.ldo & 7) == 0) {
-        if constexpr (PATCH_ALIASED) {
-          // 16-wave tile: no LDS left behind the stage buffers -> the patches live in the stage buffer of the last
-          // K-step (the prefetch above went to the other one).  Everyone must be done reading it first; the barrier
-          // at the top of the next tile's first K-step keeps stage(.., 1) out of it until every epilogue has finished.
-          __syncthreads();
-          epilogue_f16_staged<T, EPI, 1, COLP>(acc, a, cm0, cn0, wave_m, wave_n, lane_e, smem + last_buf * T::STAGE + wave * (16 * ROWB), lnp, colp);
-        } else {
-          epilogue_f16_staged<T, EPI, 1, COLP>(acc, a, cm0, cn0, wave_m, wave_n, lane_e, smem + T::SMEM + wave * (16 * ROWB), lnp, colp);
-        }
-      } else {
-        epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane_e);
-      }
-    } else {
-      epilogue_direct<T, EPI, OUT_F32>(acc, a, cm0, cn0, wave_m, wave_n, lane_e);
-    }
-#ifdef CLIPMI_TUNING
-    if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-    if (!has_next) break;
-  }
-}
-
-template <typename T, int EPI, bool OUT_F32>
-int launch_persist(KArgs k, hipStream_t s, float2* ln_rows = nullptr) {
-  constexpr int SMEM_SEP = T::SMEM + T::NW * 16 * (T::WTN * 2 + 16);
-  constexpr int SMEM = (SMEM_SEP > 160 * 1024 ? T::SMEM : SMEM_SEP) + 2 * T::BM * (int)sizeof(float2) + 4 * T::BN * (int)sizeof(float);   // + row / column parameters
-  static DeviceOnce attr_once;
-  auto fn = gemm_persist_kernel<T, EPI, OUT_F32>;
-  ensure_dynamic_lds(fn, SMEM, attr_once);
-  int n_cu = device_cus();
-  n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
-  k.tiles_n = (k.N + T::BN - 1) / T::BN;
-  k.band = pick_band(k.tiles_n, T::BN, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
-  const int grid = k.nwg < n_cu * per_cu ? k.nwg : n_cu * per_cu;
-  constexpr bool DMA_OK = (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) && !OUT_F32;
-  const float2* rows = nullptr;
-  if (DMA_OK && k.ln_stats && ln_rows) {   // the row partials -> (rstd, mean * rstd), once per GEMM
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((k.M + 255) / 256), dim3(256), 0, s, k, ln_rows);
-    const int rc = check_launch("ln_finalize_kernel");
-    if (rc) return rc;
-    rows = ln_rows;
-  }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(T::NT), SMEM, s, k, rows);
-  return check_launch("gemm_persist_kernel");
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Deferred-store persistent variant (fp16-out epilogues only): 256 x 192 tile, TWELVE waves of 64 x 64 (three per SIMD,
-// 170 VGPRs each), one workgroup per CU walking its tiles.  What it changes against the kernels above: the output of
-// tile i is converted to fp16 right after its main loop (bias / LayerNorm fold / QuickGELU) and HELD in 32 registers
-// per wave; its LDS transpose and global stores are then issued in four 16-row slices spread over the K loop of tile
-// i+1.  Every tile of the other kernels ends in a burst -- 256 CUs x 128 KB of stores at once, then a relaunch or a
-// vmcnt(0) that waits for that burst to be acknowledged (phase stamps: 2.6-5 us per 23-26 us tile).  Here the HBM write
-// stream is continuous and the only epilogue work left on the critical path is the element-wise math.
-// ---------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(768, 3) void gemm_defer_kernel(const KArgs a) {
-  constexpr int BM = 256, BN = 192, NT = 768, TM = 4, TN = 4, WGM = 4;
-  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
-  constexpr int XI = 3, WI = 2;                       // 2048 / 768 (last one partial) and 1536 / 768 DMA instructions per stage
-  constexpr int ROWB = 64 * 2 + 16, PATCH = 16 * ROWB;
-  constexpr int PATCH_OFF = 2 * STAGE, LNP_OFF = PATCH_OFF + 12 * PATCH, COLP_OFF = LNP_OFF + 2 * BM * 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % WGM, wave_n = wave / WGM;
-  const int tiles_m = (a.M + BM - 1) / BM;
-
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
-  const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
-  auto row_off = [](int base, int add) {
-    int r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
-    return r;
-  };
-  const int lds_wave_off = wave * 1024;
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int swz = (r16 >> 1) & 7;
-  int foff[2];
-  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
-  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
-  const int xbase = wave_m * 64 * 128;
-  const int wbase = XBYTES + wave_n * 64 * 128;
-  const int nk = a.K / BK;
-  const int step = nk >= 4 ? nk / 4 : 1;              // a store slice every `step` K-steps
-
-  auto coords = [&](int vb, int& m0, int& n0) {
-    const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    const int per_band = tiles_m * a.band;
-    const int b = wg / per_band;
-    const int within = wg - b * per_band;
-    const int rem = a.tiles_n - b * a.band;
-    const int gw = rem < a.band ? rem : a.band;
-    const int tm = within / gw;
-    m0 = tm * BM;
-    n0 = (b * a.band + (within - tm * gw)) * BN;
-  };
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
-    char* xs = smem + buf * STAGE + lds_wave_off;
-    char* ws = xs + XBYTES;
-    const int k0 = kt * BK * 2;
-#pragma unroll
-    for (int i = 0; i < XI; ++i)
-      if (i * NT + wave * 64 < BM * 8)   // wave-uniform: the third instruction covers slots 1536..2047 only
-        CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff0, i * xstep), k0);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff0, i * wstep), k0);
-  };
-  constexpr bool CONSUMER = EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU;
-  auto params = [&](int row0, int col0, int which) {   // (rstd, mean*rstd) per row and (bias, g) per column of a tile -> LDS
-    if constexpr (CONSUMER) {
-      if (a.ln_stats) {
-        float2* dst = reinterpret_cast<float2*>(smem + LNP_OFF) + which * BM;
-        for (int t = tid; t < BM; t += NT) {
-          float rs, mrs;
-          ln_row_params(a, row0 + t, rs, mrs);
-          dst[t] = make_float2(rs, mrs);
-        }
-      }
-    }
-    float* dst = reinterpret_cast<float*>(smem + COLP_OFF) + which * 2 * BN;
-    for (int t = tid; t < BN; t += NT) {
-      const int n = col0 + t;
-      dst[t] = (EPI != CLIPMI_EPI_NONE && n < a.N) ? a.bias[n] : 0.f;
-      dst[BN + t] = (n < a.N && a.ln_stats) ? a.ln_g[n] : 0.f;
-    }
-  };
-
-  int vb = blockIdx.x;
-  int m0, n0;
-  coords(vb, m0, n0);
-  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int first_buf = 0, par = 0;
-  stage(xrs, wrs, first_buf, 0);
-  params(m0, n0, 0);
-
-  f16x4 held[TN][TM];        // the previous tile's outputs of this wave, fp16
-  int hm0 = 0, hn0 = 0;      // its origin
-  int pending = TM;          // next 16-row slice (j) of `held` to store; TM = nothing held
-  half_t* out = static_cast<half_t*>(a.out);
-  char* patch = smem + PATCH_OFF + wave * PATCH;
-  auto flush = [&](int j) {  // slice j of the held tile: LDS transpose, then 16-byte stores, 128 contiguous bytes per row
-    int le = lane;
-    asm volatile("" : "+v"(le));
-    const int er16 = le & 15, eg4 = le >> 4, rrow = le >> 3, rcol = le & 7;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) *reinterpret_cast<f16x4*>(patch + er16 * ROWB + (i * 16 + eg4 * 4) * 2) = held[i][j];
-    const int n_st = hn0 + wave_n * 64 + rcol * 8;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t * 8 + rrow;
-      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
-      const int m = hm0 + wave_m * 64 + j * 16 + row;
-      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(out + (int64_t)m * a.ldo + n_st) = val;
-    }
-  };
-
-  while (true) {
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = (first_buf + kt) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage kt (and the store slice issued a K-step ago)
-      __syncthreads();
-      if (kt + 1 < nk) stage(xrs, wrs, buf ^ 1, kt + 1);
-      if (pending < TM && kt >= 1 + pending * step) {     // wave-uniform
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          if (j == pending) flush(j);
-        ++pending;
-      }
-      const char* st = smem + buf * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f16x8 xf[TM], wcur, wnext;
-#pragma unroll
-        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
-        wcur = *reinterpret_cast<const f16x8*>(st + wbase + foff[ks]);
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if (i + 1 < TN) wnext = *reinterpret_cast<const f16x8*>(st + wbase + (i + 1) * 2048 + foff[ks]);
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur, xf[j], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          wcur = wnext;
-        }
-      }
-    }
-    // anything of the previous tile still held (short K): out it goes before `held` is overwritten
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-      if (j >= pending) flush(j);
-
-    const int last_buf = (first_buf + nk - 1) & 1;
-    const int cm0 = m0, cn0 = n0;
-    const int nvb = vb + gridDim.x;
-    const bool has_next = nvb < a.nwg;
-    if (has_next) {
-      vb = nvb;
-      coords(vb, m0, n0);
-      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-      first_buf = last_buf ^ 1;
-      stage(xrs, wrs, first_buf, 0);
-      params(m0, n0, par ^ 1);
-    }
-    // ---- element-wise epilogue into `held` (row / column parameters from LDS)
-    {
-      int le = lane;
-      asm volatile("" : "+v"(le));
-      const int er16 = le & 15, eg4 = le >> 4;
-      const bool fold = CONSUMER && a.ln_stats != nullptr;
-      const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF) + par * BM;
-      const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        float rs = 1.f, mrs = 0.f;
-        if (fold) {
-          const float2 pr = lnp[wave_m * 64 + j * 16 + er16];
-          rs = pr.x;
-          mrs = pr.y;
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int nl = wave_n * 64 + i * 16 + eg4 * 4;
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(colp + nl);
-          const f32x4 gg = *reinterpret_cast<const f32x4*>(colp + BN + nl);
-          f32x4 v = acc[i][j] * rs + (bb - mrs * gg);
-          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-          }
-          held[i][j] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        }
-      }
-    }
-    hm0 = cm0;
-    hn0 = cn0;
-    pending = 0;
-    par ^= 1;
-    if (!has_next) break;
-  }
-#pragma unroll
-  for (int j = 0; j < TM; ++j) flush(j);   // the last tile's outputs
-}
-
-template <int EPI>
-int launch_defer(KArgs k, hipStream_t s) {
-  constexpr int SMEM = 2 * (256 + 192) * 128 + 12 * 16 * 144 + 2 * 256 * 8 + 2 * 2 * 192 * 4;
-  static DeviceOnce attr_once;
-  auto fn = gemm_defer_kernel<EPI>;
-  ensure_dynamic_lds(fn, SMEM, attr_once);
-  int n_cu = device_cus();
-  n_cu &= ~7;   // the XCD label of a virtual block id must not change across rounds
-  const int tiles_m = (k.M + 255) / 256;
-  k.tiles_n = (k.N + 191) / 192;
-  k.band = pick_band(k.tiles_n, 192, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  const int grid = k.nwg < n_cu ? k.nwg : n_cu;
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(768), SMEM, s, k);
-  return check_launch("gemm_defer_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1400,11 +773,14 @@ __device__ __forceinline__ void lgkm_wait5(f16x8& a, f16x8& b, f16x8& c, f16x8& 
 #endif
 using TStream = Tile<256, 256, 2, 4, 2>;
 constexpr int STREAM_RAW_PARTS = 4;   // row-partial slots of gemm_stream_kernel's LDS table (D <= 1024 with 256-column producer tiles)
-// the streamed kernel can finalise the LayerNorm row partials itself (RAW mode) unless there are too many or the option says no;
-// without a scratch row for ln_finalize_kernel it must
-inline bool stream_raw_ok(const KArgs& k, const float2* ln_rows) {
-  if (k.ln_parts > STREAM_RAW_PARTS) return false;
-  return ln_rows == nullptr || options().ln_inline.load(std::memory_order_relaxed) == 1;
+// the streamed kernel finalises the LayerNorm row partials itself (RAW mode) while they fit its LDS table; wider producers
+// (more than STREAM_RAW_PARTS column tiles) go through one ln_finalize_kernel launch per folded GEMM, which needs a scratch row
+inline bool stream_raw_ok(const KArgs& k) { return k.ln_parts <= STREAM_RAW_PARTS; }
+// the persistent kernels address a tile with 32-bit byte offsets from its first row (257 rows of any operand must fit) and map
+// virtual block ids to XCD labels through a grid that is a multiple of 8
+inline bool stream_offsets_ok(const KArgs& k) {
+  const int64_t lim = (1ll << 31) / (2 * 257);
+  return k.lda < lim && k.ldw < lim && k.ldo < lim && (device_cus() & ~7) >= 8;
 }
 
 template <int EPI>
@@ -1859,11 +1235,11 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
   k.band = pick_band(k.tiles_n, T::BN, k.K);
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  CLIPMI_REQUIRE(257 * k.ldo * 2 < (1ll << 31), CLIPMI_ERR_SHAPE, "gemm: output rows too long for the 32-bit tile offsets of the streamed epilogue");
+  CLIPMI_REQUIRE(stream_offsets_ok(k), CLIPMI_ERR_SHAPE, "gemm: leading dimensions too long for the 32-bit tile offsets of the streamed kernel");
   k.nwg = (int)nwg;
-  // RAW mode (default): the kernel finalises the row partials itself; otherwise (more partials than its LDS table holds, or
-  // option ln_inline = 0) they are reduced to (rstd, mean * rstd) once per GEMM by ln_finalize_kernel
-  const bool raw = k.ln_stats && stream_raw_ok(k, ln_rows);
+  // RAW mode: the kernel finalises the row partials itself; with more partials than its LDS table holds they are reduced to
+  // (rstd, mean * rstd) once per GEMM by ln_finalize_kernel
+  const bool raw = k.ln_stats && stream_raw_ok(k);
   if (k.ln_stats && !raw) {
     hipLaunchKernelGGL(ln_finalize_kernel, dim3((k.M + 255) / 256), dim3(256), 0, s, k, ln_rows);
     const int rc = check_launch("ln_finalize_kernel");
@@ -1893,7 +1269,7 @@ __device__ __forceinline__ void lgkm_wait_x(f16x8 (&x)[H]) {
   static_assert(H == 4 || H == 5, "half of the wave tile: 4 or 5 activation blocks");
 }
 
-template <typename T, int EPI, bool OUT_F32, bool WIDE = false>
+template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
   static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
@@ -1906,20 +1282,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
   const int grp = wave >> 2;   // uniform: waves w and w + 4 share a SIMD
 
-  // mixed tile heights (mixed_tile_rows): only the fp16-stream residual epilogue of the 320-row tile knows about short tiles
-  constexpr bool MIX = EPI == EPI_RESIDUAL_FOLD16 && H == 5 && !WIDE;
   int tile_m, tile_n;
   tile_coords(a, a.nwg / a.tiles_n, tile_m, tile_n);
-  int m0 = tile_m * BM;
-  bool tall = true;   // workgroup-uniform (kernel arguments and blockIdx only)
-  if constexpr (MIX) {
-    if (a.mix > 0) {
-      mixed_tile_rows(a, BM, tile_m, m0, tall);
-      if (m0 >= a.M) return;   // spare tile of the last round
-    }
-  }
-  const int nb = tall ? TM : TM - 1;   // live 16-row blocks per wave: the wave's rows start at wave_m * nb * 16
-  const int n0 = tile_n * T::BN;
+  const int m0 = tile_m * BM, n0 = tile_n * T::BN;
 
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
@@ -1933,24 +1298,21 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
     return r;
   };
   const int lds_wave_off = wave * 1024;
-  auto stage_piece = [&](auto p_tag, int buf, int kt, auto partner_tag) {
+  auto stage_piece = [&](auto p_tag, int buf, int kt) {
     constexpr int P = decltype(p_tag)::value;
-    constexpr bool PARTNER = decltype(partner_tag)::value;   // the piece of wave + 4 (its rows lie 32 further: (tid + 256) >> 3; same chunk swizzle)
     if constexpr (P < NP) {
-      char* xs = smem + buf * T::STAGE + lds_wave_off + (PARTNER ? 4 * 1024 : 0);
+      char* xs = smem + buf * T::STAGE + lds_wave_off;
       const int k0 = kt * BK * 2;
-      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep + (PARTNER ? xstep / 2 : 0)), k0);
-      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep + (PARTNER ? wstep / 2 : 0)), k0);
+      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
+      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
     }
   };
-  constexpr std::false_type own{};
-  constexpr std::true_type partner{};
 
   const int r16 = lane & 15, g4 = lane >> 4;
   const int swz = (r16 >> 1) & 7;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t f0 = (uint32_t)(r16 * 128 + (((0 + g4) ^ swz) << 4)), f1 = (uint32_t)(r16 * 128 + (((4 + g4) ^ swz) << 4));
-  const uint32_t xb = (uint32_t)(wave_m * nb * 16 * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
+  const uint32_t xb = (uint32_t)(wave_m * T::WTM * 128), wb = (uint32_t)(T::XBYTES + wave_n * T::WTN * 128);
   const int nk = a.K / BK;
 
 #ifdef CLIPMI_TUNING
@@ -1961,11 +1323,11 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   }
 #endif
   // ---- prologue: stage 0, and (LayerNorm-fold consumers) the tile's row parameters, behind the DMA latency
-  stage_piece(std::integral_constant<int, 0>{}, 0, 0, own); stage_piece(std::integral_constant<int, 1>{}, 0, 0, own);
-  stage_piece(std::integral_constant<int, 2>{}, 0, 0, own); stage_piece(std::integral_constant<int, 3>{}, 0, 0, own);
-  stage_piece(std::integral_constant<int, 4>{}, 0, 0, own); stage_piece(std::integral_constant<int, 5>{}, 0, 0, own);
-  stage_piece(std::integral_constant<int, 6>{}, 0, 0, own); stage_piece(std::integral_constant<int, 7>{}, 0, 0, own);
-  stage_piece(std::integral_constant<int, 8>{}, 0, 0, own);
+  stage_piece(std::integral_constant<int, 0>{}, 0, 0); stage_piece(std::integral_constant<int, 1>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 2>{}, 0, 0); stage_piece(std::integral_constant<int, 3>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 4>{}, 0, 0); stage_piece(std::integral_constant<int, 5>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 6>{}, 0, 0); stage_piece(std::integral_constant<int, 7>{}, 0, 0);
+  stage_piece(std::integral_constant<int, 8>{}, 0, 0);
   static_assert(NP <= 9, "at most nine pieces per wave and stage");
   float2* lnp = nullptr;
   if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
@@ -1988,16 +1350,6 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 #endif
 
   f32x4 acc[TN][TM];
-#ifdef CLIPMI_TUNING
-  // part timers (diagnostic build): lane 0 of waves 0 and 4 sums the shader-clock time of its load parts (issue -> fragments in
-  // registers), of the wait at the barrier behind them, of its compute parts and of the wait at the barrier behind those;
-  // written to stamps[(4096 + blockIdx) * 8 + 4 * group + {0,1,2,3}] (tools/gemm_stamps.py prints the medians)
-  long long tm_load = 0, tm_b1 = 0, tm_comp = 0, tm_b2 = 0;
-  const bool timer = a.stamps != nullptr && lane == 0 && (wave & 3) == 0;
-#define PP_T() (timer ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
-#else
-#define PP_T() 0ll
-#endif
   auto kstep = [&](auto first_tag, auto more_tag, int kt) {
     constexpr bool FIRSTK = decltype(first_tag)::value;
     constexpr bool MORE = decltype(more_tag)::value;
@@ -2009,16 +1361,13 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       constexpr int P = decltype(p_tag)::value;
       constexpr int KS = P >> 1, JH = P & 1;
       // ---- load part
-      [[maybe_unused]] const long long t0 = PP_T();
       {
         const uint32_t xa = KS ? xa1 : xa0;
         ds_read128<(JH * H + 0) * 2048>(xf[0], xa);
         ds_read128<(JH * H + 1) * 2048>(xf[1], xa);
         ds_read128<(JH * H + 2) * 2048>(xf[2], xa);
         ds_read128<(JH * H + 3) * 2048>(xf[3], xa);
-        if constexpr (H == 5) {
-          if (!MIX || JH == 0 || tall) ds_read128<(JH * H + 4) * 2048>(xf[H - 1], xa);   // a short tile has no tenth block
-        }
+        if constexpr (H == 5) ds_read128<(JH * H + 4) * 2048>(xf[H - 1], xa);
         if constexpr (JH == 0) {
           const uint32_t wa = KS ? wa1 : wa0;
           ds_read128<0>(wf[0], wa);
@@ -2028,9 +1377,9 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
         }
       }
       if constexpr (MORE && P < 3) {
-        stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1, own);
-        stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1, own);
-        stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1, own);
+        stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1);
+        stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1);
+        stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1);
         static_assert(PPP == 3, "three pieces per load part");
       }
       if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
@@ -2038,16 +1387,13 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       if constexpr (P == 3) {
         if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
       }
-      [[maybe_unused]] const long long t1 = PP_T();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!(CLIPMI_ABLATE & 32)) __builtin_amdgcn_s_barrier();   // (ablation 32: timing without the load -> compute barriers; results wrong)
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      [[maybe_unused]] const long long t2 = PP_T();
       // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        if (MIX && JH == 1 && j == H - 1 && !tall) break;   // short tile: block TM - 1 does not exist (uniform branch)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           if constexpr (FIRSTK && KS == 0)
@@ -2060,84 +1406,14 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       if constexpr (P == 3) {
         if (grp == 0) wait_vmcnt<0>();
       }
-      [[maybe_unused]] const long long t3 = PP_T();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef CLIPMI_TUNING
-      if (timer) {
-        const long long t4 = (long long)__builtin_amdgcn_s_memtime();
-        tm_load += t1 - t0; tm_b1 += t2 - t1; tm_comp += t3 - t2; tm_b2 += t4 - t3;
-      }
-#endif
-    };
-    // WIDE: two phases per K-step (one per k-half, all TM activation blocks): half the barriers -- part timers put a barrier at
-    // ~130 cycles, eight per K-step against 2 560 cycles of MFMAs on the 320-row tile.  The next stage's pieces must all be out
-    // by the third of the four slots, so the groups share them unevenly: waves 0-3 issue six of their own in their first load
-    // part and their last three plus their partner's last three in the second; waves 4-7 six of their own in their first.
-    auto wide_phase = [&](auto p_tag) {
-      constexpr int KS = decltype(p_tag)::value;
-      f16x8 xw[TM];
-      {
-        const uint32_t xa = KS ? xa1 : xa0, wa = KS ? wa1 : wa0;
-        ds_read128<0>(wf[0], wa);
-        ds_read128<2048>(wf[1], wa);
-        ds_read128<4096>(wf[2], wa);
-        ds_read128<6144>(wf[3], wa);
-        ds_read128<0 * 2048>(xw[0], xa); ds_read128<1 * 2048>(xw[1], xa); ds_read128<2 * 2048>(xw[2], xa); ds_read128<3 * 2048>(xw[3], xa);
-        ds_read128<4 * 2048>(xw[4], xa); ds_read128<5 * 2048>(xw[5], xa); ds_read128<6 * 2048>(xw[6], xa); ds_read128<7 * 2048>(xw[7], xa);
-        if constexpr (TM == 10) { ds_read128<8 * 2048>(xw[8], xa); ds_read128<9 * 2048>(xw[TM - 1], xa); }
-      }
-      if constexpr (MORE) {
-        if constexpr (KS == 0) {   // both groups: own pieces 0..5
-          stage_piece(std::integral_constant<int, 0>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 1>{}, buf ^ 1, kt + 1, own);
-          stage_piece(std::integral_constant<int, 2>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 3>{}, buf ^ 1, kt + 1, own);
-          stage_piece(std::integral_constant<int, 4>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 5>{}, buf ^ 1, kt + 1, own);
-        } else if (grp == 0) {     // waves 0-3: own 6..8 and the partner's 6..8
-          stage_piece(std::integral_constant<int, 6>{}, buf ^ 1, kt + 1, own); stage_piece(std::integral_constant<int, 7>{}, buf ^ 1, kt + 1, own);
-          stage_piece(std::integral_constant<int, 8>{}, buf ^ 1, kt + 1, own);
-          stage_piece(std::integral_constant<int, 6>{}, buf ^ 1, kt + 1, partner); stage_piece(std::integral_constant<int, 7>{}, buf ^ 1, kt + 1, partner);
-          stage_piece(std::integral_constant<int, 8>{}, buf ^ 1, kt + 1, partner);
-        }
-      }
-      lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
-      lgkm_wait4<0>(xw[0], xw[1], xw[2], xw[3]);
-      lgkm_wait4<0>(xw[4], xw[5], xw[6], xw[7]);
-      if constexpr (TM == 10) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[8]), "+v"(xw[TM - 1]));
-      if constexpr (KS == 1) {
-        if (grp == 1) wait_vmcnt<0>();   // this wave's pieces (issued three slots ago) have landed
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if constexpr (FIRSTK && KS == 0)
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
-          else
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
-        }
-      __builtin_amdgcn_s_setprio(0);
-      if constexpr (KS == 1) {
-        if (grp == 0) wait_vmcnt<0>();
-      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (WIDE) {
-      static_assert(!WIDE || (NP == 9 || NP == 8), "piece plan of the wide phases");
-      wide_phase(std::integral_constant<int, 0>{});
-      wide_phase(std::integral_constant<int, 1>{});
-    } else {
-      phase(std::integral_constant<int, 0>{});
-      phase(std::integral_constant<int, 1>{});
-      phase(std::integral_constant<int, 2>{});
-      phase(std::integral_constant<int, 3>{});
-    }
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
   };
 
   constexpr std::false_type no{};
@@ -2153,13 +1429,8 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
     a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
     a.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
   }
-  if (timer && blockIdx.x < 4096) {
-    long long* tp = a.stamps + (4096 + blockIdx.x) * 8 + 4 * grp;
-    tp[0] = tm_load; tp[1] = tm_b1; tp[2] = tm_comp; tp[3] = tm_b2;
-  }
 #endif
-#undef PP_T
-  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp, MIX ? nb : TM);
+  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
 #ifdef CLIPMI_TUNING
   if (a.stamps != nullptr) {
     if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -2169,34 +1440,18 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 #endif
 }
 
-template <typename T, int EPI, bool OUT_F32, bool WIDE = false>
+template <typename T, int EPI, bool OUT_F32>
 int launch_pp(KArgs k, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = gemm_pp_kernel<T, EPI, OUT_F32, WIDE>;
+  auto fn = gemm_pp_kernel<T, EPI, OUT_F32>;
   constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
   constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;
   constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   static_assert(SMEM <= 160 * 1024, "tile does not fit the CU's LDS");
   ensure_dynamic_lds(fn, SMEM, attr_once);
-  int tiles_m = (k.M + T::BM - 1) / T::BM;
+  const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
-  k.mix = 0;
-  if constexpr (EPI == EPI_RESIDUAL_FOLD16 && T::BM == 320 && !WIDE) {
-    // Mixed tile heights (mixed_tile_rows): as many m-tiles as the launch's rounds hold, 288 rows each, plus the 320-row ones
-    // needed to cover M -- at most (32 CUs - tiles_n + 1) / tiles_n per XCD, so that all of them start in the first round.
-    const int n_cu = device_cus(), tn = k.tiles_n;
-    const int rounds = (int)(((int64_t)tiles_m * tn + n_cu - 1) / n_cu);
-    if (options().gemm_mix.load(std::memory_order_relaxed) == 1 && rounds >= 2 && n_cu % 8 == 0 && k.band == tn) {
-      const int64_t fit = (int64_t)rounds * n_cu / tn;                       // m-tiles that fit the same number of rounds
-      const int64_t need = (int64_t)k.M - (int64_t)(T::BM - 32) * fit;       // rows the tall tiles must add
-      const int n_tall = need <= 0 ? 0 : (int)((need + 32 * 8 - 1) / (32 * 8));   // per XCD
-      if (fit < (1 << 24) && fit >= tiles_m && n_tall * tn + tn - 1 <= n_cu / 8 && (int64_t)(n_tall + 2) * tn <= fit * tn / 8) {
-        k.mix = n_tall + 1;
-        tiles_m = n_tall == 0 ? (k.M + (T::BM - 32) - 1) / (T::BM - 32) : (int)fit;   // all short: no spare tiles needed
-      }
-    }
-  }
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
   k.nwg = (int)nwg;
@@ -2205,308 +1460,463 @@ int launch_pp(KArgs k, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipelined variant (the default for large problems): 256 x 256 tile, 8 waves of 128(m) x 64(n), BK = 32 stages in
-// the 4-slot ring, loads three stages ahead.  Each stage is two clusters of 16 MFMAs (m-tiles 0-3, then 4-7, against
-// the stage's 4 n-tile fragments); the LDS reads of a cluster are issued one cluster ahead into a second register
-// set, so a wave's ds_read latency hides under its own MFMAs, and the single barrier of a stage sits between the two
-// clusters with the operands of the following cluster already in registers.
-//   iteration kt:  read xb(kt) | MFMA a(kt) | wait stage kt+1, barrier | issue stage kt+3 | read xa,w(kt+1) | MFMA b(kt)
+// Persistent ROW-RANGE kernel for the fp16-stream residual GEMMs (EPI_RESIDUAL_FOLD16: out-proj, c_proj; round 3):
+//     x16[m, n] = fp16(x16[m, n] + A[m, :] . W[n, :] + bias[n])  in place,  + the LayerNorm-fold row partials of the rounded rows.
+//
+// Why.  gemm_pp_kernel runs these shapes as 320 x 256 tiles, one per workgroup, 1.85 rounds of 256 CUs; phase stamps
+// (profiles/r02_gemm_stamps_final.txt) put an out-proj tile at 1.3 us prologue + 20.4 us main loop + 11.3 us epilogue with the
+// matrix pipe idle: the residual rows come in and the sums go out as one burst per round (82 MB at once, HBM-bound), and every CU
+// reaches that burst at the same moment.  out-proj at N = K = 768 is close to HBM-bound as a whole (231 MB for 59.5 GFLOP), so its
+// traffic has to be a continuous stream under the MFMAs, not a burst between them.
+//
+// What.  One workgroup per CU (eight waves, two per SIMD, ping-pong as in gemm_stream_kernel).  The M x N problem is cut into
+// (row range, 256-column tile) UNITS, one per workgroup: the rows in `groups` near-equal ranges of 32-row pairs, every range taken
+// by tiles_n workgroups with adjacent ids (same XCD: the activation rows are fetched into its L2 once).  A workgroup walks its
+// range in TILES of 32 nb rows, nb = 4 .. 7 chosen so that the tiles of a range are equal to within one pair (M = 50 432, N = 768
+// on 256 CUs: 85 ranges of 18-19 pairs = tiles of 7 + 6 + 6 pairs; every CU carries the same 19 x 12 block-K-steps, where the
+// 320-row grid gives 218 CUs 20 and 38 CUs 10).  The epilogue leaves the critical path:
+//   * a wave keeps its nb x (16 rows x 64 columns) output slices as packed fp16 in 8 registers each ("slots");
+//   * slot j of the PREVIOUS tile is stored inside K-step j of the current tile (two 16-byte stores), and right behind it the
+//     RESIDUAL slice j of the CURRENT tile is loaded into the same registers (two 16-byte loads, the layout the stores use) -- a
+//     slot holds outputs early in a K loop and residual late; by the end of the K loop every residual slice has landed (in-order
+//     VMEM: the counted wait of the next K-step covers it), so the tile end is arithmetic only: un-swap, add in fp32, round once,
+//     row partials, re-pack into the slot;
+//   * the row partials of the four column waves meet in LDS and are reduced behind the tile's closing barrier, while the next
+//     tile's first stage (DMA'd piece by piece between the slices) is already in.
+// HBM sees 4 x 16 B per lane and K-step in each direction for the whole launch instead of 164 KB per CU in a burst.
+//
+// K loop: TWO wide phases per K-step (k-half ks): a LOAD part -- four weight fragments + nb activation fragments by pinned LDS reads,
+// this wave's share of the next stage's LDS-DMA pieces, the slot traffic -- and a COMPUTE part of 4 nb MFMAs on registers only, a
+// workgroup barrier after each part; waves 4-7 run one part behind waves 0-3 (with 16-MFMA quarter phases the load part, not the
+// matrix pipe, would set the slot length at nb <= 7).  Slots (S = 4 k + ..; G0 = waves 0-3, G1 = waves 4-7):
+//     S + 0: G0 load ks 0 (own pieces 0..5)              | G1 compute ks 1 of K-step k - 1
+//     S + 1: G0 compute ks 0                             | G1 load ks 0 (own pieces 0..5)
+//     S + 2: G0 load ks 1 (own 6, 7 + G1's 6, 7, slot j) | G1 compute ks 0
+//     S + 3: G0 compute ks 1, then vmcnt                 | G1 load ks 1 (slot j), then vmcnt
+//   WAR  stage k + 1 goes into the buffer of stage k - 1, last read by G1 in slot S - 1; the first piece is issued in slot S.
+//   RAW  every piece is out by slot S + 2 and waited for by its issuing wave at the end of slot S + 3 (G1's pieces 6, 7 are
+//        issued by its SIMD partner in G0, so that G1 issues nothing it would have to wait for in the same slot); the first read of
+//        stage k + 1 is in slot S + 4.  The slot traffic is issued BEHIND the pieces: vmcnt(4) leaves exactly it in flight.
+// Same K order, same MFMA, same (acc + bias) + residual, same partial sums as gemm_pp_kernel / gemm_f16_kernel with the fold16
+// epilogue: bit-identical results (tests/test_gpu_ops.py::test_gemm_residual_stream_race_screen).
+// Needs K >= 8 K-steps (slots 0..6 ride on K-steps 0..6, all of which prefetch a next stage), N % 8 == 0, at least 4 pairs per range.
 // ---------------------------------------------------------------------------------------------------------------
-using TPipe = Tile<256, 256, 2, 4, 2>;
+struct RStream {
+  static constexpr int TM = 7, TN = 4, NT = 512;
+  static constexpr int XB = 32 * TM * 128, WB = 256 * 128, STAGE = XB + WB;   // 224 activation rows + 256 weight rows of 64 k
+  static constexpr int BIAS_OFF = 2 * STAGE, RED_OFF = BIAS_OFF + 256 * 4;
+  static constexpr int SMEM = RED_OFF + 4 * 32 * TM * 8;                      // + [4 column waves][224 rows] (sum, sumsq)
+};
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const KArgs a) {
-  using T = TPipe;
-  using R = Ring<T, 4>;
-  constexpr int NT = T::NT;
+__device__ __forceinline__ void rs_wait_reads(f16x8 (&w)[4], f16x8 (&x)[RStream::TM]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, const int groups, const int pairs) {
+  using R = RStream;
+  constexpr int TM = R::TM, TN = R::TN, NT = R::NT;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
+  const int wave_m = wave & 1, wave_n = wave >> 1;
+  const int grp = wave >> 2;   // uniform: waves w and w + 4 share a SIMD
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int nk = a.K / BK;
 
-  int tile_m, tile_n;
-  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
-  const int m0 = tile_m * T::BM, n0 = tile_n * T::BN;
+  // ---- this workgroup's unit: logical id u (contiguous ranges of ids per XCD label, as tile_coords) -> (row range g, column tile t)
+  int u;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+    u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int g = u / a.tiles_n, tn = u - g * a.tiles_n;
+  const int n0 = tn * 256;
+  const int p_lo = (int)((int64_t)g * pairs / groups), p_hi = (int)((int64_t)(g + 1) * pairs / groups);
+  const int len = p_hi - p_lo;                              // >= 4 (launcher)
+  const int n_tiles = (len + TM - 1) / TM, nb_base = len / n_tiles, nb_rem = len - nb_base * n_tiles;
+  // tile k of the range: nb = nb_base + (k < nb_rem) pairs, the taller tiles first (the last tile's epilogue is the exposed one)
+  auto tile_nb = [&](int k) { return nb_base + (k < nb_rem ? 1 : 0); };
+  auto tile_m0 = [&](int k) { return (p_lo + k * nb_base + (k < nb_rem ? k : nb_rem)) * 32; };
 
-  const int srow = tid >> 2;
-  const int schunk = (tid & 3) ^ ring_swz(srow);
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int xoff[R::XI], woff[R::WI];
-#pragma unroll
-  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
-#pragma unroll
-  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
-  const int lds_wave_off = wave * 1024;
-  auto stage = [&](int kt) {
-    char* xs = smem + (kt & 3) * R::STAGE + lds_wave_off;
-    char* ws = xs + R::XB;
-    const int k0 = kt * R::BKR * 2;
-#pragma unroll
-    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
-#pragma unroll
-    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
+  // ---- staging: wave w, piece p covers rows 64 p + 8 w .. + 7 of an operand's stage image (1 KiB), XOR swizzle on the source
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
+  const int xstep = 64 * (int)a.lda * 2, wstep = 64 * (int)a.ldw * 2;
+  auto row_off = [](int base, int add) {
+    int r;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+    return r;
+  };
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);   // rows >= N read as zero
+  auto x_piece = [&](auto p_tag, const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf, int kt) {
+    constexpr int P = decltype(p_tag)::value;
+    if (64 * P + wave * 8 < 32 * nbx)   // uniform: rows of this tile only
+      CLIPMI_BUFFER_LOAD_LDS16(xrs, smem + buf * R::STAGE + P * 8192 + wave * 1024, row_off(xoff0, P * xstep), kt * BK * 2);
+  };
+  auto w_piece = [&](auto p_tag, auto partner_tag, int buf, int kt) {
+    constexpr int P = decltype(p_tag)::value;
+    constexpr int PARTNER = decltype(partner_tag)::value ? 1 : 0;   // the piece of wave + 4: 32 rows further, same chunk swizzle
+    CLIPMI_BUFFER_LOAD_LDS16(wrs, smem + buf * R::STAGE + R::XB + P * 8192 + (wave + 4 * PARTNER) * 1024,
+                             row_off(woff0, P * wstep + PARTNER * (wstep / 2)), kt * BK * 2);
+  };
+  constexpr std::false_type own{};
+  constexpr std::true_type partner{};
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  auto stage_all = [&](const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf) {   // a tile's first stage: every wave its own eight pieces
+    x_piece(I0{}, xrs, nbx, buf, 0); x_piece(I1{}, xrs, nbx, buf, 0); x_piece(I2{}, xrs, nbx, buf, 0); x_piece(I3{}, xrs, nbx, buf, 0);
+    w_piece(I0{}, own, buf, 0); w_piece(I1{}, own, buf, 0); w_piece(I2{}, own, buf, 0); w_piece(I3{}, own, buf, 0);
   };
 
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
-  const char* xrd = smem + wave_m * T::WTM * 64 + foff;
-  const char* wrd = smem + R::XB + wave_n * T::WTN * 64 + foff;
+  // ---- fragment read offsets
+  const int swz = (r16 >> 1) & 7;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t f0 = (uint32_t)(r16 * 128 + (((0 + g4) ^ swz) << 4)), f1 = (uint32_t)(r16 * 128 + (((4 + g4) ^ swz) << 4));
+  const uint32_t wb = (uint32_t)(R::XB + wave_n * 64 * 128);
 
-  f32x4 acc[4][8];
+  // ---- slots: store / load layout of a 16 x 64 slice (see gemm_stream_kernel: v_permlane16_swap on block pairs -> 8 consecutive
+  // columns per lane, two 16-byte accesses per slice).  voffset = lane part + scalar part; out-of-range = dropped / zero.
+  half_t* x16 = a.x16;
+  const int lcol = (g4 & 1) * 16 + (g4 >> 1) * 8;
+  const int st_lane = (r16 * (int)a.ldo + lcol) * 2;
+  const int slice_bytes = 16 * (int)a.ldo * 2;
+  const bool col_ok[2] = {n0 + wave_n * 64 + lcol < a.N, n0 + wave_n * 64 + lcol + 32 < a.N};
+  auto slot_voff = [&](int nbx, int j, int pp) {   // rows 16 j .. of this wave's part (which starts at row wave_m * 16 nbx) of a tile of nbx pairs
+    const int in_range = row_off(st_lane, (wave_m * 16 * nbx * (int)a.ldo + wave_n * 64) * 2 + j * slice_bytes + pp * 64);
+    return (j < nbx && col_ok[pp]) ? in_range : (int)0xFFFFFFF0;
+  };
+  auto tile_rsrc = [&](int m0x) { return make_rsrc(x16 + (int64_t)m0x * a.ldo + n0, ((int64_t)(a.M - m0x) * a.ldo - n0) * 2); };
+  auto pack_slice = [&](const f16x4 (&v)[TN], u32x4 (&o)[2]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / R::BKR;   // even (K % 64 == 0)
-  f16x8 xa[4], xb[4], w0[4], w1[4];
-
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  if (nk > 2) wait_vmcnt<2 * R::G>();
-  else if (nk > 1) wait_vmcnt<R::G>();
-  else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const f16x8*>(xrd + j * 1024);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w0[i] = *reinterpret_cast<const f16x8*>(wrd + i * 1024);
-
-  // FULL = true: steady state (stages kt+1..kt+3 all exist) -> straight-line code, so that hipcc's waitcnt pass
-  // can count the LDS reads instead of draining them at every basic-block merge.
-  auto step = [&](auto full_tag, int kt, f16x8 (&wc)[4], f16x8 (&wn)[4]) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const int so = (kt & 3) * R::STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xb[j] = *reinterpret_cast<const f16x8*>(xrd + so + (4 + j) * 1024);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], xa[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (FULL || kt + 1 < nk) {
-      if (FULL || kt + 2 < nk) wait_vmcnt<R::G>();   // stage kt+2 may stay in flight
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();          // stage kt+1 visible; nobody still reads slot (kt+3)&3
-      if (FULL || kt + 3 < nk) stage(kt + 3);
-      const int sn = ((kt + 1) & 3) * R::STAGE;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const f16x8*>(xrd + sn + j * 1024);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const f16x8*>(wrd + sn + i * 1024);
+    for (int p = 0; p < 2; ++p) {
+      const u32x2 lo = __builtin_bit_cast(u32x2, v[2 * p]), hi = __builtin_bit_cast(u32x2, v[2 * p + 1]);
+      const auto r0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+      o[p] = u32x4{r0[0], r1[0], r0[1], r1[1]};
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+  };
+  auto unpack_slice = [&](const u32x4 (&o)[2], f16x4 (&v)[TN]) {   // the swap is its own inverse
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], xb[j], acc[i][4 + j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int p = 0; p < 2; ++p) {
+      const auto r0 = __builtin_amdgcn_permlane16_swap(o[p][0], o[p][2], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(o[p][1], o[p][3], false, false);
+      v[2 * p] = __builtin_bit_cast(f16x4, u32x2{r0[0], r1[0]});
+      v[2 * p + 1] = __builtin_bit_cast(f16x4, u32x2{r0[1], r1[1]});
+    }
   };
 
-  int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {   // both steps of the pair are in steady state
-    step(std::true_type{}, kt, w0, w1);
-    step(std::true_type{}, kt + 1, w1, w0);
+  // ---- first tile: bias of this unit's 256 columns (once), stage 0
+  int kt_tile = 0;
+  int m0 = tile_m0(0), nb = tile_nb(0);
+  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  __amdgpu_buffer_rsrc_t rrs = tile_rsrc(m0);      // residual of the current tile
+  __amdgpu_buffer_rsrc_t ors = make_rsrc(x16, 0);   // outputs of the previous tile: none yet (zero bytes: every store is dropped)
+  int nb_prev = 0;
+  int first_buf = 0;
+  if (wave == 0) {
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(a.bias + n0, (int64_t)(a.N - n0) * 4);
+    CLIPMI_BUFFER_LOAD_LDS16(brs, smem + R::BIAS_OFF, lane * 16, 0);
   }
-  for (; kt < nk; kt += 2) {
-    step(std::false_type{}, kt, w0, w1);
-    step(std::false_type{}, kt + 1, w1, w0);
-  }
-  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
-}
+  stage_all(xrs, nb, 0);
 
-template <int EPI, bool OUT_F32>
-int launch_pipe(KArgs k, hipStream_t s) {
-  using T = TPipe;
-  using R = Ring<T, 4>;
-  static DeviceOnce attr_once;
-  auto fn = gemm_pipe_kernel<EPI, OUT_F32>;
-  ensure_dynamic_lds(fn, R::SMEM, attr_once);
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
-  k.tiles_n = (k.N + T::BN - 1) / T::BN;
-  k.band = pick_band(k.tiles_n, T::BN, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
-  return check_launch("gemm_pipe_kernel");
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Wide-wave variant: 256 x 256 tile, FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers each).  The
-// 16-wave kernel reads every operand element from LDS four times (4 x 4 wave grid); at 128 B/clk/CU that LDS traffic
-// takes as long as the MFMAs themselves, so its main loop tops out near 60 % of the matrix peak.  A 2 x 2 wave grid
-// halves the LDS bytes per flop.  With a single wave per SIMD nothing else hides latency, so the wave pipelines
-// itself: BK = 32 stages in a 4-slot LDS ring, DMA issued three stages ahead (counted vmcnt), and the MFMA fragments
-// of stage kt+1 are read from LDS into a second register set while the 64 MFMAs of stage kt execute.
-// Per iteration kt:  wait(stage kt+1 landed) ; barrier ; DMA stage kt+3 -> slot of stage kt-1 (its fragment reads
-// completed before any wave left iteration kt-1) ; ds_read fragments kt+1 ; MFMAs on fragments kt.
-// MEASURED (tools/gemm_ksweep.py, profiles/r01_gemm_wide.txt): 7-12 % SLOWER than the 16-wave kernel, in slope (main loop)
-// and intercept (a lone wave per SIMD stores its 128 x 128 outputs with nothing to overlap) alike -- the 16-wave loop is
-// bound by the latency of the one-stage-ahead L2->LDS DMA, not by LDS bandwidth.  Variants that move the fragment reads
-// into the MFMA stream make hipcc shuffle accumulators between AGPRs and VGPRs (400+ v_accvgpr moves per iteration).
-// Kept as CLIPMI_GEMM_VARIANT=c (parity-tested), never chosen by the cost model.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(T::NT, 1) void gemm_wide_kernel(const KArgs a) {
-  using R = Ring<T, 4>;
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
-
-  int tile_m, tile_n;
-  tile_coords(a, (a.M + T::BM - 1) / T::BM, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int srow = tid >> 2;
-  const int schunk = (tid & 3) ^ ring_swz(srow);
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int xoff[R::XI], woff[R::WI];
+  u32x4 held[2][TM];
 #pragma unroll
-  for (int i = 0; i < R::XI; ++i) xoff[i] = ((i * (NT / 4) + srow) * (int)a.lda + schunk * 8) * 2;
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-  for (int i = 0; i < R::WI; ++i) woff[i] = ((i * (NT / 4) + srow) * (int)a.ldw + schunk * 8) * 2;
-  const int lds_wave_off = wave * 1024;
-  auto stage = [&](int kt) {
-    char* xs = smem + (kt & 3) * R::STAGE + lds_wave_off;
-    char* ws = xs + R::XB;
-    const int k0 = kt * R::BKR * 2;
-#pragma unroll
-    for (int i = 0; i < R::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), xoff[i], k0);
-#pragma unroll
-    for (int i = 0; i < R::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), woff[i], k0);
-  };
-
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int foff = r16 * 64 + ((g4 ^ ring_swz(r16)) << 4);
-  const int xbase = wave_m * T::WTM * 64 + foff;
-  const int wbase = R::XB + wave_n * T::WTN * 64 + foff;
-
+    for (int j = 0; j < TM; ++j) held[p][j] = u32x4{0u, 0u, 0u, 0u};
   f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f16x8 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+#ifdef CLIPMI_TUNING
+  // part timers (diagnostic build): lane 0 of waves 0 and 4 sums, over a tile's K loop, the shader-clock time of: issuing its load part |
+  // the LDS wait | the vmcnt wait | the barrier behind the load part | its compute part | the vmcnt wait behind it | the barrier behind
+  // that; written to stamps[(4096 + 4 u + tile) * 8 ..] (group 0) / stamps[(6144 + 4 u + tile) * 8 ..] (group 1)
+  long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
+  const bool timer = a.stamps != nullptr && lane == 0 && (wave & 3) == 0;
+#define RS_T() (timer ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
+#else
+#define RS_T() 0ll
+#endif
 
-  // Fragment reads of stage kt+1 are issued in two halves INSIDE the MFMA stream of stage kt (after the first 8 and after
-  // the first 32 MFMAs).  The LDS counter is 4 bits on gfx9, so "16 reads in flight while waiting for the 16 before them"
-  // cannot be expressed; instead every wait the compiler needs is an lgkmcnt(0) that falls in front of the first MFMA
-  // of a step, when the newest outstanding read was issued 32 MFMAs (~500 cycles) earlier.
-  auto read_x = [&](int kt, f16x8 (&xf)[TM]) {
-    const char* st = smem + (kt & 3) * R::STAGE;
+  auto kstep = [&](auto slot_tag, auto first_tag, auto more_tag, int kt) {
+    constexpr int SLOT = decltype(slot_tag)::value;       // >= 0: this K-step carries slot SLOT (previous tile's outputs out, this tile's residual in)
+    constexpr bool FIRSTK = decltype(first_tag)::value;   // the accumulators start at 0
+    constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
+    constexpr int NOPS = SLOT >= 0 ? 4 : 0;               // VMEM operations issued behind the pieces
+    static_assert(SLOT < 0 || MORE, "slots ride on K-steps that prefetch");
+    const int buf = (first_buf + kt) & 1;
+    const uint32_t sb = lds_base + (uint32_t)(buf * R::STAGE);
+    const uint32_t xbase = sb + (uint32_t)(wave_m * nb * 16 * 128);
+    const uint32_t xa0 = xbase + f0, xa1 = xbase + f1, wa0 = sb + wb + f0, wa1 = sb + wb + f1;
+    f16x8 wf[4], xw[TM];
+    auto phase = [&](auto ks_tag) {
+      constexpr int KS = decltype(ks_tag)::value;
+      // ---- load part
+      [[maybe_unused]] const long long t0 = RS_T();
+      {
+        const uint32_t xa = KS ? xa1 : xa0, wa = KS ? wa1 : wa0;
+        ds_read128<0>(wf[0], wa); ds_read128<2048>(wf[1], wa); ds_read128<4096>(wf[2], wa); ds_read128<6144>(wf[3], wa);
+        ds_read128<0 * 2048>(xw[0], xa); ds_read128<1 * 2048>(xw[1], xa); ds_read128<2 * 2048>(xw[2], xa); ds_read128<3 * 2048>(xw[3], xa);
+        if (nb > 4) ds_read128<4 * 2048>(xw[4], xa);
+        if (nb > 5) ds_read128<5 * 2048>(xw[5], xa);
+        if (nb > 6) ds_read128<6 * 2048>(xw[6], xa);
+      }
+      if constexpr (MORE) {
+        if constexpr (KS == 0) {
+          x_piece(I0{}, xrs, nb, buf ^ 1, kt + 1); x_piece(I1{}, xrs, nb, buf ^ 1, kt + 1);
+          x_piece(I2{}, xrs, nb, buf ^ 1, kt + 1); x_piece(I3{}, xrs, nb, buf ^ 1, kt + 1);
+          w_piece(I0{}, own, buf ^ 1, kt + 1); w_piece(I1{}, own, buf ^ 1, kt + 1);
+        } else if (grp == 0) {
+          w_piece(I2{}, own, buf ^ 1, kt + 1); w_piece(I3{}, own, buf ^ 1, kt + 1);
+          w_piece(I2{}, partner, buf ^ 1, kt + 1); w_piece(I3{}, partner, buf ^ 1, kt + 1);
+        }
+      }
+      if constexpr (KS == 1 && SLOT >= 0) {
+        __builtin_amdgcn_raw_buffer_store_b128(held[0][SLOT], ors, slot_voff(nb_prev, SLOT, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(held[1][SLOT], ors, slot_voff(nb_prev, SLOT, 1), 0, 0);
+        held[0][SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slot_voff(nb, SLOT, 0), 0, 0);
+        held[1][SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slot_voff(nb, SLOT, 1), 0, 0);
+      }
+      [[maybe_unused]] const long long t0b = RS_T();
+      rs_wait_reads(wf, xw);
+      [[maybe_unused]] const long long t0c = RS_T();
+      if constexpr (KS == 1) {
+        if (grp == 1) wait_vmcnt<NOPS>();   // this wave's pieces of the next stage (issued in its ks 0 load part) have landed
+      }
+      [[maybe_unused]] const long long t1 = RS_T();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      [[maybe_unused]] const long long t2 = RS_T();
+      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 1024);
-  };
-  auto read_w = [&](int kt, f16x8 (&wf)[TN]) {
-    const char* st = smem + (kt & 3) * R::STAGE;
+      for (int j = 0; j < TM; ++j) {
+        if (j < 4 || j < nb) {   // uniform: blocks 0..3 always exist
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 1024);
-  };
-  auto mfma_rows = [&](int i0, int i1, const f16x8 (&xf)[TM], const f16x8 (&wf)[TN]) {
-#pragma unroll
-    for (int i = i0; i < i1; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-  };
-  // one pipeline step: fragments of stage kt are in (xc, wc); (xn, wn) receive stage kt+1.  FULL = steady state
-  // (stages kt+1 .. kt+3 all exist), otherwise the same sequence with its guards.
-  auto step = [&](auto full, int kt, int nk, const f16x8 (&xc)[TM], const f16x8 (&wc)[TN], f16x8 (&xn)[TM], f16x8 (&wn)[TN]) {
-    constexpr bool FULL = decltype(full)::value;
-    const bool next = FULL || kt + 1 < nk;
-    if (next) {
-      if (FULL || kt + 2 < nk) wait_vmcnt<R::G>();   // stage kt+2 may stay in flight
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                  // stage kt+1 visible; every wave is past the MFMAs of stage kt-1
-      if (FULL || kt + 3 < nk) stage(kt + 3);
-    }
-    if (next) {
-      read_x(kt + 1, xn);
-      read_w(kt + 1, wn);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_rows(0, TN, xc, wc);
-    __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < TN; ++i) {
+            if constexpr (FIRSTK && KS == 0)
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
+            else
+              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      [[maybe_unused]] const long long t3 = RS_T();
+      if constexpr (KS == 1) {
+        if (grp == 0) wait_vmcnt<NOPS>();
+      }
+      [[maybe_unused]] const long long t3b = RS_T();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef CLIPMI_TUNING
+      if (timer) {
+        const long long t4 = (long long)__builtin_amdgcn_s_memtime();
+        tm[0] += t0b - t0; tm[1] += t0c - t0b; tm[2] += t1 - t0c; tm[3] += t2 - t1; tm[4] += t3 - t2; tm[5] += t3b - t3; tm[6] += t4 - t3b;
+      }
+#endif
+    };
+    phase(I0{});
+    phase(I1{});
   };
 
-  const int nk = a.K / R::BKR;   // even: K is a multiple of 64
-  stage(0);
-  stage(1);
-  if (2 < nk) stage(2);
-  if (2 < nk) wait_vmcnt<2 * R::G>();
-  else wait_vmcnt<R::G>();
+#ifdef CLIPMI_TUNING
+  const bool stamp = a.stamps != nullptr && tid == 0;
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first tile's stage 0 and the bias
   __builtin_amdgcn_s_barrier();
-  read_x(0, xf0);
-  read_w(0, wf0);
-  int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {   // steady state: no branches inside
-    step(std::true_type{}, kt, nk, xf0, wf0, xf1, wf1);
-    step(std::true_type{}, kt + 1, nk, xf1, wf1, xf0, wf0);
+  while (true) {
+#ifdef CLIPMI_TUNING
+    long long* sp = a.stamps + ((size_t)u * 4 + (kt_tile < 3 ? kt_tile : 3)) * 8;
+    if (stamp) { sp[0] = (long long)__builtin_amdgcn_s_memrealtime(); sp[5] = (long long)blockIdx.x; }
+#endif
+    constexpr std::false_type no{};
+    constexpr std::true_type yes{};
+    using NS = std::integral_constant<int, -1>;
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 start one part later
+    kstep(std::integral_constant<int, 0>{}, yes, yes, 0);
+#ifdef CLIPMI_TUNING
+    if (stamp) { sp[1] = (long long)__builtin_amdgcn_s_memrealtime(); sp[6] = (long long)__builtin_amdgcn_s_memtime(); }
+#endif
+    kstep(std::integral_constant<int, 1>{}, no, yes, 1);
+    kstep(std::integral_constant<int, 2>{}, no, yes, 2);
+    kstep(std::integral_constant<int, 3>{}, no, yes, 3);
+    kstep(std::integral_constant<int, 4>{}, no, yes, 4);
+    kstep(std::integral_constant<int, 5>{}, no, yes, 5);
+    kstep(std::integral_constant<int, 6>{}, no, yes, 6);
+    for (int kt = 7; kt < nk - 1; ++kt) kstep(NS{}, no, yes, kt);   // nk >= 8 (launcher)
+    kstep(NS{}, no, no, nk - 1);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+#ifdef CLIPMI_TUNING
+    if (stamp) { sp[2] = (long long)__builtin_amdgcn_s_memrealtime(); sp[7] = (long long)__builtin_amdgcn_s_memtime(); }
+    if (timer) {
+      long long* tp = a.stamps + ((size_t)(grp ? 6144 : 4096) + (size_t)u * 4 + (kt_tile < 3 ? kt_tile : 3)) * 8;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { tp[i] = tm[i]; tm[i] = 0; }
+      tp[7] = nb;
+    }
+#endif
+
+    // ---- tile end.  Every residual slice of this tile sits in its slot (loaded in K-steps 0..6, covered by the counted wait of
+    // the K-step after); nothing of the next tile has been issued yet.
+    const int last_buf = (first_buf + nk - 1) & 1;
+    const int cm0 = m0, cnb = nb;
+    const bool has_next = kt_tile + 1 < n_tiles;
+    int m0n = m0, nbn = nb;
+    __amdgpu_buffer_rsrc_t xrs_n = xrs;
+    if (has_next) {
+      m0n = tile_m0(kt_tile + 1);
+      nbn = tile_nb(kt_tile + 1);
+      xrs_n = make_rsrc(a.A + (int64_t)m0n * a.lda, ((int64_t)(a.M - m0n) * a.lda) * 2);
+      first_buf = last_buf ^ 1;   // the buffer that was NOT read last is free
+    }
+    {
+      // every slot's residual landed K-steps ago; telling the compiler so HERE (it tracks the loads, not the counted waits) keeps its
+      // own vmcnt out of the slice loop below, where it would wait for the next tile's pieces
+      asm volatile("" : "+v"(held[0][0]), "+v"(held[0][1]), "+v"(held[0][2]), "+v"(held[0][3]), "+v"(held[0][4]), "+v"(held[0][5]), "+v"(held[0][6]),
+                        "+v"(held[1][0]), "+v"(held[1][1]), "+v"(held[1][2]), "+v"(held[1][3]), "+v"(held[1][4]), "+v"(held[1][5]), "+v"(held[1][6]));
+      // bias of this lane's columns: pinned LDS reads (the compiler would put a vmcnt(0) in front of an ordinary one)
+      f32x4 bb[TN];
+      const uint32_t ba = lds_base + (uint32_t)(R::BIAS_OFF + (wave_n * 64 + g4 * 4) * 4);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba));
+      const uint32_t red_lane = lds_base + (uint32_t)(R::RED_OFF + (wave_n * 32 * TM + wave_m * 16 * cnb + r16) * 8);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        if (j < cnb) {   // uniform
+          u32x4 hv[2] = {held[0][j], held[1][j]};
+          f16x4 res[TN];
+          unpack_slice(hv, res);
+          f16x4 cv[TN];
+          float rsum = 0.f, rsq = 0.f;
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            f32x4 v = acc[i][j] + bb[i] + f32x4{(float)res[i][0], (float)res[i][1], (float)res[i][2], (float)res[i][3]};
+            cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            v = f32x4{(float)cv[i][0], (float)cv[i][1], (float)cv[i][2], (float)cv[i][3]};   // the partials are those of the ROUNDED row
+            fold_row_sums(v, rsum, rsq);
+          }
+          rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
+          rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+          if (g4 == 0) {
+            const float2 pr = make_float2(rsum, rsq);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(red_lane + (uint32_t)(j * 128)), "v"(pr) : "memory");   // row 16 j + r16 of this wave's part
+          }
+          pack_slice(cv, hv);
+          held[0][j] = hv[0];
+          held[1][j] = hv[1];
+        }
+        if (has_next) {   // the next tile's first stage, two pieces behind each of the first four slices
+          if (j == 0) { x_piece(I0{}, xrs_n, nbn, first_buf, 0); x_piece(I1{}, xrs_n, nbn, first_buf, 0); }
+          if (j == 1) { x_piece(I2{}, xrs_n, nbn, first_buf, 0); x_piece(I3{}, xrs_n, nbn, first_buf, 0); }
+          if (j == 2) { w_piece(I0{}, own, first_buf, 0); w_piece(I1{}, own, first_buf, 0); }
+          if (j == 3) { w_piece(I2{}, own, first_buf, 0); w_piece(I3{}, own, first_buf, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one slice at a time: the accumulators die as they are converted
+      }
+    }
+    ors = rrs;   // this tile's slots leave through its own descriptor during the next K loop (or behind the loop)
+    nb_prev = cnb;
+#ifdef CLIPMI_TUNING
+    if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile's stage 0; this wave's row partials are in LDS
+    __builtin_amdgcn_s_barrier();
+#ifdef CLIPMI_TUNING
+    if (stamp) sp[4] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- row partials of the finished tile: thread t owns row t, adds the four column waves in order (as the tile kernels do)
+    if (tid < 32 * cnb) {
+      const int m = cm0 + tid;
+      if (m < a.M) {
+        const float2* red = reinterpret_cast<const float2*>(smem + R::RED_OFF);
+        float sx = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float2 pr = red[w * 32 * TM + tid];
+          sx += pr.x;
+          sq += pr.y;
+        }
+        *reinterpret_cast<float2*>(a.stats_out + 2 * ((int64_t)tn * a.M + m)) = make_float2(sx, sq);
+      }
+    }
+    if (!has_next) break;
+    ++kt_tile;
+    m0 = m0n;
+    nb = nbn;
+    xrs = xrs_n;
+    rrs = tile_rsrc(m0);
   }
-  for (; kt < nk; kt += 2) {       // at most four general steps
-    step(std::false_type{}, kt, nk, xf0, wf0, xf1, wf1);
-    step(std::false_type{}, kt + 1, nk, xf1, wf1, xf0, wf0);
+  // the last tile's slots: nothing left to hide them behind
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    __builtin_amdgcn_raw_buffer_store_b128(held[0][j], ors, slot_voff(nb_prev, j, 0), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(held[1][j], ors, slot_voff(nb_prev, j, 1), 0, 0);
   }
-  epilogue<T, EPI, OUT_F32>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem);
 }
 
-template <typename T, int EPI, bool OUT_F32>
-int launch_wide(KArgs k, hipStream_t s) {
-  using R = Ring<T, 4>;
+#undef RS_T
+
+// the row-range kernel takes a shape when every range holds at least two tiles' worth of pairs (below that nothing is streamed:
+// the one-tile-per-workgroup kernel is the better fit) -- or, forced (gemm_variant = 16), at least one tile of four pairs
+inline bool rstream_fits(const KArgs& k, bool forced) {
+  const int n_cu = device_cus() & ~7;
+  const int tiles_n = (k.N + 255) / 256;
+  if (n_cu < 8 || tiles_n > n_cu || tiles_n > LN_MAX_PARTS) return false;
+  const int groups = n_cu / tiles_n;
+  const int64_t pairs = ((int64_t)k.M + 31) / 32;
+  if (!(k.K >= 8 * BK && (k.N & 7) == 0 && (k.ldo & 7) == 0 && stream_offsets_ok(k))) return false;
+  return pairs >= (forced ? 4 : 8) * (int64_t)groups;
+}
+
+int launch_rstream(KArgs k, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = gemm_wide_kernel<T, EPI, OUT_F32>;
-  ensure_dynamic_lds(fn, R::SMEM, attr_once);
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
-  k.tiles_n = (k.N + T::BN - 1) / T::BN;
-  k.band = pick_band(k.tiles_n, T::BN, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), R::SMEM, s, k);
-  return check_launch("gemm_wide_kernel");
+  ensure_dynamic_lds(gemm_rstream_kernel, RStream::SMEM, attr_once);
+  const int n_cu = device_cus() & ~7;
+  k.tiles_n = (k.N + 255) / 256;
+  const int groups = n_cu / k.tiles_n;
+  const int pairs = (int)(((int64_t)k.M + 31) / 32);
+  k.nwg = groups * k.tiles_n;
+  k.band = k.tiles_n;
+  hipLaunchKernelGGL(gemm_rstream_kernel, dim3(k.nwg), dim3(RStream::NT), RStream::SMEM, s, k, groups, pairs);
+  return check_launch("gemm_rstream_kernel");
 }
 
 using T128 = Tile<128, 128, 2, 2, 2>;      // 4 waves of 64x64, 64 KiB LDS, 2 workgroups / CU
 using T256w16 = Tile<256, 256, 4, 4, 4>;   // 16 waves of 64x64, 128 KiB LDS, 1 workgroup / CU, 4 waves / SIMD
-using T256w8 = Tile<256, 256, 2, 4, 2>;    // 8 waves of 128x64
-using T320w8 = Tile<320, 256, 2, 4, 2>;     // 8 waves of 160x64: 474 tiles at M=50432, N=768 (1.85 rounds instead of 2.31)
-using T256x128 = Tile<256, 128, 4, 2, 2>;  // 8 waves of 64x64, 96 KiB LDS
-using T128x256o4 = Tile<128, 256, 2, 4, 4>;  // 8 waves of 64x64, <=128 VGPRs so two workgroups share a CU
-using T256x128o4 = Tile<256, 128, 4, 2, 4>;
-using T256w4 = Tile<256, 256, 2, 2, 1>;    // 4 waves of 128x128 (gemm_wide_kernel)
+using T256w8 = Tile<256, 256, 2, 4, 2>;    // 8 waves of 128x64 (the implicit-GEMM convolution)
+using T320w8 = Tile<320, 256, 2, 4, 2>;    // 8 waves of 160x64: 474 tiles at M=50432, N=768 (1.85 rounds instead of 2.31)
 
-// Tile choice.  CLIPMI_GEMM_VARIANT = 0..9, a forces a configuration (tuning / test aid; every one is parity-tested).
-// Default: minimise a cost model  rounds x tile area x workgroups-per-CU x penalty  over the three configurations that
-// won the interleaved A/B runs on MI355X (tools/gemm_ab.py, profiles/r01_gemm_ab.txt):
-//   1  256 x 256, 16 waves of 64 x 64   half the L2->LDS bytes per flop of the 128^2 tile; best whenever its tile
-//                                        count fills the CUs evenly (qkv 1034 TF, fc 908 TF at M = 50432)
-//   a  320 x 256,  8 waves of 160 x 64  for tile counts that quantise badly at 256 rows: N = 768 at M = 50432 is
-//                                        591 tiles = 2.31 rounds with (1) but 474 = 1.85 rounds here (proj 917 vs 760 TF)
-//   0  128 x 128,  4 waves, 2 WG / CU   small problems (final projections, tiny batches)
+// Tile choice among the one-tile-per-workgroup kernels: minimise  rounds x tile area x workgroups-per-CU x penalty  over the three
+// configurations that won the interleaved A/B runs on MI355X (tools/gemm_ab.py, profiles/r01_gemm_ab.txt):
+//   1   256 x 256, 16 waves of 64 x 64   half the L2->LDS bytes per flop of the 128^2 tile; best whenever its tile count fills
+//                                         the CUs evenly
+//   10  320 x 256,  8 waves of 160 x 64  ping-pong main loop (gemm_pp_kernel); for tile counts that quantise badly at 256 rows:
+//                                         N = 768 at M = 50432 is 591 tiles = 2.31 rounds with (1) but 474 = 1.85 rounds here
+//   0   128 x 128,  4 waves, 2 WG / CU   small problems (final projections, tiny batches)
 // rounds = ceil(tiles / (CUs x workgroups per CU)); penalties are the measured per-flop slowdowns relative to (1).
+// The two persistent kernels sit on top of this choice (launch_one): 13 = gemm_stream_kernel (fp16-out epilogues), 16 =
+// gemm_rstream_kernel (fp16-stream residual epilogue).  Option gemm_variant (CLIPMI_GEMM_VARIANT) forces one of {0, 1, 10, 13, 16}
+// where the shape allows it -- a test aid: the records of the kernel families that were measured and removed (ring, register
+// pipeline, persistent 16-wave, deferred stores, 128 x 128 wave tiles) are profiles/r01_gemm_variants.txt and r02_*_ab.txt.
 int pick_variant(const KArgs& k) {
   const int forced = options().gemm_variant.load(std::memory_order_relaxed);   // -1 unless a test / tuning run forces one
-  if (forced >= 0) return forced;
+  if (forced == 0 || forced == 1 || forced == 13 || forced == 16) return forced;
+  if (forced == 10) return k.K >= 2 * BK ? 10 : 1;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
   int best = 1;
   double best_cost = 1e300;
   for (const Cand& c : cands) {
+    if (c.id == 10 && k.K < 2 * BK) continue;   // the ping-pong loop needs two K-steps
     const int64_t tiles = (int64_t)((k.M + c.bm - 1) / c.bm) * ((k.N + c.bn - 1) / c.bn);
     const int64_t slots = (int64_t)cus * c.per_cu;
     const int64_t rounds = (tiles + slots - 1) / slots;
@@ -2516,10 +1926,6 @@ int pick_variant(const KArgs& k) {
     if (c.id == 10 && k.K <= 512) cost *= 0.93;
     if (cost < best_cost) { best_cost = cost; best = c.id; }
   }
-  // CLIPMI_GEMM_PERSIST=1: use the persistent form of (1) (variant b: next tile's first stage prefetched before the
-  // epilogue, no workgroup relaunch gap) for multi-round problems.  Isolated A/B: +4.5 % on qkv, neutral on fc; inside the
-  // tower it measures 1 % slower (20.33 vs 20.55 k img/s, three alternating runs), so it stays opt-in.
-  if (best == 1 && options().gemm_persist.load(std::memory_order_relaxed) == 1 && (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)cus) best = 11;
   return best;
 }
 
@@ -2642,79 +2048,51 @@ int launch_conv_tile(KArgs k, const ConvArgs& cv, hipStream_t s) {
   return check_launch("gemm_conv3x3_kernel");
 }
 
-// the convolution epilogues (ModifiedResNet, SURVEY f-4) only come in the three cost-model configurations
-template <int EPI, bool OUT_F32>
-int launch_basic(const KArgs& k, hipStream_t s) {
-  switch (pick_variant(k)) {
-    case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
-      if (options().gemm_pp.load(std::memory_order_relaxed) == 2 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32, true>(k, s);   // two wide phases per K-step
-      if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
-      return launch_tile<T320w8, EPI, OUT_F32>(k, s);
+template <typename Tl, int EPI, bool OUT_F32>
+int launch_by_variant(int variant, const KArgs& k, hipStream_t s) {
+  switch (variant) {
+    case 10: return launch_pp<T320w8, EPI, OUT_F32>(k, s);
     case 0: return launch_tile<T128, EPI, OUT_F32>(k, s);
     default: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
   }
 }
 
+// the convolution epilogues (ModifiedResNet, SURVEY f-4) only come in the three cost-model configurations
+template <int EPI, bool OUT_F32>
+int launch_basic(const KArgs& k, hipStream_t s) {
+  int variant = pick_variant(k);
+  if (variant == 13 || variant == 16) variant = 1;
+  return launch_by_variant<void, EPI, OUT_F32>(variant, k, s);
+}
+
 template <int EPI, bool OUT_F32>
 int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = nullptr) {
   int variant = pick_variant(k);
-  // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 9 K-steps: the streamed-epilogue persistent kernel
-  // (the cost model above only ranks the one-tile-per-workgroup kernels)
-  if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-    const int pm = options().gemm_persist.load(std::memory_order_relaxed);
-    if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && pm >= 2 && (k.N & 7) == 0 && (k.ldo & 7) == 0 &&
-        (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
-      variant = pm == 3 ? 9 : 11;   // persistent tiles with DMA'd parameters: 2 = 16 waves, 3 = 8 waves
-  }
+  const bool forced = options().gemm_variant.load(std::memory_order_relaxed) >= 0;
+  // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 8 K-steps: the streamed-epilogue persistent kernel
+  // (the cost model only ranks the one-tile-per-workgroup kernels)
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-    if (options().gemm_variant.load(std::memory_order_relaxed) < 0 && options().gemm_stream.load(std::memory_order_relaxed) == 1 &&
-        (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
-        (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus())
-      variant = 13;
+    const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
+                      stream_offsets_ok(k);
+    const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
+    if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) return launch_stream<EPI>(k, ln_rows, s);
   }
-  if (k.x16) {   // producer fold: needs the non-persistent epilogue and at most LN_MAX_PARTS column tiles
-    if (variant == 9) variant = 2;
-    if (variant == 11 || variant == 12 || variant == 13) variant = 1;
-    const int bn = (variant == 0) ? 128 : (variant == 3 || variant == 7) ? 128 : 256;
+  if constexpr (EPI == EPI_RESIDUAL_FOLD16) {
+    // fp16-stream residual GEMMs whose row ranges hold at least two tiles each: the persistent row-range kernel
+    const bool want = variant == 16 || (!forced && options().gemm_rstream.load(std::memory_order_relaxed) == 1);
+    if (want && rstream_fits(k, variant == 16)) {
+      *parts_out = (k.N + 255) / 256;
+      return launch_rstream(k, s);
+    }
+  }
+  if (variant == 13 || variant == 16) variant = 1;
+  if (k.x16) {   // producer fold: one row partial per 256-column tile (128-column tiles: two), at most LN_MAX_PARTS of them
+    const int bn = variant == 0 ? 128 : 256;
     if ((k.N + bn - 1) / bn > LN_MAX_PARTS) variant = 1;
     CLIPMI_REQUIRE((k.N + 255) / 256 <= LN_MAX_PARTS, CLIPMI_ERR_SHAPE, "gemm: N=%d has too many column tiles for the LayerNorm fold", k.N);
-    const int bn2 = (variant == 0 || variant == 3 || variant == 7) ? 128 : 256;
-    *parts_out = (k.N + bn2 - 1) / bn2;
+    *parts_out = (k.N + (variant == 0 ? 128 : 256) - 1) / (variant == 0 ? 128 : 256);
   }
-  switch (variant) {
-    case 1: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
-    case 2: return launch_tile<T256w8, EPI, OUT_F32>(k, s);
-    case 3: return launch_tile<T256x128, EPI, OUT_F32>(k, s);
-    case 4: return launch_ring<T256w16, 4, EPI, OUT_F32>(k, s);
-    case 5: return launch_ring<T256w8, 4, EPI, OUT_F32>(k, s);
-    case 6: return launch_ring<T128x256o4, 3, EPI, OUT_F32>(k, s);   // 72 KiB -> 2 workgroups / CU
-    case 7: return launch_ring<T256x128o4, 3, EPI, OUT_F32>(k, s);
-    case 8: return launch_pipe<EPI, OUT_F32>(k, s);
-    case 9: return launch_persist<T256w8, EPI, OUT_F32>(k, s, ln_rows);
-    case 10:   // 320 x 256: ping-pong main loop (option gemm_pp, default) or the compiler-scheduled two-stage loop
-      if (options().gemm_pp.load(std::memory_order_relaxed) == 2 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32, true>(k, s);   // two wide phases per K-step
-      if (options().gemm_pp.load(std::memory_order_relaxed) == 1 && k.K >= 2 * BK) return launch_pp<T320w8, EPI, OUT_F32>(k, s);
-      return launch_tile<T320w8, EPI, OUT_F32>(k, s);
-    case 11: return launch_persist<T256w16, EPI, OUT_F32>(k, s, ln_rows);
-    case 14:   // 256 x 256, eight waves, ping-pong main loop (A/B aid; the 16-wave two-stage kernel is variant 1)
-      if (k.K >= 2 * BK) return launch_pp<T256w8, EPI, OUT_F32>(k, s);
-      return launch_tile<T256w8, EPI, OUT_F32>(k, s);
-    case 13:   // streamed-epilogue persistent kernel: fp16-out epilogues on 8-column-aligned outputs, K >= 9 K-steps
-      if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-        if ((k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS))
-          return launch_stream<EPI>(k, ln_rows, s);
-      }
-      return launch_tile<T256w16, EPI, OUT_F32>(k, s);
-    case 15:   // deferred-store persistent kernel: fp16-out epilogues on 8-column-aligned outputs only
-      if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-        if ((k.N & 7) == 0 && (k.ldo & 7) == 0) return launch_defer<EPI>(k, s);
-      }
-      return launch_tile<T256w16, EPI, OUT_F32>(k, s);
-    case 12:
-      if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) return launch_tile<T256w16, EPI, OUT_F32>(k, s);   // fold epilogue: 64-column wave tiles only
-      else return launch_wide<T256w4, EPI, OUT_F32>(k, s);
-    default: return launch_tile<T128, EPI, OUT_F32>(k, s);
-  }
+  return launch_by_variant<void, EPI, OUT_F32>(variant, k, s);
 }
 
 }  // namespace
@@ -2750,7 +2128,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   CLIPMI_REQUIRE((!a.x16 && !a.stats_out) || (a.x16 && a.stats_out && a.parts_out && a.epilogue == CLIPMI_EPI_BIAS_RESIDUAL &&
                                               a.N % 8 == 0 && a.ldo % 8 == 0),
                  CLIPMI_ERR_ARG, "gemm: x16/stats_out/parts_out come together, only with BIAS_RESIDUAL and N %% 8 == 0");
-  k.tiles_n = 0; k.nwg = 0; k.mix = 0;
+  k.tiles_n = 0; k.nwg = 0;
 
   switch (a.epilogue) {
     case CLIPMI_EPI_NONE:

@@ -234,6 +234,16 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.device
 
     # ---- weight binding ---------------------------------------------------------------------------------------
+    def _ensure_handle(self):
+        if self._handle is None:
+            g = self.geometry
+            geo = _lib.Geometry(g.embed_dim, g.image_resolution, g.vision_patch_size, g.vision_width, g.vision_layers,
+                                g.context_length, g.vocab_size, g.transformer_width, g.transformer_layers,
+                                g.transformer_heads)
+            h = C.c_void_p()
+            check(lib.clipmi_create(C.byref(geo), C.byref(h)), "clipmi_create")
+            self._handle = h.value
+
     def _ensure_bound(self):
         if self._bound is not None:
             return
@@ -242,13 +252,7 @@ class CLIP(nn.Module):
             raise RuntimeError("clipmi: the model must be on a ROCm GPU before it is run (model.to('cuda')); "
                                "there is no CPU path")
         g = self.geometry
-        if self._handle is None:
-            geo = _lib.Geometry(g.embed_dim, g.image_resolution, g.vision_patch_size, g.vision_width, g.vision_layers,
-                                g.context_length, g.vocab_size, g.transformer_width, g.transformer_layers,
-                                g.transformer_heads)
-            h = C.c_void_p()
-            check(lib.clipmi_create(C.byref(geo), C.byref(h)), "clipmi_create")
-            self._handle = h.value
+        self._ensure_handle()
         keep: List[torch.Tensor] = []
 
         def f16(t):  # GEMM operand: fp16, contiguous (aliases the parameter when it already is)
@@ -302,6 +306,24 @@ class CLIP(nn.Module):
         check(lib.clipmi_set_text_weights(self._handle, C.byref(tw)), "clipmi_set_text_weights")
         self._bound = (keep, vb, tb)
 
+    # ---- per-model settings (include/clipmi.h, clipmi_model_set_option) ------------------------------------------
+    _MODEL_OPTIONS = ("residual_f16", "ln_fold", "cls_only_last_block")
+
+    def set_option(self, name: str, value: int) -> None:
+        """Precision / variant selection of THIS model: the reference picks precision per model (cfg.TRAINER.<X>.PREC,
+        trainers/classification/coop.py:243-245) and builds a second CLIP in the same process (base_learner.py:262-272).
+        -1 = follow the process-wide default again."""
+        if name not in self._MODEL_OPTIONS:
+            raise KeyError(f"unknown model option {name!r}; one of {self._MODEL_OPTIONS}")
+        self._ensure_handle()
+        check(lib.clipmi_model_set_option(self._handle, name.encode(), int(value)), "clipmi_model_set_option")
+
+    def get_option(self, name: str) -> int:
+        self._ensure_handle()
+        v = C.c_int(0)
+        check(lib.clipmi_model_get_option(self._handle, name.encode(), C.byref(v)), "clipmi_model_get_option")
+        return v.value
+
     def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(kind)
         if ws is None or ws.numel() < nbytes or ws.device != self.device:
@@ -326,8 +348,9 @@ class CLIP(nn.Module):
 
     # ---- towers -------------------------------------------------------------------------------------------------
     def image_features_f32(self, image: torch.Tensor, shared_ctx: Optional[torch.Tensor] = None,
-                           deep_prompts: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
-        """VisionTransformer.forward / ModifiedResNet.forward with fp32 output (un-normalised)."""
+                           deep_prompts: Optional[Sequence[torch.Tensor]] = None, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+        """VisionTransformer.forward / ModifiedResNet.forward with fp32 output (un-normalised).  ``flags``: per-call
+        stream precision (``_lib.CALL_STREAM_F32`` / ``_F16``); default = the model's setting."""
         if self.is_resnet:
             if shared_ctx is not None:
                 raise ValueError("prompt tokens apply to the ViT towers only")
@@ -349,14 +372,14 @@ class CLIP(nn.Module):
         nbytes = lib.clipmi_vision_workspace_bytes(self._handle, B, n_ctx)
         ws = self._workspace("vision", nbytes)
         check(lib.clipmi_encode_image(self._handle, image.data_ptr(), _DT[image.dtype], B, hook_ref, out.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), ops._stream()), "clipmi_encode_image")
+                                      ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_encode_image")
         return out
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:
         """clip/model.py:597-598."""
         return self.visual(image.type(self.dtype))
 
-    def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int) -> torch.Tensor:
+    def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
         self._ensure_bound()
         g = self.geometry
         x_lnd = ops._dev(x_lnd, "x", (torch.float16, torch.float32))
@@ -371,12 +394,14 @@ class CLIP(nn.Module):
             hook_ref = C.byref(hook)
         ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
         check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
-                                     ws.numel(), ops._stream()), "clipmi_text_blocks")
+                                     ws.numel(), int(flags), ops._stream()), "clipmi_text_blocks")
         return y.permute(1, 0, 2)
 
     def text_encoder_f32(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor,
-                         deep_prompts: Optional[Sequence[torch.Tensor]] = None, n_ctx: int = 0) -> torch.Tensor:
-        """TextEncoder.forward fused (coop.py:56-67; maple.py:60-74): prompts [C,77,D] (no pos-emb) -> fp32 [C,E]."""
+                         deep_prompts: Optional[Sequence[torch.Tensor]] = None, n_ctx: int = 0,
+                         flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+        """TextEncoder.forward fused (coop.py:56-67; maple.py:60-74): prompts [C,77,D] (no pos-emb) -> fp32 [C,E].
+        ``flags``: per-call stream precision (CoCoOp's per-image passes ask for ``_lib.CALL_STREAM_F16``)."""
         self._ensure_bound()
         g = self.geometry
         prompts = ops._dev(prompts, "prompts", (torch.float16, torch.float32))
@@ -394,22 +419,22 @@ class CLIP(nn.Module):
             hook_ref = C.byref(hook)
         ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
         check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, hook_ref,
-                                      out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "clipmi_text_encoder")
+                                      out.data_ptr(), ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_text_encoder")
         return out
 
-    def text_features_f32(self, text: torch.Tensor) -> torch.Tensor:
+    def text_features_f32(self, text: torch.Tensor, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
         self._ensure_bound()
         g = self.geometry
         text = ops._dev(text, "text", (torch.int64,))
         if text.dim() != 2 or text.shape[1] != g.context_length:
             raise ValueError(f"encode_text: expected ids [C,{g.context_length}], got {tuple(text.shape)}")
         if self.ivlp_text_prompts()[0]:      # IVLP text blocks splice their own tokens: embeddings in, hook on
-            return self.text_encoder_f32(self.token_embedding(text), text)
+            return self.text_encoder_f32(self.token_embedding(text), text, flags=flags)
         Cn = text.shape[0]
         out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=text.device)
         ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
         check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     ops._stream()), "clipmi_encode_text")
+                                     int(flags), ops._stream()), "clipmi_encode_text")
         return out
 
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:

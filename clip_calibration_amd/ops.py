@@ -61,6 +61,27 @@ def gemm_f16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     return out
 
 
+def gemm_residual_f16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x16: torch.Tensor):
+    """``x16 <- fp16(x16 + a @ w^T + bias)`` in place (one rounding of the fp32 sum): the residual GEMM of a block on the fp16
+    stream (reference clip/model.py:186-187).  Returns (stats fp32 [8, M, 2], parts): the LayerNorm-fold row partials
+    ``stats[t, m] = (sum, sum of squares)`` over the t-th column tile of the rounded row m, ``parts`` tiles of them."""
+    import ctypes as C
+    a = _dev(a, "a", (torch.float16,))
+    w = _dev(w, "w", (torch.float16,))
+    bias = _dev(bias, "bias", (torch.float32,))
+    if not (isinstance(x16, torch.Tensor) and x16.is_cuda and x16.dtype == torch.float16 and x16.is_contiguous()):
+        raise TypeError("gemm_residual_f16: x16 must be a contiguous fp16 GPU tensor (it is updated in place)")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or tuple(x16.shape) != (M, N) or bias.numel() != N:
+        raise ValueError(f"gemm_residual_f16: a {tuple(a.shape)}, w {tuple(w.shape)}, bias {tuple(bias.shape)}, x16 {tuple(x16.shape)}")
+    stats = torch.empty(8, M, 2, dtype=torch.float32, device=a.device)
+    parts = C.c_int(0)
+    check(lib.clipmi_gemm_residual_f16(a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr(), x16.data_ptr(), N, stats.data_ptr(),
+                                       C.byref(parts), M, N, K, _stream()), "clipmi_gemm_residual_f16")
+    return stats, parts.value
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out_dtype: Optional[torch.dtype] = None, gather_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32-statistics LayerNorm over the last dim (reference clip/model.py:153-159)."""

@@ -67,7 +67,9 @@ class CustomCLIP(nn.Module):
         # Here the TEXT tower is the hot path (B * C prompts per batch, cocoop.py:186-197).  text_stream_f16: run it on the fp16
         # residual stream like the image tower (the reference's own GPU precision: clip/model.py:186-187 adds in fp16) -- +20 %
         # prompts/s (profiles/r02_text_tower_f16_stream.txt).  The library default keeps the text tower's stream in fp32 because
-        # zero-shot / CoOp text features are computed once and feed every logit; a process that set residual_f16 = 0 keeps fp32.
+        # zero-shot / CoOp text features are computed once and feed every logit.  It is a PER-CALL flag of the tower call
+        # (CLIPMI_CALL_STREAM_F16): no library state is touched, the same model handle keeps serving fp32-stream text features;
+        # a model (or process) set to residual_f16 = 0 or ln_fold = 0 keeps the fp32 stream here too.
         self.text_stream_f16 = text_stream_f16
         self.prompt_learner = PromptLearner(clip_model, tokenized_prompts, n_ctx, **kw)
         self.tokenized_prompts = self.prompt_learner.tokenized_prompts
@@ -92,13 +94,14 @@ class CustomCLIP(nn.Module):
         out = torch.empty(B, Cn, self.clip_model.geometry.embed_dim, dtype=torch.float32, device=image_features.device)
         step = max(1, self.prompts_per_call // Cn)
         from .. import _lib
-        mode = _lib.get_option("residual_f16")
-        with _lib.option("residual_f16", 1 if (self.text_stream_f16 and mode == 2) else mode):   # 2 = image tower only (the default)
-            for lo in range(0, B, step):
-                nb = min(step, B - lo)
-                prompts = ops.cocoop_prompts(pl.base_embedding(), ctx_shifted[lo:lo + nb])
-                ids = self.tokenized_prompts.repeat(nb, 1)                       # EOT index plumbing
-                out[lo:lo + nb] = self.text_encoder(prompts, ids).view(nb, Cn, -1)
+        m = self.clip_model
+        f16 = self.text_stream_f16 and m.get_option("residual_f16") == 2 and m.get_option("ln_fold") == 1   # 2 = image tower only (the default)
+        flags = _lib.CALL_STREAM_F16 if f16 else _lib.CALL_DEFAULT
+        for lo in range(0, B, step):
+            nb = min(step, B - lo)
+            prompts = ops.cocoop_prompts(pl.base_embedding(), ctx_shifted[lo:lo + nb])
+            ids = self.tokenized_prompts.repeat(nb, 1)                       # EOT index plumbing
+            out[lo:lo + nb] = self.text_encoder(prompts, ids, flags=flags).view(nb, Cn, -1)
         return out
 
     @torch.no_grad()

@@ -21,8 +21,8 @@ class TextEncoder(nn.Module):
         self.dtype = clip_model.dtype
 
     def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor, compound_prompts_deeper_text=None,
-                n_ctx: int = 0) -> torch.Tensor:
-        return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx)
+                n_ctx: int = 0, flags: int = 0) -> torch.Tensor:
+        return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx, flags=flags)
 
 
 def n_ctx_from_init_ids(ctx_init_ids: torch.Tensor, context_length: int) -> int:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 10
+#define CLIPMI_ABI_VERSION 11
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -59,29 +59,28 @@ const char* clipmi_strerror(int code);
 const char* clipmi_last_error(void);
 
 /* Runtime switches, process-wide.  The reference has none (its knobs are yacs config keys read by Dassl); these select
- * between parity-tested implementations of the same operator and exist for tests, A/B measurements and the precision
+ * between parity-tested implementations of the same operator and exist for tests, A/B measurements and the DEFAULT precision
  * policy.  Each option also has an environment spelling that is read ONCE, at the first launch; after that only
- * clipmi_set_option changes it (no launch path calls getenv).  Unknown names return CLIPMI_ERR_ARG.
- *   gemm_variant     (CLIPMI_GEMM_VARIANT)    -1 = cost model (default); 0..12, 15 force one GEMM tile configuration
+ * clipmi_set_option changes it (no launch path calls getenv, and no launch path writes an option).  Unknown names return
+ * CLIPMI_ERR_ARG.
+ *   gemm_variant     (CLIPMI_GEMM_VARIANT)    -1 = default dispatch; 0 (128 x 128 tiles), 1 (256 x 256, 16 waves), 10 / 'a' (320 x 256
+ *                                             ping-pong), 13 / 's' (persistent, streamed fp16 epilogue), 16 / 'r' (persistent row ranges,
+ *                                             streamed residual epilogue) force one kernel family where the shape allows it (test aid)
  *   gemm_band        (CLIPMI_GEMM_BAND)       0 = default; n-tiles per traversal band
- *   gemm_persist     (CLIPMI_GEMM_PERSIST)    0 = one tile per workgroup (default); persistent tiles for multi-round fp16-out GEMMs:
- *                                             1 = 16 waves, 2 = 16 waves with DMA'd row / column parameters, 3 = 8 waves with them
- *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs, K >= 512
- *   gemm_pp          (CLIPMI_GEMM_PP)         1 (default) = ping-pong main loop in the one-tile-per-workgroup 320 x 256 kernel (residual GEMMs)
- *   ln_inline        (CLIPMI_LN_INLINE)       1 (default) = the streamed GEMM kernel reduces the LayerNorm row partials of its tile itself (no
- *                                             ln_finalize_kernel launch per folded GEMM; same bits); 0 = one such launch per folded GEMM
- *   gemm_mix         (CLIPMI_GEMM_MIX)        0 (default) = uniform 320-row tiles in the residual GEMMs; 1 = 288- and 320-row tiles in one grid when the
- *                                             uniform grid's last round is part empty (bit-identical results; A/B aid, no faster on a power-bound chip)
+ *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out
+ *                                             GEMMs, K >= 512 (in-proj / c_fc); 0 = one tile per workgroup (same bits with the bias epilogue)
+ *   gemm_rstream     (CLIPMI_GEMM_RSTREAM)    1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
+ *                                             residual GEMMs (out-proj / c_proj); 0 = one 320 x 256 tile per workgroup (same bits)
+ *   attn_loader      (CLIPMI_ATTN_LOADER)     1 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
+ *                                             by LDS-DMA from a dedicated loader wave; 0 = the persistent kernel (same bits)
+ *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
+ * and the process-wide DEFAULTS of the three per-model settings (clipmi_model_set_option overrides them per handle):
  *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block
  *                    runs out-proj, c_fc, c_proj (and ln_2) on the class rows only -- the rows ln_post reads (clip/model.py:419) -- as
  *                    GEMMs with M = batch and row stride L * D; same per-element arithmetic, features equal to 2e-7 in cosine
  *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
  *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
- *                                             (default; env 'v'), 3 = text tower only (env 't')
- *   attn_no_tr / attn_no_persist / attn_no_stream / attn_stagger / attn_loader   (CLIPMI_ATTN_*)  attention kernel selection
- *                                             (attn_loader = 1, default: 193..200-token non-causal attention runs the kernel whose operands all
- *                                             arrive by LDS-DMA from a dedicated loader wave; 2 = two loader waves; 0 = the persistent kernel)
- *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits as three launches instead of the fused tail kernel */
+ *                                             (default; env 'v'), 3 = text tower only (env 't') */
 int clipmi_set_option(const char* name, int value);
 int clipmi_get_option(const char* name, int* value);
 
@@ -96,6 +95,14 @@ int clipmi_get_option(const char* name, int* value);
 int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     const void* residual, void* out, int64_t ldo, int out_dtype,
                     int M, int N, int K, int epilogue, clipmi_stream_t stream);
+
+/* The residual GEMM of a block on the fp16 residual stream (out-proj / c_proj, clip/model.py:186-187: `x = x + f(x)` on fp16 tensors):
+ * x16[m,n] = fp16(x16[m,n] + A[m,:] . W[n,:] + bias[n]) IN PLACE (one rounding of the fp32 sum), plus the LayerNorm-fold row
+ * partials the next GEMM consumes: stats[(t * M + m) * 2 + {0,1}] = (sum, sum of squares) over the 256 columns of column tile t of
+ * the ROUNDED row m; *parts (host int) receives the number of column tiles, (N + 255) / 256 <= 8.  A fp16 [M,K] (lda), W fp16 [N,K]
+ * (ldw), bias fp32 [N], x16 fp16 [M,N] (ldx), stats fp32 [parts * M * 2].  K % 64 == 0, N % 8 == 0, ldx % 8 == 0, 16-byte aligned. */
+int clipmi_gemm_residual_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* x16, int64_t ldx,
+                             float* stats, int* parts, int M, int N, int K, clipmi_stream_t stream);
 
 /* LayerNorm subclass with fp32 statistics (clip/model.py:153-159): y[r,:] = (x[row(r),:] - mean) * rsqrt(var+eps)
  * * gamma + beta.  row(r) = gather_idx ? gather_idx[r] : r, addressed with in_stride (elements).  D % 4 == 0,
@@ -314,6 +321,22 @@ typedef struct clipmi_prompt_hook {
 
 int clipmi_create(const clipmi_geometry* geom, clipmi_model** out);
 int clipmi_destroy(clipmi_model* m);
+
+/* Per-model settings.  The reference chooses precision per model (cfg.TRAINER.<X>.PREC, trainers/classification/coop.py:243-245) and
+ * builds a second CLIP inside the same process (trainers/classification/base_learner.py:262-272), so these live on the handle:
+ * names "residual_f16" (0..3, see clipmi_set_option), "ln_fold" (0 / 1), "cls_only_last_block" (0 / 1); value -1 (the initial
+ * state) follows the process-wide option of the same name.  clipmi_model_get_option returns the EFFECTIVE value.
+ * Threading contract: calls on DIFFERENT handles may run concurrently from different threads and streams (each call touches only
+ * its handle, its workspace and its stream); calls on one handle, and clipmi_model_set_option on it, are serialised by the caller. */
+int clipmi_model_set_option(clipmi_model* m, const char* name, int value);
+int clipmi_model_get_option(const clipmi_model* m, const char* name, int* value);
+
+/* Per-call flags of the tower calls (last argument before the stream): 0, or ONE of the two stream-precision overrides for THIS
+ * call only (no state is changed): CoCoOp's per-image text passes run the fp16 stream while the same handle's zero-shot features
+ * keep the fp32 stream.  CLIPMI_CALL_STREAM_F16 needs the LayerNorm-folded operands (else CLIPMI_ERR_STATE). */
+#define CLIPMI_CALL_DEFAULT 0u
+#define CLIPMI_CALL_STREAM_F32 1u /* residual stream in fp32 (+ fp16 operand shadow) */
+#define CLIPMI_CALL_STREAM_F16 2u /* residual stream in fp16: the reference's own GPU precision (clip/model.py:186-187) */
 int clipmi_set_vision_weights(clipmi_model* m, const clipmi_vision_weights* w);
 int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w);
 
@@ -325,23 +348,23 @@ size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts);
  * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns). */
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
-                        clipmi_stream_t stream);
+                        unsigned flags, clipmi_stream_t stream);
 
 /* `clip_model.transformer(x)` as the trainers' TextEncoder uses it (coop.py:58-60, maple.py:64-66): the causal
  * blocks only.  x fp16|fp32 [C, L, Dt] token-major in, y same dtype/shape out (x == y allowed). */
 int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts,
                        const clipmi_prompt_hook* hook, void* workspace, size_t workspace_bytes,
-                       clipmi_stream_t stream);
+                       unsigned flags, clipmi_stream_t stream);
 
 /* TextEncoder.forward (coop.py:56-67, maple.py:60-74): prompts (fp16|fp32) [C,L,Dt] WITHOUT positional embedding,
  * eot int32[C] = tokenized_prompts.argmax(-1)  ->  out fp32 [C,E] = ln_final(blocks(prompts + pos))[eot] @ text_projection. */
 int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
-                        clipmi_stream_t stream);
+                        unsigned flags, clipmi_stream_t stream);
 
 /* CLIP.encode_text (clip/model.py:600-613): ids int64 [C,L] -> out fp32 [C,E]; EOT row = argmax(ids), computed on device. */
 int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace,
-                       size_t workspace_bytes, clipmi_stream_t stream);
+                       size_t workspace_bytes, unsigned flags, clipmi_stream_t stream);
 
 /* Timing aid for bench.py (the per-kernel roofline of its JSON line): the five launches of the vision tower's residual
  * block 0 -- 0 in-proj, 1 attention, 2 out-proj + residual, 3 c_fc + QuickGELU, 4 c_proj + residual (clip/model.py:181-188)

@@ -57,7 +57,16 @@ def test_argument_validation_needs_no_gpu():
     assert L.clipmi_create(ctypes.byref(geo), ctypes.byref(h)) == _lib.ERR_SHAPE                          # width % 64
     geo = _lib.Geometry(512, 224, 16, 768, 12, 77, 49408, 512, 12, 8)
     assert L.clipmi_create(ctypes.byref(geo), ctypes.byref(h)) == _lib.OK
-    assert L.clipmi_encode_image(h, p, 1, 1, None, p, p, 1 << 30, None) == _lib.ERR_STATE                # unbound weights
+    assert L.clipmi_encode_image(h, p, 1, 1, None, p, p, 1 << 30, 0, None) == _lib.ERR_STATE             # unbound weights
+    # per-model settings live on the handle (clipmi_model_set_option); -1 follows the process-wide default
+    v = ctypes.c_int(-7)
+    assert L.clipmi_model_get_option(h, b"residual_f16", ctypes.byref(v)) == _lib.OK and v.value == _lib.get_option("residual_f16")
+    assert L.clipmi_model_set_option(h, b"residual_f16", 0) == _lib.OK
+    assert L.clipmi_model_get_option(h, b"residual_f16", ctypes.byref(v)) == _lib.OK and v.value == 0
+    assert _lib.get_option("residual_f16") == 2                                                          # the process-wide default is untouched
+    assert L.clipmi_model_set_option(h, b"residual_f16", 7) == _lib.ERR_ARG and L.clipmi_model_set_option(h, b"gemm_band", 1) == _lib.ERR_ARG
+    assert L.clipmi_model_set_option(h, b"residual_f16", -1) == _lib.OK
+    assert L.clipmi_model_get_option(h, b"residual_f16", ctypes.byref(v)) == _lib.OK and v.value == 2
     assert L.clipmi_vision_workspace_bytes(h, 256, 0) == pytest.approx((22 * 768 + 64) * 256 * 197, rel=1e-3)   # 22*D B of activations + 64 B of LN-fold partials per token row
     assert L.clipmi_destroy(h) == _lib.OK
 

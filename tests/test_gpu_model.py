@@ -322,37 +322,19 @@ def test_vit_large_towers_vs_oracle(gname, batch):
 
 
 @pytest.mark.parametrize("batch", [256, 300, 160, 131])
-def test_mixed_tile_heights_bit_identical(clipmi_option, batch):
-    """Option gemm_mix (off by default: it measured no faster): the fp16-stream residual GEMMs (out-proj, c_proj) run 288- and 320-row tiles in one grid when
-    the uniform 320-row grid leaves its last round part empty.  Only the partition of the rows over workgroups changes -- every
-    output element and every LayerNorm row partial is the same K-ordered / column-ordered sum -- so the image features must be
-    bit-identical: batch 256 (6 tall m-tiles per XCD, 510 tiles in 2 rounds), 300 and 160 (all tiles short), 131 (M = 25807: 1.9
-    rounds of 320-row tiles -> 90 short m-tiles), twice each to screen for a race on the rows between neighbouring tiles."""
+def test_row_range_residual_kernel_bit_identical_in_tower(clipmi_option, batch):
+    """gemm_rstream_kernel (option gemm_rstream = 1, the default for the fp16-stream residual GEMMs out-proj / c_proj) against the
+    one-tile-per-workgroup kernel (gemm_rstream = 0).  Only the partition of the rows over workgroups and the moment the residual
+    rows are read and the sums stored change -- every output element and every LayerNorm row partial is the same K-ordered /
+    column-ordered sum -- so the image features must be bit-identical: batch 256 (85 ranges of 18-19 pairs: tiles of 7 + 6 + 6),
+    300 (22-23 pairs: four tiles), 160 (11-12 pairs: two tiles), 131 (M = 25807, a ragged last pair), twice each to screen for a
+    race on the slots between consecutive tiles."""
     sd, model = _build("ViT-B/16")
     images = syn.synthetic_images(batch, "ViT-B/16", seed=9).cuda()
     with torch.no_grad():
-        clipmi_option("gemm_mix", 0)
+        clipmi_option("gemm_rstream", 0)
         ref = model.image_features_f32(images).clone()
-        clipmi_option("gemm_mix", 1)
-        a = model.image_features_f32(images).clone()
-        b = model.image_features_f32(images).clone()
-    assert torch.isfinite(a).all()
-    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
-
-
-@pytest.mark.parametrize("gname,batch", [("ViT-B/16", 256), ("ViT-B/16", 131), ("ViT-L/14@336px", 40)])
-def test_layernorm_partials_finalised_in_kernel(clipmi_option, gname, batch):
-    """Option ln_inline (default 1): gemm_stream_kernel reduces the LayerNorm row partials of its tile itself (thread t owns row t,
-    ln_row_params' arithmetic, in place in LDS) instead of reading what one ln_finalize_kernel launch per folded GEMM prepared.
-    Same sums in the same order -> bit-identical image features; ViT-L is the four-partial case (width 1024)."""
-    if gname not in syn.GEOMETRIES:
-        pytest.skip(f"no synthetic geometry {gname}")
-    sd, model = _build(gname)
-    images = syn.synthetic_images(batch, gname, seed=12).cuda()
-    with torch.no_grad():
-        clipmi_option("ln_inline", 0)
-        ref = model.image_features_f32(images).clone()
-        clipmi_option("ln_inline", 1)
+        clipmi_option("gemm_rstream", 1)
         a = model.image_features_f32(images).clone()
         b = model.image_features_f32(images).clone()
     assert torch.isfinite(a).all()
@@ -360,20 +342,21 @@ def test_layernorm_partials_finalised_in_kernel(clipmi_option, gname, batch):
 
 
 @pytest.mark.parametrize("n_prompts", [1000, 700])
-def test_mixed_tile_heights_text_tower(clipmi_option, n_prompts):
-    """gemm_mix on the text tower's shapes (fp16 residual stream switched on for it: residual_f16 = 1): N = 512 is two column
-    tiles, M = 77 000 gives 13 tall m-tiles per XCD among 256, M = 53 900 an all-short grid -- bit-identical text features."""
-    clipmi_option("residual_f16", 1)
+def test_row_range_residual_kernel_text_tower(n_prompts):
+    """The same on the text tower's shapes with the fp16 stream asked for per call (CLIPMI_CALL_STREAM_F16): N = 512 is two column
+    tiles (128 row ranges), K = 512 is the shortest K loop the kernel takes (8 K-steps: slot 6 rides on the last prefetching one)."""
+    from clip_calibration_amd import _lib
     sd, model = _build("ViT-B/16")
     ids = syn.synthetic_token_ids(n_prompts, "ViT-B/16", seed=4).cuda()
     with torch.no_grad():
-        clipmi_option("gemm_mix", 0)
-        ref = model.text_features_f32(ids).clone()
-        clipmi_option("gemm_mix", 1)
-        a = model.text_features_f32(ids).clone()
-        b = model.text_features_f32(ids).clone()
+        with _lib.option("gemm_rstream", 0):
+            ref = model.text_features_f32(ids, flags=_lib.CALL_STREAM_F16).clone()
+        a = model.text_features_f32(ids, flags=_lib.CALL_STREAM_F16).clone()
+        b = model.text_features_f32(ids, flags=_lib.CALL_STREAM_F16).clone()
+        f32 = model.text_features_f32(ids).clone()
     assert torch.isfinite(a).all()
     assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+    assert not torch.equal(a, f32)                                # the flag does select the fp16 stream
 
 
 @pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70)])
@@ -584,7 +567,8 @@ def test_cocoop_vs_oracle_with_dac_larger_batch():
 def test_cocoop_text_stream_f16_at_depth():
     """CoCoOp runs its text tower -- the hot path there -- on the fp16 residual stream (text_stream_f16, default on; the
     reference's GPU precision, clip/model.py:186-187).  At ViT-B/16 depth: against the fp32-stream setting and against the
-    oracle, in cosine-logit terms; a process-wide residual_f16 = 0 is respected (bit-identical to text_stream_f16 = False)."""
+    oracle, in cosine-logit terms; a model set to residual_f16 = 0 is respected (bit-identical to text_stream_f16 = False).  The fp16
+    stream is a per-call flag of the tower call (CLIPMI_CALL_STREAM_F16): the trainer writes no library option."""
     from clip_calibration_amd import _lib
     from clip_calibration_amd.trainers import CoCoOpCLIP
     sd, model = _build("ViT-B/16")
@@ -600,12 +584,13 @@ def test_cocoop_text_stream_f16_at_depth():
         outs[f16] = co(images.cuda())[0].cpu().numpy() / co.scale
         if f16:
             pl = {k: v.detach().float().cpu() for k, v in co.prompt_learner.state_dict().items()}
-            with _lib.option("residual_f16", 0):
-                fp32_everywhere = co(images.cuda())[0].cpu().numpy() / co.scale
-            with _lib.option("residual_f16", 0):
-                co.text_stream_f16 = False
-                assert np.array_equal(co(images.cuda())[0].cpu().numpy() / co.scale, fp32_everywhere)
-    assert _lib.get_option("residual_f16") == 2                                  # restored
+            model.set_option("residual_f16", 0)                                  # per MODEL: no process-wide state is touched
+            fp32_everywhere = co(images.cuda())[0].cpu().numpy() / co.scale
+            co.text_stream_f16 = False
+            assert np.array_equal(co(images.cuda())[0].cpu().numpy() / co.scale, fp32_everywhere)
+            model.set_option("residual_f16", -1)
+            co.text_stream_f16 = True
+    assert _lib.get_option("residual_f16") == 2 and model.get_option("residual_f16") == 2   # nothing global was written
     assert np.abs(outs[True] - outs[False]).max() < COS_TOL / 2
     assert np.abs(outs[True] - outs[False]).max() > 0                            # the switch does switch
     with torch.no_grad():
