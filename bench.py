@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=("zeroshot", "coop_dac"), default="zeroshot")
+    ap.add_argument("--workload", choices=("zeroshot", "coop_dac", "level1", "stream"), default="zeroshot",
+                    help="zeroshot = the headline (BASELINE configs[1]); coop_dac = configs[2]; level1 = the reference caller's own statements "
+                         "with only build_model swapped (INTEGRATION level 1); stream = host fp32 batches through runner.device_batches")
+    ap.add_argument("--sustained-seconds", type=float, default=3.2, help="length of the second, sustained timed loop (0 = skip)")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--classes", type=int, default=None, help="default: 1000 (zeroshot) / 500 (coop_dac)")
     ap.add_argument("--model", default="ViT-B/16")
@@ -163,6 +166,183 @@ def kernel_roofline(model, syn, geom, model_name, B, images):
             "tower_frac": tower_tf / MFMA_F16_DENSE_PEAK_TFLOPS}
 
 
+class PowerSampler:
+    """Package power, power cap and shader clock of the benchmarked GPU while a loop runs, read from sysfs hwmon files by a Python
+    thread (files only: nothing is exec'ed from this GPU-initialised process).  amdgpu exposes power1_average / power1_input and
+    power1_cap in microwatts and freq1_input (sclk) in Hz under /sys/class/drm/card*/device/hwmon/hwmon*/."""
+
+    def __init__(self, device_index: int, period_s: float = 0.05):
+        import glob
+        import threading
+        self.period, self._stop, self._thread = period_s, threading.Event(), None
+        self.samples = {}   # hwmon dir -> [(power_w, sclk_mhz)]
+        self.dirs, self.note = [], ""
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:   # older torch: no PCI ids on the properties object
+            pass
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if any(os.path.exists(os.path.join(h, f)) for f in ("power1_average", "power1_input")):
+                self.dirs.append(h)
+        if want:
+            hit = [h for h in self.dirs if os.path.realpath(os.path.join(h, "..", "..")).endswith(want)]
+            if hit:
+                self.dirs, self.note = hit, f"pci {want}"
+        if not self.dirs:
+            self.note = "no readable amdgpu hwmon power file on this box"
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            for h in self.dirs:
+                pw = self._read(os.path.join(h, "power1_average"))
+                if pw is None:
+                    pw = self._read(os.path.join(h, "power1_input"))
+                fr = self._read(os.path.join(h, "freq1_input"))
+                self.samples.setdefault(h, []).append((None if pw is None else pw * 1e-6, None if fr is None else fr * 1e-6))
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.dirs:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join()
+        if not self.samples:
+            return {"avg_w": None, "cap_w": None, "sclk_mhz_avg": None, "note": self.note or "no samples"}
+        best, best_w = None, -1.0
+        for h, sm in self.samples.items():   # several cards visible and no PCI match: the one that drew the most power ran the loop
+            ws = [a for a, _ in sm if a is not None]
+            if ws and sum(ws) / len(ws) > best_w:
+                best, best_w = h, sum(ws) / len(ws)
+        if best is None:
+            return {"avg_w": None, "cap_w": None, "sclk_mhz_avg": None, "note": "power files unreadable"}
+        sm = self.samples[best][1:] or self.samples[best]   # the first sample predates the loop
+        ws = [a for a, _ in sm if a is not None]
+        fs = [b for _, b in sm if b is not None]
+        cap = self._read(os.path.join(best, "power1_cap"))
+        return {"avg_w": sum(ws) / len(ws) if ws else None, "max_w": max(ws) if ws else None, "cap_w": None if cap is None else cap * 1e-6,
+                "sclk_mhz_avg": sum(fs) / len(fs) if fs else None, "sclk_mhz_min": min(fs) if fs else None, "samples": len(sm),
+                "source": best + "/{power1_average|power1_input, freq1_input, power1_cap}" + (f" ({self.note})" if self.note else ""),
+                "note": "sampled every 50 ms during the sustained loop; sysfs sclk reads up to ~10 % above the in-kernel clock of MFMA-dense loops "
+                        "(MI355X_MICROARCH.md, DVFS give-back 6)"}
+
+
+def level1_workload(args, dev, syn, model, sd):
+    """INTEGRATION level 1: ONLY clip.build_model is swapped; every statement the reference's zero-shot trainer and evaluator execute per
+    batch runs as the reference wrote it (trainers/classification/zsclip.py:97-102, trainers/classification/base_learner.py:84-88,
+    evaluators/vl_evaluator.py:40-51): fp16 `encode_image` output, normalise and `logit_scale * img @ txt.t()` as torch ops, then four
+    `.data.cpu().numpy().tolist()` per batch.  Reported beside the Level-2 mirror (the headline) to show what an unchanged caller gets."""
+    B, Cn = args.batch, args.classes or 1000
+    ids = syn.synthetic_token_ids(Cn, args.model, seed=0).to(dev)
+    images = syn.synthetic_images(B, args.model, seed=0, device=dev)
+    labels = torch.zeros(B, dtype=torch.int64, device=dev)
+    with torch.no_grad():
+        text_features = model.encode_text(ids)                                          # zsclip.py:90-92
+        text_features = text_features / text_features.norm(dim=-1, keepdim=True)
+
+        def model_inference(image):                                                     # zsclip.py:97-102, statement for statement
+            image_features = model.encode_image(image)
+            image_features = image_features / image_features.norm(dim=-1, keepdim=True)
+            logit_scale = model.logit_scale.exp()
+            logits = logit_scale * image_features @ text_features.t()
+            return logits, image_features, text_features
+
+        y_score, y_true, tf_l, if_l = [], [], [], []
+
+        def process(mo, gt, image_features, text_feats):                               # vl_evaluator.py:40-51
+            y_score.extend(mo.data.cpu().numpy().tolist())
+            y_true.extend(gt.data.cpu().numpy().tolist())
+            tf_l.extend(text_feats.data.cpu().numpy().tolist())
+            if_l.extend(image_features.data.cpu().numpy().tolist())
+
+        def loop(n, with_evaluator):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out, imf, txf = model_inference(images)
+                if with_evaluator:
+                    process(out, labels, imf, txf)
+                    for lst in (y_score, y_true, tf_l, if_l):
+                        lst.clear()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        loop(args.warmup, False)
+        t_inf = loop(args.steps, False)
+        loop(1, True)
+        n_ev = max(2, min(args.steps, 5))
+        t_ev = loop(n_ev, True)
+    return {"metric": "images/sec ViT-B/16 zero-shot, reference caller unchanged (INTEGRATION level 1; not the headline metric)",
+            "value": B * args.steps / t_inf, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_inf / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"reference zsclip.model_inference statements on the swapped build_model, {args.model}, batch {B}, {Cn} prompts", "batch_per_gpu": B, "classes": Cn},
+            "level1": {"model_inference_images_per_s": B * args.steps / t_inf, "model_inference_ms": 1e3 * t_inf / args.steps,
+                       "with_reference_evaluator_process_images_per_s": B * n_ev / t_ev, "with_reference_evaluator_process_ms": 1e3 * t_ev / n_ev,
+                       "what": "model_inference: HIP image tower -> fp16 features -> torch normalise + matmul (fp16, 3 small torch kernels); "
+                               "evaluator.process: four .data.cpu().numpy().tolist() per batch (logits [B,C], labels, text [C,E], image [B,E]) as "
+                               "evaluators/vl_evaluator.py:40-51 does -- host-bound; the Level-2 mirror keeps all of it on the device"}}
+
+
+def stream_workload(args, dev, syn, model):
+    """Host fp32 batches -> pinned staging -> side-stream H2D (runner.device_batches), a batch ahead -> ZeroshotCLIP.model_inference with the
+    device evaluator: the test loop of base_learner.py:84-88 with its input leg included (PCIe), against the resident-batch headline."""
+    from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
+    from clip_calibration_amd.runner import device_batches
+    from clip_calibration_amd.trainers import ZeroshotCLIP
+    B, Cn = args.batch, args.classes or 1000
+    zs = ZeroshotCLIP(model, syn.synthetic_token_ids(Cn, args.model, seed=0))
+    host = [(syn.synthetic_images(B, args.model, seed=k), torch.randint(0, Cn, (B,), generator=torch.Generator().manual_seed(k))) for k in range(4)]
+    ev = DeviceCalibrationEvaluator(10, dev)
+
+    def loader(n):
+        for i in range(n):
+            yield host[i % len(host)]
+
+    def loop(n, staged):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = device_batches(loader(n), dev) if staged else ((im.to(dev), lb.to(dev)) for im, lb in loader(n))   # pageable .to(): what parse_batch_test does
+        for image, label in it:
+            zs.model_inference(image, want_conf_pred=True, labels=label, evaluator=ev)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    with torch.no_grad():
+        loop(args.warmup, True)
+        t_staged = loop(args.steps, True)
+        loop(2, False)
+        t_page = loop(args.steps, False)
+        resident = host[0][0].to(dev), host[0][1].to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            zs.model_inference(resident[0], want_conf_pred=True, labels=resident[1], evaluator=ev)
+        torch.cuda.synchronize()
+        t_res = time.perf_counter() - t0
+    bytes_per_batch = host[0][0].numel() * 4
+    return {"metric": "images/sec ViT-B/16 zero-shot + ECE, inputs streamed from host memory (not the headline metric)",
+            "value": B * args.steps / t_staged, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_staged / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"host fp32 batches of {B} (4 distinct, cycled) -> pinned + non_blocking H2D on a side stream -> {args.model} zero-shot + ECE, {Cn} prompts",
+                       "batch_per_gpu": B, "classes": Cn},
+            "stream": {"pinned_double_buffered_images_per_s": B * args.steps / t_staged, "pageable_to_device_images_per_s": B * args.steps / t_page,
+                       "resident_images_per_s": B * args.steps / t_res, "h2d_gbytes_per_s": bytes_per_batch * args.steps / t_staged / 1e9,
+                       "bytes_per_image": bytes_per_batch // B, "pcie_gen5_x16_spec_gbytes_per_s": 63.0}}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +374,13 @@ def main():
     from clip_calibration_amd.parallel import EmbeddingExchange
     from clip_calibration_amd.trainers import CoOpCLIP, ZeroshotCLIP
 
+    if args.workload in ("level1", "stream"):
+        if world != 1:
+            raise SystemExit(f"--workload {args.workload} is a single-GPU line")
+        sd_ = syn.synthetic_state_dict(args.model, seed=0)
+        model_ = build_model(dict(sd_), {"trainer": "ZeroshotCLIP"}).to(dev)
+        print(json.dumps(level1_workload(args, dev, syn, model_, sd_) if args.workload == "level1" else stream_workload(args, dev, syn, model_)))
+        return
     geom = syn.GEOMETRIES[args.model]
     coop = args.workload == "coop_dac"
     B = args.batch
@@ -201,7 +388,11 @@ def main():
     E = geom.embed_dim
     sd = syn.synthetic_state_dict(args.model, seed=0)
     model = build_model(dict(sd), {"trainer": "CoOp" if coop else "ZeroshotCLIP"}).to(dev)
-    exchange = EmbeddingExchange(dev, backend="torch" if same_gpu else "auto") if world > 1 else None
+    # N > 1 on real GPUs: the exchange MUST be the library's RCCL communicator over all ranks -- a run that fell back to torch.distributed
+    # would look like a scaling measurement of something else.  backend="rccl" raises (on every rank alike) if it cannot be built.
+    exchange = EmbeddingExchange(dev, backend="torch" if same_gpu else "rccl") if world > 1 else None
+    if exchange is not None and not same_gpu and not (exchange.backend == "rccl" and exchange.rccl_ranks == world):
+        raise SystemExit(f"bench: the exchange is {exchange.backend} over {exchange.rccl_ranks} ranks, not RCCL over {world}: refusing to time it")
 
     # ---- text side: computed once, outside the timed region (zsclip.py:90-92; CoOp: cached while ctx is unchanged)
     extra = {}
@@ -306,6 +497,18 @@ def main():
         elapsed, last = run(labels, args.steps)
         res = evaluator.evaluate()
         bins_np = evaluator.bins.cpu().numpy().copy()
+        if args.sustained_seconds > 0:
+            # a second timed loop of the SAME step, long enough for the chip to reach its power / clock steady state (the K-step headline
+            # region is ~0.2 s); `value` stays the K-step number
+            n_s = max(args.steps, int(np.ceil(args.sustained_seconds / (elapsed / args.steps))))
+            sampler = PowerSampler(local_rank) if rank == 0 else None
+            if sampler:
+                sampler.start()
+            el_s, _ = run(labels, n_s)
+            extra["sustained"] = {"seconds": el_s, "steps": n_s, "images_per_s": world * B * n_s / el_s, "ms_per_step": 1e3 * el_s / n_s,
+                                  "ratio_to_value": (world * B * n_s / el_s) / (world * B * args.steps / elapsed)}
+            if sampler:
+                extra["power"] = sampler.stop()
         if coop:
             n_rt = max(2, args.steps // 2)
             for _ in range(2):

@@ -202,6 +202,13 @@ __device__ __forceinline__ void fold_row_sums(const f32x4& v, float& rsum, float
   rsum += (v[0] + v[1]) + (v[2] + v[3]);
   rsq += __builtin_fmaf(v[0], v[0], v[1] * v[1]) + __builtin_fmaf(v[2], v[2], v[3] * v[3]);
 }
+// The same for the fp16 stream, whose partials are those of the ROUNDED row: v_dot2_f32_f16 on the fp16 pairs (fp32 accumulation),
+// four instructions per four elements instead of four conversions + eight adds / fused multiply-adds.
+__device__ __forceinline__ void fold_row_sums16(const f16x4& h, float& rsum, float& rsq) {
+  const f16x2 lo = f16x2{h[0], h[1]}, hi = f16x2{h[2], h[3]}, one = f16x2{(half_t)1.f, (half_t)1.f};
+  rsum = __builtin_amdgcn_fdot2(hi, one, __builtin_amdgcn_fdot2(lo, one, rsum, false), false);
+  rsq = __builtin_amdgcn_fdot2(hi, hi, __builtin_amdgcn_fdot2(lo, lo, rsq, false), false);
+}
 
 // Producer side of the LayerNorm fold: BIAS_RESIDUAL epilogue that, besides the fp32 read-modify-write of the residual
 // stream, stores fp16(out) to x16 through the wave-private LDS transpose and writes this tile's row partials.
@@ -245,13 +252,12 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
           if constexpr (F16RES) {
             const f16x4 r = *reinterpret_cast<const f16x4*>(a.x16 + (int64_t)m * a.ldo + n);
             v = acc[i][jc * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
+            fold_row_sums16(f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}, rsum, rsq);
           } else {
             v = acc[i][jc * 2 + jj] + bias[i] + *reinterpret_cast<const f32x4*>(a.residual + (int64_t)m * a.ldo + n);
             *reinterpret_cast<f32x4*>(out + (int64_t)m * a.ldo + n) = v;
+            fold_row_sums(v, rsum, rsq);
           }
-          fold_row_sums(v, rsum, rsq);
         }
         *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
             f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -377,9 +383,7 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m < a.M && n < a.N) {
           v = acc[i][c * 2 + jj] + bias[i] + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (float)(half_t)v[e];
-          fold_row_sums(v, rsum, rsq);
+          fold_row_sums16(f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]}, rsum, rsq);
         }
         *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       }
@@ -1461,61 +1465,52 @@ int launch_pp(KArgs k, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent ROW-RANGE kernel for the fp16-stream residual GEMMs (EPI_RESIDUAL_FOLD16: out-proj, c_proj; round 3):
-//     x16[m, n] = fp16(x16[m, n] + A[m, :] . W[n, :] + bias[n])  in place,  + the LayerNorm-fold row partials of the rounded rows.
+//     x16[m, n] = fp16(x16[m, n] + bias[n] + A[m, :] . W[n, :])  in place,  + the LayerNorm-fold row partials of the rounded rows.
 //
 // Why.  gemm_pp_kernel runs these shapes as 320 x 256 tiles, one per workgroup, 1.85 rounds of 256 CUs; phase stamps
 // (profiles/r02_gemm_stamps_final.txt) put an out-proj tile at 1.3 us prologue + 20.4 us main loop + 11.3 us epilogue with the
-// matrix pipe idle: the residual rows come in and the sums go out as one burst per round (82 MB at once, HBM-bound), and every CU
-// reaches that burst at the same moment.  out-proj at N = K = 768 is close to HBM-bound as a whole (231 MB for 59.5 GFLOP), so its
-// traffic has to be a continuous stream under the MFMAs, not a burst between them.
+// matrix pipe idle: the residual rows come in and the sums go out as one burst per round (84 MB at once, 7.4 TB/s: bandwidth
+// bound), every CU reaches that burst at the same moment, and the next workgroup cannot start before the stores have drained.
+// A first form of this kernel (profiles/r03_rstream_slots_ab.txt) held the output slices in registers and streamed them, and the
+// residual, through the next tile's K loop -- which needs tiles of <= 224 rows, i.e. three per CU, and a K-step costs ~3300
+// cycles whatever the tile height (the load part of a phase, not the matrix pipe, sets it): 36 K-steps against 24 lost.
 //
-// What.  One workgroup per CU (eight waves, two per SIMD, ping-pong as in gemm_stream_kernel).  The M x N problem is cut into
-// (row range, 256-column tile) UNITS, one per workgroup: the rows in `groups` near-equal ranges of 32-row pairs, every range taken
-// by tiles_n workgroups with adjacent ids (same XCD: the activation rows are fetched into its L2 once).  A workgroup walks its
-// range in TILES of 32 nb rows, nb = 4 .. 7 chosen so that the tiles of a range are equal to within one pair (M = 50 432, N = 768
-// on 256 CUs: 85 ranges of 18-19 pairs = tiles of 7 + 6 + 6 pairs; every CU carries the same 19 x 12 block-K-steps, where the
-// 320-row grid gives 218 CUs 20 and 38 CUs 10).  The epilogue leaves the critical path:
-//   * a wave keeps its nb x (16 rows x 64 columns) output slices as packed fp16 in 8 registers each ("slots");
-//   * slot j of the PREVIOUS tile is stored inside K-step j of the current tile (two 16-byte stores), and right behind it the
-//     RESIDUAL slice j of the CURRENT tile is loaded into the same registers (two 16-byte loads, the layout the stores use) -- a
-//     slot holds outputs early in a K loop and residual late; by the end of the K loop every residual slice has landed (in-order
-//     VMEM: the counted wait of the next K-step covers it), so the tile end is arithmetic only: un-swap, add in fp32, round once,
-//     row partials, re-pack into the slot;
-//   * the row partials of the four column waves meet in LDS and are reduced behind the tile's closing barrier, while the next
-//     tile's first stage (DMA'd piece by piece between the slices) is already in.
-// HBM sees 4 x 16 B per lane and K-step in each direction for the whole launch instead of 164 KB per CU in a burst.
+// What.  One workgroup per CU (eight waves, two per SIMD, the four-phase ping-pong loop of gemm_pp_kernel).  The M x N problem is cut
+// into (row range, 256-column tile) UNITS, one per workgroup: the rows in `groups` near-equal ranges of 32-row pairs, every range
+// taken by tiles_n workgroups with adjacent ids (same XCD: the activation rows reach its L2 once).  A workgroup walks its range in
+// TILES of 32 nb rows, nb <= 10, equal to within one pair (M = 50 432, N = 768 on 256 CUs: 85 ranges of 18-19 pairs = tiles of 10 + 9
+// or 9 + 9 pairs: every CU carries 18-19 blocks through 2 x nk K-steps, where the 320-row grid gives 218 CUs 20 and 38 CUs 10).
+//   * The residual is PRELOADED INTO THE ACCUMULATORS: a tile starts from acc = bias + residual (fp32) and the MFMAs add the products
+//     on top, so the tile end needs no operand -- round, row partials, store.  The residual of tile i + 1 is loaded (two 16-byte loads
+//     per 16 x 64 slice, the layout the stores use) while tile i is being converted, into the registers its accumulators free.
+//   * Stores are the YOUNGEST operations in the queue: every load and every LDS-DMA piece of the next tile is issued first, all
+//     stores of the finished tile last, and the wait that opens the next tile is vmcnt(#stores) -- the stores drain under its K loop.
+//   * The next tile's first stage is DMA'd before the conversion starts; the row partials of the four column waves meet in LDS and
+//     are reduced behind the tile's closing barrier.
+// Arithmetic: (bias + residual) + sum_k products in K order, one rounding to fp16 -- the same sum as the tile kernels' (sum_k
+// products + bias) + residual in a different fp32 order: results agree with gemm_pp_kernel to the last fp16 bit on all but a few
+// elements in ten thousand (a rounding boundary), never more than one ulp; run-to-run bit-identical
+// (tests/test_gpu_ops.py::test_gemm_residual_f16_vs_reference, ::test_gemm_residual_stream_race_screen).
 //
-// K loop: TWO wide phases per K-step (k-half ks): a LOAD part -- four weight fragments + nb activation fragments by pinned LDS reads,
-// this wave's share of the next stage's LDS-DMA pieces, the slot traffic -- and a COMPUTE part of 4 nb MFMAs on registers only, a
-// workgroup barrier after each part; waves 4-7 run one part behind waves 0-3 (with 16-MFMA quarter phases the load part, not the
-// matrix pipe, would set the slot length at nb <= 7).  Slots (S = 4 k + ..; G0 = waves 0-3, G1 = waves 4-7):
-//     S + 0: G0 load ks 0 (own pieces 0..5)              | G1 compute ks 1 of K-step k - 1
-//     S + 1: G0 compute ks 0                             | G1 load ks 0 (own pieces 0..5)
-//     S + 2: G0 load ks 1 (own 6, 7 + G1's 6, 7, slot j) | G1 compute ks 0
-//     S + 3: G0 compute ks 1, then vmcnt                 | G1 load ks 1 (slot j), then vmcnt
-//   WAR  stage k + 1 goes into the buffer of stage k - 1, last read by G1 in slot S - 1; the first piece is issued in slot S.
-//   RAW  every piece is out by slot S + 2 and waited for by its issuing wave at the end of slot S + 3 (G1's pieces 6, 7 are
-//        issued by its SIMD partner in G0, so that G1 issues nothing it would have to wait for in the same slot); the first read of
-//        stage k + 1 is in slot S + 4.  The slot traffic is issued BEHIND the pieces: vmcnt(4) leaves exactly it in flight.
-// Same K order, same MFMA, same (acc + bias) + residual, same partial sums as gemm_pp_kernel / gemm_f16_kernel with the fold16
-// epilogue: bit-identical results (tests/test_gpu_ops.py::test_gemm_residual_stream_race_screen).
-// Needs K >= 8 K-steps (slots 0..6 ride on K-steps 0..6, all of which prefetch a next stage), N % 8 == 0, at least 4 pairs per range.
+// K loop (as gemm_pp_kernel): a K-step is four phases per wave (k-half ks = p >> 1, row half jh = p & 1): a LOAD part -- the
+// phase's fragments by pinned LDS reads (the half's activation blocks, plus the 4 weight blocks when jh == 0) and, in phases 0..2, a
+// third of this wave's nine LDS-DMA pieces of the next stage -- and a COMPUTE part of 4 x (blocks of the half) MFMAs on registers
+// only, a workgroup barrier after each part; waves 4-7 run one part behind waves 0-3.  A wave's nb blocks are split h0 = ceil(nb / 2)
+// | h1 = nb - h0 over the two row halves; block b < 5 of the accumulator array is block b of half 0, block b >= 5 block b - 5 of
+// half 1 (uniform branches skip the blocks a shorter tile does not have).
+// Needs K >= 2 K-steps, N % 8 == 0.
 // ---------------------------------------------------------------------------------------------------------------
 struct RStream {
-  static constexpr int TM = 7, TN = 4, NT = 512;
-  static constexpr int XB = 32 * TM * 128, WB = 256 * 128, STAGE = XB + WB;   // 224 activation rows + 256 weight rows of 64 k
+  static constexpr int TM = 10, H = 5, TN = 4, NT = 512;
+  static constexpr int XB = 32 * TM * 128, WB = 256 * 128, STAGE = XB + WB;   // 320 activation rows + 256 weight rows of 64 k
   static constexpr int BIAS_OFF = 2 * STAGE, RED_OFF = BIAS_OFF + 256 * 4;
-  static constexpr int SMEM = RED_OFF + 4 * 32 * TM * 8;                      // + [4 column waves][224 rows] (sum, sumsq)
+  static constexpr int SMEM = RED_OFF + 4 * 32 * TM * 8;                      // + [4 column waves][320 rows] (sum, sumsq)
+  static_assert(SMEM <= 160 * 1024, "row-range kernel LDS");
 };
-
-__device__ __forceinline__ void rs_wait_reads(f16x8 (&w)[4], f16x8 (&x)[RStream::TM]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]));
-}
 
 __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, const int groups, const int pairs) {
   using R = RStream;
-  constexpr int TM = R::TM, TN = R::TN, NT = R::NT;
+  constexpr int TM = R::TM, H = R::H, TN = R::TN;
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1527,7 +1522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
   const int r16 = lane & 15, g4 = lane >> 4;
   const int nk = a.K / BK;
 
-  // ---- this workgroup's unit: logical id u (contiguous ranges of ids per XCD label, as tile_coords) -> (row range g, column tile t)
+  // ---- this workgroup's unit: logical id u (contiguous ranges of ids per XCD label, as tile_coords) -> (row range g, column tile tn)
   int u;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
@@ -1536,9 +1531,9 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
   const int g = u / a.tiles_n, tn = u - g * a.tiles_n;
   const int n0 = tn * 256;
   const int p_lo = (int)((int64_t)g * pairs / groups), p_hi = (int)((int64_t)(g + 1) * pairs / groups);
-  const int len = p_hi - p_lo;                              // >= 4 (launcher)
+  const int len = p_hi - p_lo;                              // >= 1 (launcher)
   const int n_tiles = (len + TM - 1) / TM, nb_base = len / n_tiles, nb_rem = len - nb_base * n_tiles;
-  // tile k of the range: nb = nb_base + (k < nb_rem) pairs, the taller tiles first (the last tile's epilogue is the exposed one)
+  // tile k of the range: nb = nb_base + (k < nb_rem) pairs, the taller tiles first
   auto tile_nb = [&](int k) { return nb_base + (k < nb_rem ? 1 : 0); };
   auto tile_m0 = [&](int k) { return (p_lo + k * nb_base + (k < nb_rem ? k : nb_rem)) * 32; };
 
@@ -1553,24 +1548,22 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     return r;
   };
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);   // rows >= N read as zero
-  auto x_piece = [&](auto p_tag, const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf, int kt) {
+  // piece P = 0..4: activations (only the rows this tile has), 5..8: weights
+  auto piece = [&](auto p_tag, const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf, int kt) {
     constexpr int P = decltype(p_tag)::value;
-    if (64 * P + wave * 8 < 32 * nbx)   // uniform: rows of this tile only
-      CLIPMI_BUFFER_LOAD_LDS16(xrs, smem + buf * R::STAGE + P * 8192 + wave * 1024, row_off(xoff0, P * xstep), kt * BK * 2);
+    if constexpr (P < 5) {
+      if (64 * P + wave * 8 < 32 * nbx)   // uniform
+        CLIPMI_BUFFER_LOAD_LDS16(xrs, smem + buf * R::STAGE + P * 8192 + wave * 1024, row_off(xoff0, P * xstep), kt * BK * 2);
+    } else {
+      CLIPMI_BUFFER_LOAD_LDS16(wrs, smem + buf * R::STAGE + R::XB + (P - 5) * 8192 + wave * 1024, row_off(woff0, (P - 5) * wstep), kt * BK * 2);
+    }
   };
-  auto w_piece = [&](auto p_tag, auto partner_tag, int buf, int kt) {
-    constexpr int P = decltype(p_tag)::value;
-    constexpr int PARTNER = decltype(partner_tag)::value ? 1 : 0;   // the piece of wave + 4: 32 rows further, same chunk swizzle
-    CLIPMI_BUFFER_LOAD_LDS16(wrs, smem + buf * R::STAGE + R::XB + P * 8192 + (wave + 4 * PARTNER) * 1024,
-                             row_off(woff0, P * wstep + PARTNER * (wstep / 2)), kt * BK * 2);
-  };
-  constexpr std::false_type own{};
-  constexpr std::true_type partner{};
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  auto stage_all = [&](const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf) {   // a tile's first stage: every wave its own eight pieces
-    x_piece(I0{}, xrs, nbx, buf, 0); x_piece(I1{}, xrs, nbx, buf, 0); x_piece(I2{}, xrs, nbx, buf, 0); x_piece(I3{}, xrs, nbx, buf, 0);
-    w_piece(I0{}, own, buf, 0); w_piece(I1{}, own, buf, 0); w_piece(I2{}, own, buf, 0); w_piece(I3{}, own, buf, 0);
+  auto stage_all = [&](const __amdgpu_buffer_rsrc_t& xrs, int nbx, int buf) {   // a tile's first stage: every wave its nine pieces
+    piece(std::integral_constant<int, 0>{}, xrs, nbx, buf, 0); piece(std::integral_constant<int, 1>{}, xrs, nbx, buf, 0);
+    piece(std::integral_constant<int, 2>{}, xrs, nbx, buf, 0); piece(std::integral_constant<int, 3>{}, xrs, nbx, buf, 0);
+    piece(std::integral_constant<int, 4>{}, xrs, nbx, buf, 0); piece(std::integral_constant<int, 5>{}, xrs, nbx, buf, 0);
+    piece(std::integral_constant<int, 6>{}, xrs, nbx, buf, 0); piece(std::integral_constant<int, 7>{}, xrs, nbx, buf, 0);
+    piece(std::integral_constant<int, 8>{}, xrs, nbx, buf, 0);
   };
 
   // ---- fragment read offsets
@@ -1579,16 +1572,22 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
   const uint32_t f0 = (uint32_t)(r16 * 128 + (((0 + g4) ^ swz) << 4)), f1 = (uint32_t)(r16 * 128 + (((4 + g4) ^ swz) << 4));
   const uint32_t wb = (uint32_t)(R::XB + wave_n * 64 * 128);
 
-  // ---- slots: store / load layout of a 16 x 64 slice (see gemm_stream_kernel: v_permlane16_swap on block pairs -> 8 consecutive
-  // columns per lane, two 16-byte accesses per slice).  voffset = lane part + scalar part; out-of-range = dropped / zero.
+  // ---- 16 x 64 slices of this wave's part: store / load layout (gemm_stream_kernel: v_permlane16_swap on block pairs -> 8 consecutive
+  // columns per lane, two 16-byte accesses per slice).  voffset = lane part + scalar part; out of range = dropped / zero.
   half_t* x16 = a.x16;
   const int lcol = (g4 & 1) * 16 + (g4 >> 1) * 8;
   const int st_lane = (r16 * (int)a.ldo + lcol) * 2;
   const int slice_bytes = 16 * (int)a.ldo * 2;
   const bool col_ok[2] = {n0 + wave_n * 64 + lcol < a.N, n0 + wave_n * 64 + lcol + 32 < a.N};
-  auto slot_voff = [&](int nbx, int j, int pp) {   // rows 16 j .. of this wave's part (which starts at row wave_m * 16 nbx) of a tile of nbx pairs
-    const int in_range = row_off(st_lane, (wave_m * 16 * nbx * (int)a.ldo + wave_n * 64) * 2 + j * slice_bytes + pp * 64);
-    return (j < nbx && col_ok[pp]) ? in_range : (int)0xFFFFFFF0;
+  // accumulator block b of a tile of nbx pairs: half 0 holds h0 = ceil(nbx / 2) blocks (b = 0 .. h0 - 1), half 1 the other nbx - h0
+  // (b = 5 ..); position = its index among the wave's nbx live blocks, i.e. rows 16 pos .. of the wave's part, which starts at row
+  // wave_m * 16 nbx of the tile
+  // (a tile has nbx >= 8 pairs, so only blocks 4 and 9 can be absent; nbx = 0 stands for "no tile": nothing is live)
+  auto blk_live = [&](int nbx, int b) { return nbx > 0 && (b < H ? b < (nbx + 1) / 2 : b - H < nbx / 2); };
+  auto blk_pos = [&](int nbx, int b) { return b < H ? b : (nbx + 1) / 2 + b - H; };
+  auto slice_voff = [&](int nbx, int b, int pp) {
+    const int in_range = row_off(st_lane, ((wave_m * nbx + blk_pos(nbx, b)) * 16 * (int)a.ldo + wave_n * 64) * 2 + pp * 64);
+    return (blk_live(nbx, b) && col_ok[pp]) ? in_range : (int)0xFFFFFFF0;
   };
   auto tile_rsrc = [&](int m0x) { return make_rsrc(x16 + (int64_t)m0x * a.ldo + n0, ((int64_t)(a.M - m0x) * a.ldo - n0) * 2); };
   auto pack_slice = [&](const f16x4 (&v)[TN], u32x4 (&o)[2]) {
@@ -1610,126 +1609,124 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     }
   };
 
-  // ---- first tile: bias of this unit's 256 columns (once), stage 0
+  f32x4 acc[TN][TM];
+  u32x4 rin[2][TM];   // residual slices of the tile about to start, as loaded
+  auto load_residual = [&](const __amdgpu_buffer_rsrc_t& rrs, int nbx, int b) {
+    rin[0][b] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slice_voff(nbx, b, 0), 0, 0);
+    rin[1][b] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slice_voff(nbx, b, 1), 0, 0);
+  };
+  // acc[.][b] = bias + residual of block b of a tile of nbx pairs.  The compiler tracks the loads behind rin and puts its own counted
+  // vmcnt in front of the first use (VMEM returns in order), so a block can be preloaded while younger stores / loads are in flight.
+  auto load_bias = [&](f32x4 (&bb)[TN]) {   // pinned LDS reads (the compiler would put a vmcnt(0) in front of an ordinary one)
+    const uint32_t ba = lds_base + (uint32_t)(R::BIAS_OFF + (wave_n * 64 + g4 * 4) * 4);
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba));
+  };
+  auto preload_block = [&](const f32x4 (&bb)[TN], int nbx, int b) {
+    if (blk_live(nbx, b)) {   // uniform
+      const u32x4 hv[2] = {rin[0][b], rin[1][b]};
+      f16x4 res[TN];
+      unpack_slice(hv, res);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) acc[i][b] = bb[i] + f32x4{(float)res[i][0], (float)res[i][1], (float)res[i][2], (float)res[i][3]};
+    } else {
+      // a block this tile does not have: no MFMA touches it, but without a definition on this path the previous tile's values
+      // would stay live across the whole tile end (and with them all 160 accumulator registers)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) asm volatile("" : "=v"(acc[i][b]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- first tile: bias of this unit's 256 columns (once), stage 0, residual
   int kt_tile = 0;
   int m0 = tile_m0(0), nb = tile_nb(0);
   __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  __amdgpu_buffer_rsrc_t rrs = tile_rsrc(m0);      // residual of the current tile
-  __amdgpu_buffer_rsrc_t ors = make_rsrc(x16, 0);   // outputs of the previous tile: none yet (zero bytes: every store is dropped)
-  int nb_prev = 0;
+  __amdgpu_buffer_rsrc_t ors = tile_rsrc(m0);   // this tile's rows of the stream: residual in, sums out
   int first_buf = 0;
   if (wave == 0) {
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(a.bias + n0, (int64_t)(a.N - n0) * 4);
     CLIPMI_BUFFER_LOAD_LDS16(brs, smem + R::BIAS_OFF, lane * 16, 0);
   }
   stage_all(xrs, nb, 0);
-
-  u32x4 held[2][TM];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) held[p][j] = u32x4{0u, 0u, 0u, 0u};
-  f32x4 acc[TN][TM];
-#ifdef CLIPMI_TUNING
-  // part timers (diagnostic build): lane 0 of waves 0 and 4 sums, over a tile's K loop, the shader-clock time of: issuing its load part |
-  // the LDS wait | the vmcnt wait | the barrier behind the load part | its compute part | the vmcnt wait behind it | the barrier behind
-  // that; written to stamps[(4096 + 4 u + tile) * 8 ..] (group 0) / stamps[(6144 + 4 u + tile) * 8 ..] (group 1)
-  long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
-  const bool timer = a.stamps != nullptr && lane == 0 && (wave & 3) == 0;
-#define RS_T() (timer ? (long long)__builtin_amdgcn_s_memtime() : 0ll)
-#else
-#define RS_T() 0ll
-#endif
-
-  auto kstep = [&](auto slot_tag, auto first_tag, auto more_tag, int kt) {
-    constexpr int SLOT = decltype(slot_tag)::value;       // >= 0: this K-step carries slot SLOT (previous tile's outputs out, this tile's residual in)
-    constexpr bool FIRSTK = decltype(first_tag)::value;   // the accumulators start at 0
-    constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
-    constexpr int NOPS = SLOT >= 0 ? 4 : 0;               // VMEM operations issued behind the pieces
-    static_assert(SLOT < 0 || MORE, "slots ride on K-steps that prefetch");
-    const int buf = (first_buf + kt) & 1;
-    const uint32_t sb = lds_base + (uint32_t)(buf * R::STAGE);
-    const uint32_t xbase = sb + (uint32_t)(wave_m * nb * 16 * 128);
-    const uint32_t xa0 = xbase + f0, xa1 = xbase + f1, wa0 = sb + wb + f0, wa1 = sb + wb + f1;
-    f16x8 wf[4], xw[TM];
-    auto phase = [&](auto ks_tag) {
-      constexpr int KS = decltype(ks_tag)::value;
-      // ---- load part
-      [[maybe_unused]] const long long t0 = RS_T();
-      {
-        const uint32_t xa = KS ? xa1 : xa0, wa = KS ? wa1 : wa0;
-        ds_read128<0>(wf[0], wa); ds_read128<2048>(wf[1], wa); ds_read128<4096>(wf[2], wa); ds_read128<6144>(wf[3], wa);
-        ds_read128<0 * 2048>(xw[0], xa); ds_read128<1 * 2048>(xw[1], xa); ds_read128<2 * 2048>(xw[2], xa); ds_read128<3 * 2048>(xw[3], xa);
-        if (nb > 4) ds_read128<4 * 2048>(xw[4], xa);
-        if (nb > 5) ds_read128<5 * 2048>(xw[5], xa);
-        if (nb > 6) ds_read128<6 * 2048>(xw[6], xa);
-      }
-      if constexpr (MORE) {
-        if constexpr (KS == 0) {
-          x_piece(I0{}, xrs, nb, buf ^ 1, kt + 1); x_piece(I1{}, xrs, nb, buf ^ 1, kt + 1);
-          x_piece(I2{}, xrs, nb, buf ^ 1, kt + 1); x_piece(I3{}, xrs, nb, buf ^ 1, kt + 1);
-          w_piece(I0{}, own, buf ^ 1, kt + 1); w_piece(I1{}, own, buf ^ 1, kt + 1);
-        } else if (grp == 0) {
-          w_piece(I2{}, own, buf ^ 1, kt + 1); w_piece(I3{}, own, buf ^ 1, kt + 1);
-          w_piece(I2{}, partner, buf ^ 1, kt + 1); w_piece(I3{}, partner, buf ^ 1, kt + 1);
-        }
-      }
-      if constexpr (KS == 1 && SLOT >= 0) {
-        __builtin_amdgcn_raw_buffer_store_b128(held[0][SLOT], ors, slot_voff(nb_prev, SLOT, 0), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(held[1][SLOT], ors, slot_voff(nb_prev, SLOT, 1), 0, 0);
-        held[0][SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slot_voff(nb, SLOT, 0), 0, 0);
-        held[1][SLOT] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slot_voff(nb, SLOT, 1), 0, 0);
-      }
-      [[maybe_unused]] const long long t0b = RS_T();
-      rs_wait_reads(wf, xw);
-      [[maybe_unused]] const long long t0c = RS_T();
-      if constexpr (KS == 1) {
-        if (grp == 1) wait_vmcnt<NOPS>();   // this wave's pieces of the next stage (issued in its ks 0 load part) have landed
-      }
-      [[maybe_unused]] const long long t1 = RS_T();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      [[maybe_unused]] const long long t2 = RS_T();
-      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        if (j < 4 || j < nb) {   // uniform: blocks 0..3 always exist
-#pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            if constexpr (FIRSTK && KS == 0)
-              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
-            else
-              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xw[j]));
-          }
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      [[maybe_unused]] const long long t3 = RS_T();
-      if constexpr (KS == 1) {
-        if (grp == 0) wait_vmcnt<NOPS>();
-      }
-      [[maybe_unused]] const long long t3b = RS_T();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef CLIPMI_TUNING
-      if (timer) {
-        const long long t4 = (long long)__builtin_amdgcn_s_memtime();
-        tm[0] += t0b - t0; tm[1] += t0c - t0b; tm[2] += t1 - t0c; tm[3] += t2 - t1; tm[4] += t3 - t2; tm[5] += t3b - t3; tm[6] += t4 - t3b;
-      }
-#endif
-    };
-    phase(I0{});
-    phase(I1{});
-  };
-
+  for (int b = 0; b < TM; ++b) load_residual(ors, nb, b);
 #ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first tile's stage 0 and the bias
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the bias, the residual
   __builtin_amdgcn_s_barrier();
+  {
+    f32x4 bb[TN];
+    load_bias(bb);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) preload_block(bb, nb, b);
+  }
+
+  auto kstep = [&](auto more_tag, int kt) {
+    constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
+    const int buf = (first_buf + kt) & 1;
+    const int h0 = (nb + 1) >> 1, h1 = nb >> 1;
+    const uint32_t sb = lds_base + (uint32_t)(buf * R::STAGE);
+    const uint32_t xlo = sb + (uint32_t)(wave_m * nb * 16 * 128), xhi = xlo + (uint32_t)(h0 * 2048);
+    const uint32_t wa0 = sb + wb + f0, wa1 = sb + wb + f1;
+    f16x8 wf[4], xf[H];
+    auto phase = [&](auto p_tag) {
+      constexpr int P = decltype(p_tag)::value;
+      constexpr int KS = P >> 1, JH = P & 1;
+      const int hc = JH ? h1 : h0;   // live blocks of this half (uniform)
+      // ---- load part
+      {
+        const uint32_t xa = (JH ? xhi : xlo) + (KS ? f1 : f0);
+        // all five reads, whatever the half holds: a fragment register that one path leaves undefined would stay live across the whole
+        // tile loop (16 registers the tile end needs); the surplus read costs one LDS access per phase in a 9-pair tile
+        ds_read128<0 * 2048>(xf[0], xa); ds_read128<1 * 2048>(xf[1], xa); ds_read128<2 * 2048>(xf[2], xa);
+        ds_read128<3 * 2048>(xf[3], xa); ds_read128<4 * 2048>(xf[4], xa);
+        if constexpr (JH == 0) {
+          const uint32_t wa = KS ? wa1 : wa0;
+          ds_read128<0>(wf[0], wa); ds_read128<2048>(wf[1], wa); ds_read128<4096>(wf[2], wa); ds_read128<6144>(wf[3], wa);
+        }
+      }
+      if constexpr (MORE && P < 3) {
+        piece(std::integral_constant<int, P * 3 + 0>{}, xrs, nb, buf ^ 1, kt + 1);
+        piece(std::integral_constant<int, P * 3 + 1>{}, xrs, nb, buf ^ 1, kt + 1);
+        piece(std::integral_constant<int, P * 3 + 2>{}, xrs, nb, buf ^ 1, kt + 1);
+      }
+      if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
+      lgkm_wait_x<0, H>(xf);
+      if constexpr (P == 3) {
+        if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
+      __builtin_amdgcn_s_setprio(1);
+      // tiles have nb >= 8 (launcher): the first four blocks of either half always exist and run back to back; one uniform branch
+      // guards the fifth (a branch in front of every block cost ~8 % of the loop: 2.0 us against 1.7 us per K-step of a 320-row tile)
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        if (j < H - 1 || hc == H) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if constexpr (P == 3) {
+        if (grp == 0) wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+  };
+
   while (true) {
 #ifdef CLIPMI_TUNING
     long long* sp = a.stamps + ((size_t)u * 4 + (kt_tile < 3 ? kt_tile : 3)) * 8;
@@ -1737,97 +1734,79 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
 #endif
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
-    using NS = std::integral_constant<int, -1>;
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // VALU-written accumulators -> the first asm MFMA that reads them
     if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 start one part later
-    kstep(std::integral_constant<int, 0>{}, yes, yes, 0);
+    kstep(yes, 0);                                 // nk >= 2 (launcher)
 #ifdef CLIPMI_TUNING
     if (stamp) { sp[1] = (long long)__builtin_amdgcn_s_memrealtime(); sp[6] = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
-    kstep(std::integral_constant<int, 1>{}, no, yes, 1);
-    kstep(std::integral_constant<int, 2>{}, no, yes, 2);
-    kstep(std::integral_constant<int, 3>{}, no, yes, 3);
-    kstep(std::integral_constant<int, 4>{}, no, yes, 4);
-    kstep(std::integral_constant<int, 5>{}, no, yes, 5);
-    kstep(std::integral_constant<int, 6>{}, no, yes, 6);
-    for (int kt = 7; kt < nk - 1; ++kt) kstep(NS{}, no, yes, kt);   // nk >= 8 (launcher)
-    kstep(NS{}, no, no, nk - 1);
+    for (int kt = 1; kt < nk - 1; ++kt) kstep(yes, kt);
+    kstep(no, nk - 1);
     if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
 #ifdef CLIPMI_TUNING
     if (stamp) { sp[2] = (long long)__builtin_amdgcn_s_memrealtime(); sp[7] = (long long)__builtin_amdgcn_s_memtime(); }
-    if (timer) {
-      long long* tp = a.stamps + ((size_t)(grp ? 6144 : 4096) + (size_t)u * 4 + (kt_tile < 3 ? kt_tile : 3)) * 8;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) { tp[i] = tm[i]; tm[i] = 0; }
-      tp[7] = nb;
-    }
 #endif
 
-    // ---- tile end.  Every residual slice of this tile sits in its slot (loaded in K-steps 0..6, covered by the counted wait of
-    // the K-step after); nothing of the next tile has been issued yet.
+    // ---- tile end: nothing is in flight (the last K-step waited for everything).  Order of issue: the next tile's first stage and
+    // residual FIRST, this tile's stores LAST, so that one counted wait covers exactly the former.
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cnb = nb;
     const bool has_next = kt_tile + 1 < n_tiles;
-    int m0n = m0, nbn = nb;
-    __amdgpu_buffer_rsrc_t xrs_n = xrs;
+    int m0n = m0, nbn = 0;
+    __amdgpu_buffer_rsrc_t xrs_n = xrs, ors_n = ors;
     if (has_next) {
       m0n = tile_m0(kt_tile + 1);
       nbn = tile_nb(kt_tile + 1);
       xrs_n = make_rsrc(a.A + (int64_t)m0n * a.lda, ((int64_t)(a.M - m0n) * a.lda) * 2);
+      ors_n = tile_rsrc(m0n);
       first_buf = last_buf ^ 1;   // the buffer that was NOT read last is free
+      stage_all(xrs_n, nbn, first_buf);
     }
-    {
-      // every slot's residual landed K-steps ago; telling the compiler so HERE (it tracks the loads, not the counted waits) keeps its
-      // own vmcnt out of the slice loop below, where it would wait for the next tile's pieces
-      asm volatile("" : "+v"(held[0][0]), "+v"(held[0][1]), "+v"(held[0][2]), "+v"(held[0][3]), "+v"(held[0][4]), "+v"(held[0][5]), "+v"(held[0][6]),
-                        "+v"(held[1][0]), "+v"(held[1][1]), "+v"(held[1][2]), "+v"(held[1][3]), "+v"(held[1][4]), "+v"(held[1][5]), "+v"(held[1][6]));
-      // bias of this lane's columns: pinned LDS reads (the compiler would put a vmcnt(0) in front of an ordinary one)
-      f32x4 bb[TN];
-      const uint32_t ba = lds_base + (uint32_t)(R::BIAS_OFF + (wave_n * 64 + g4 * 4) * 4);
-      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\t"
-                   "s_waitcnt lgkmcnt(0)"
-                   : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba));
-      const uint32_t red_lane = lds_base + (uint32_t)(R::RED_OFF + (wave_n * 32 * TM + wave_m * 16 * cnb + r16) * 8);
+    // Per slice, in this order: the slice is converted, its two stores are issued, and the residual of the SAME slice of the NEXT
+    // tile is requested -- into the registers the slice's accumulators have just left: the live set only shrinks (holding the packed
+    // slices back so that the stores are the youngest operations of the queue, or requesting the residual ahead of the conversion,
+    // needs more registers than the allocator finds: it spilled the residual behind a vmcnt(0)).  nbn = 0 (no next tile): every
+    // load offset is out of range, nothing is fetched.
+    // LAG slices later -- its residual has had that long to arrive -- block b - LAG of the NEXT tile is preloaded into its (dead)
+    // accumulators: at most LAG loaded slices wait in registers instead of all ten.
+    constexpr int LAG = 4;
+    f32x4 bb[TN];
+    load_bias(bb);
+    const uint32_t red_lane = lds_base + (uint32_t)(R::RED_OFF + (wave_n * 32 * TM + wave_m * 16 * cnb + r16) * 8);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        if (j < cnb) {   // uniform
-          u32x4 hv[2] = {held[0][j], held[1][j]};
-          f16x4 res[TN];
-          unpack_slice(hv, res);
-          f16x4 cv[TN];
-          float rsum = 0.f, rsq = 0.f;
+    for (int b = 0; b < TM; ++b) {
+      if (blk_live(cnb, b)) {   // uniform
+        f16x4 cv[TN];
+        float rsum = 0.f, rsq = 0.f;
 #pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            f32x4 v = acc[i][j] + bb[i] + f32x4{(float)res[i][0], (float)res[i][1], (float)res[i][2], (float)res[i][3]};
-            cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            v = f32x4{(float)cv[i][0], (float)cv[i][1], (float)cv[i][2], (float)cv[i][3]};   // the partials are those of the ROUNDED row
-            fold_row_sums(v, rsum, rsq);
-          }
-          rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
-          rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
-          if (g4 == 0) {
-            const float2 pr = make_float2(rsum, rsq);
-            asm volatile("ds_write_b64 %0, %1" ::"v"(red_lane + (uint32_t)(j * 128)), "v"(pr) : "memory");   // row 16 j + r16 of this wave's part
-          }
-          pack_slice(cv, hv);
-          held[0][j] = hv[0];
-          held[1][j] = hv[1];
+        for (int i = 0; i < TN; ++i) {
+          const f32x4 v = acc[i][b];
+          cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          fold_row_sums16(cv[i], rsum, rsq);   // the partials are those of the ROUNDED row
         }
-        if (has_next) {   // the next tile's first stage, two pieces behind each of the first four slices
-          if (j == 0) { x_piece(I0{}, xrs_n, nbn, first_buf, 0); x_piece(I1{}, xrs_n, nbn, first_buf, 0); }
-          if (j == 1) { x_piece(I2{}, xrs_n, nbn, first_buf, 0); x_piece(I3{}, xrs_n, nbn, first_buf, 0); }
-          if (j == 2) { w_piece(I0{}, own, first_buf, 0); w_piece(I1{}, own, first_buf, 0); }
-          if (j == 3) { w_piece(I2{}, own, first_buf, 0); w_piece(I3{}, own, first_buf, 0); }
+        rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
+        rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+        if (g4 == 0) {
+          const float2 pr = make_float2(rsum, rsq);
+          asm volatile("ds_write_b64 %0, %1" ::"v"(red_lane + (uint32_t)(blk_pos(cnb, b) * 128)), "v"(pr) : "memory");   // row 16 pos + r16 of this wave's part
         }
-        __builtin_amdgcn_sched_barrier(0);   // one slice at a time: the accumulators die as they are converted
+        u32x4 o[2];
+        pack_slice(cv, o);
+        __builtin_amdgcn_raw_buffer_store_b128(o[0], ors, slice_voff(cnb, b, 0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[1], ors, slice_voff(cnb, b, 1), 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // one slice at a time: the accumulators die as they are converted
+      load_residual(ors_n, nbn, b);
+      __builtin_amdgcn_sched_barrier(0);
+      if (b >= LAG) preload_block(bb, nbn, b - LAG);
     }
-    ors = rrs;   // this tile's slots leave through its own descriptor during the next K loop (or behind the loop)
-    nb_prev = cnb;
 #ifdef CLIPMI_TUNING
     if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next tile's stage 0; this wave's row partials are in LDS
+    // the next tile's stage 0 and residual have landed (and, the queue being in order, this tile's stores are out); this wave's row
+    // partials are in LDS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef CLIPMI_TUNING
     if (stamp) sp[4] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1852,28 +1831,28 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     m0 = m0n;
     nb = nbn;
     xrs = xrs_n;
-    rrs = tile_rsrc(m0);
-  }
-  // the last tile's slots: nothing left to hide them behind
+    ors = ors_n;
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    __builtin_amdgcn_raw_buffer_store_b128(held[0][j], ors, slot_voff(nb_prev, j, 0), 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(held[1][j], ors, slot_voff(nb_prev, j, 1), 0, 0);
+    for (int b = TM - LAG; b < TM; ++b) preload_block(bb, nb, b);
   }
 }
 
-#undef RS_T
 
-// the row-range kernel takes a shape when every range holds at least two tiles' worth of pairs (below that nothing is streamed:
-// the one-tile-per-workgroup kernel is the better fit) -- or, forced (gemm_variant = 16), at least one tile of four pairs
-inline bool rstream_fits(const KArgs& k, bool forced) {
+// the row-range kernel takes a shape when every range splits into tiles of 8 .. 10 pairs of rows (its K loop runs the first four
+// blocks of a row half unconditionally): ranges of 8-10, 16-20, 24-30 or >= 32 pairs
+inline bool rstream_fits(const KArgs& k) {
   const int n_cu = device_cus() & ~7;
   const int tiles_n = (k.N + 255) / 256;
   if (n_cu < 8 || tiles_n > n_cu || tiles_n > LN_MAX_PARTS) return false;
   const int groups = n_cu / tiles_n;
   const int64_t pairs = ((int64_t)k.M + 31) / 32;
-  if (!(k.K >= 8 * BK && (k.N & 7) == 0 && (k.ldo & 7) == 0 && stream_offsets_ok(k))) return false;
-  return pairs >= (forced ? 4 : 8) * (int64_t)groups;
+  if (!(k.K >= 2 * BK && (k.N & 7) == 0 && (k.ldo & 7) == 0 && stream_offsets_ok(k))) return false;
+  for (int64_t len = pairs / groups; len <= (pairs + groups - 1) / groups; ++len) {   // the two range lengths that occur
+    if (len < 8) return false;
+    const int64_t n_tiles = (len + RStream::TM - 1) / RStream::TM;
+    if (len / n_tiles < 8) return false;
+  }
+  return true;
 }
 
 int launch_rstream(KArgs k, hipStream_t s) {
@@ -2080,7 +2059,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   if constexpr (EPI == EPI_RESIDUAL_FOLD16) {
     // fp16-stream residual GEMMs whose row ranges hold at least two tiles each: the persistent row-range kernel
     const bool want = variant == 16 || (!forced && options().gemm_rstream.load(std::memory_order_relaxed) == 1);
-    if (want && rstream_fits(k, variant == 16)) {
+    if (want && rstream_fits(k)) {
       *parts_out = (k.N + 255) / 256;
       return launch_rstream(k, s);
     }

@@ -322,13 +322,12 @@ def test_vit_large_towers_vs_oracle(gname, batch):
 
 
 @pytest.mark.parametrize("batch", [256, 300, 160, 131])
-def test_row_range_residual_kernel_bit_identical_in_tower(clipmi_option, batch):
+def test_row_range_residual_kernel_in_tower(clipmi_option, batch):
     """gemm_rstream_kernel (option gemm_rstream = 1, the default for the fp16-stream residual GEMMs out-proj / c_proj) against the
-    one-tile-per-workgroup kernel (gemm_rstream = 0).  Only the partition of the rows over workgroups and the moment the residual
-    rows are read and the sums stored change -- every output element and every LayerNorm row partial is the same K-ordered /
-    column-ordered sum -- so the image features must be bit-identical: batch 256 (85 ranges of 18-19 pairs: tiles of 7 + 6 + 6),
-    300 (22-23 pairs: four tiles), 160 (11-12 pairs: two tiles), 131 (M = 25807, a ragged last pair), twice each to screen for a
-    race on the slots between consecutive tiles."""
+    one-tile-per-workgroup kernel (gemm_rstream = 0).  The row-range kernel starts a tile from bias + residual and adds the products
+    on top -- the same fp32 terms in another order, one rounding to fp16 -- so the image features agree to a few 1e-6 in cosine
+    (against 1e-3 of tolerance), and are bit-identical run to run: batch 256 (85 ranges of 18-19 pairs: tiles of 10 + 9 / 9 + 9), 300
+    (22-23 pairs: three tiles), 160 (11-12 pairs: two tiles of 6), 131 (M = 25807, one tile per workgroup, a ragged last pair)."""
     sd, model = _build("ViT-B/16")
     images = syn.synthetic_images(batch, "ViT-B/16", seed=9).cuda()
     with torch.no_grad():
@@ -338,13 +337,15 @@ def test_row_range_residual_kernel_bit_identical_in_tower(clipmi_option, batch):
         a = model.image_features_f32(images).clone()
         b = model.image_features_f32(images).clone()
     assert torch.isfinite(a).all()
-    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+    assert torch.equal(a, b), f"run-to-run max diff {float((a - b).abs().max())}"
+    an, rn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(ref, dim=1)
+    assert float((an - rn).abs().max()) < 5e-5 and float((1 - (an * rn).sum(1)).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("n_prompts", [1000, 700])
 def test_row_range_residual_kernel_text_tower(n_prompts):
     """The same on the text tower's shapes with the fp16 stream asked for per call (CLIPMI_CALL_STREAM_F16): N = 512 is two column
-    tiles (128 row ranges), K = 512 is the shortest K loop the kernel takes (8 K-steps: slot 6 rides on the last prefetching one)."""
+    tiles (128 row ranges of 18-19 pairs), K = 512 and 2048."""
     from clip_calibration_amd import _lib
     sd, model = _build("ViT-B/16")
     ids = syn.synthetic_token_ids(n_prompts, "ViT-B/16", seed=4).cuda()
@@ -355,7 +356,9 @@ def test_row_range_residual_kernel_text_tower(n_prompts):
         b = model.text_features_f32(ids, flags=_lib.CALL_STREAM_F16).clone()
         f32 = model.text_features_f32(ids).clone()
     assert torch.isfinite(a).all()
-    assert torch.equal(a, ref) and torch.equal(b, ref), f"max diff {float((a - ref).abs().max())}"
+    assert torch.equal(a, b), f"run-to-run max diff {float((a - b).abs().max())}"
+    an, rn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(ref, dim=1)
+    assert float((1 - (an * rn).sum(1)).abs().max()) < 2e-6
     assert not torch.equal(a, f32)                                # the flag does select the fp16 stream
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic (never a benchmark): per-tile stamps and part timers of gemm_rstream_kernel as the image tower launches it
-(out-proj = step 2, c_proj = step 4 of clipmi_profile_block).  Needs the tuning build:
+"""Diagnostic (never a benchmark): per-tile stamps of gemm_rstream_kernel as the image tower launches it (out-proj = step 2,
+c_proj = step 4 of clipmi_profile_block).  Needs the tuning build:
 
     make -C clip_calibration_amd/csrc tuning
     CLIPMI_LIBRARY=clip_calibration_amd/csrc/libclipmi_tuning.so python tools/rstream_stamps.py
@@ -27,7 +27,6 @@ with torch.no_grad():
     for _ in range(20):
         model.image_features_f32(images)
 torch.cuda.synchronize()
-NK = {"out_proj": 12, "c_proj": 48}
 for name, step in (("out_proj", 2), ("c_proj", 4)):
     stamps = torch.zeros(8192 * 8, dtype=torch.int64, device="cuda")
     model.profile_block_ms(B, iters=3, only=step)
@@ -40,21 +39,15 @@ for name, step in (("out_proj", 2), ("c_proj", 4)):
     live = s[:, 0] > 0
     t0 = s[live, 0].min()
     t = (s[:, :5] - t0) / 100.0
-    print(f"{name}: hipEvents {ms * 1e3:.1f} us; {int(live.sum())} tiles stamped; last tile end {t[live, 4].max():.1f} us")
+    print(f"{name}: hipEvents {ms * 1e3:.1f} us; {int(live.sum())} tiles stamped; first tile start spread {np.ptp(t[live & (np.arange(1024) % 4 == 0), 0]):.2f} us; "
+          f"last tile end (closing barrier) {t[live, 4].max():.1f} us")
     for k in range(4):
         rows = np.arange(k, 1024, 4)
         rows = rows[live[rows]]
         if not len(rows):
             continue
-        tk = t[rows]
-        sk = s[rows]
+        tk, sk = t[rows], s[rows]
         clk = (sk[:, 7] - sk[:, 6]) / np.maximum(sk[:, 2] - sk[:, 1], 1) * 100.0
-        g0 = raw[4096 + rows].astype(np.float64)
-        g1 = raw[6144 + rows].astype(np.float64)
-        nph = 2 * NK[name]
-        print(f"  tile {k}: start med {np.median(tk[:, 0]):6.1f} us | K-step 0 {np.median(tk[:, 1] - tk[:, 0]):5.2f} | K loop rest {np.median(tk[:, 2] - tk[:, 1]):6.2f} "
-              f"| epilogue {np.median(tk[:, 3] - tk[:, 2]):5.2f} | stage-0 wait + barrier {np.median(tk[:, 4] - tk[:, 3]):5.2f} | clock {np.median(clk):.0f} MHz | nb {np.median(g0[:, 7]):.0f}")
-        for gname, gg in (("G0", g0), ("G1", g1)):
-            m = np.median(gg[:, :7], axis=0) / nph
-            print(f"     {gname} per phase (cycles): issue {m[0]:5.0f} | lds wait {m[1]:5.0f} | vmcnt {m[2]:5.0f} | barrier {m[3]:5.0f} | compute {m[4]:5.0f} | vmcnt {m[5]:5.0f} | barrier {m[6]:5.0f}"
-                  f"  = {m.sum():.0f}")
+        print(f"  tile {k}: {len(rows)} tiles | start med {np.median(tk[:, 0]):6.1f} us | K-step 0 {np.median(tk[:, 1] - tk[:, 0]):5.2f} | rest of the K loop {np.median(tk[:, 2] - tk[:, 1]):6.2f} "
+              f"| convert + store + next residual {np.median(tk[:, 3] - tk[:, 2]):5.2f} (p90 {np.percentile(tk[:, 3] - tk[:, 2], 90):5.2f}) "
+              f"| wait + barrier {np.median(tk[:, 4] - tk[:, 3]):5.2f} (p90 {np.percentile(tk[:, 4] - tk[:, 3], 90):5.2f}) | clock {np.median(clk):.0f} MHz")
