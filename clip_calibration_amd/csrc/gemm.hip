@@ -210,6 +210,33 @@ __device__ __forceinline__ void fold_row_sums16(const f16x4& h, float& rsum, flo
   rsq = __builtin_amdgcn_fdot2(hi, hi, __builtin_amdgcn_fdot2(lo, lo, rsq, false), false);
 }
 
+// Sum of a value over the four lanes that hold one row of a 16 x 16 accumulator block (lanes l, l ^ 16, l ^ 32, l ^ 48), valid in the
+// lanes of the first 16-lane row (g4 == 0) -- the only ones that use it.  v_permlane16_swap / v_permlane32_swap of the value with
+// itself bring the partner's copy into the lane: no LDS round trip (__shfl_xor compiles to ds_bpermute: two dependent ~100-cycle
+// trips per sum).  Same association as  v += shfl_xor(v, 16); v += shfl_xor(v, 32)  in those lanes: bit-identical.
+__device__ __forceinline__ float row4_sum(float v) {
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // [0]: rows (0, 0, 2, 2) of v, [1]: rows (1, 1, 3, 3)
+  const float s = __builtin_bit_cast(float, (unsigned int)a[0]) + __builtin_bit_cast(float, (unsigned int)a[1]);
+  const unsigned int w = __builtin_bit_cast(unsigned int, s);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // [0]: lower half of s in both halves, [1]: upper half
+  return __builtin_bit_cast(float, (unsigned int)b[0]) + __builtin_bit_cast(float, (unsigned int)b[1]);
+}
+
+// a += float(h), one v_fma_mix_f32 per element (fp16 source operand, fp32 accumulator: a + h rounded once, the bits of a conversion
+// followed by an add) instead of a conversion and half a packed add -- the residual is added inside the K loop of
+// gemm_rstream_kernel, where every VALU issue slot is taken from the partner wave's MFMAs
+__device__ __forceinline__ void add_f16x4(f32x4& a, const f16x4& h) {
+  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ r = __builtin_bit_cast(u32x2_, h);
+  float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a0) : "v"(r[0]));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a1) : "v"(r[0]));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a2) : "v"(r[1]));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a3) : "v"(r[1]));
+  a = f32x4{a0, a1, a2, a3};
+}
+
 // Producer side of the LayerNorm fold: BIAS_RESIDUAL epilogue that, besides the fp32 read-modify-write of the residual
 // stream, stores fp16(out) to x16 through the wave-private LDS transpose and writes this tile's row partials.
 // Worked in chunks of 32 rows with a scheduling fence between chunks, so that the residual loads of later chunks are
@@ -262,8 +289,8 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
         *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) =
             f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       }
-      rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
-      rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+      rsum = row4_sum(rsum);   // the 4 lanes of a row
+      rsq = row4_sum(rsq);
       if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
     }
 #pragma unroll
@@ -387,8 +414,8 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
         }
         *reinterpret_cast<f16x4*>(p) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       }
-      rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
-      rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+      rsum = row4_sum(rsum);   // the 4 lanes of a row
+      rsq = row4_sum(rsq);
       if (g4 == 0) red[wave_n * T::BM + ml] = make_float2(rsum, rsq);
     }
     // same wave, LDS in order: the reads below see the writes above
@@ -1610,36 +1637,23 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
   };
 
   f32x4 acc[TN][TM];
-  u32x4 rin[2][TM];   // residual slices of the tile about to start, as loaded
-  auto load_residual = [&](const __amdgpu_buffer_rsrc_t& rrs, int nbx, int b) {
-    rin[0][b] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slice_voff(nbx, b, 0), 0, 0);
-    rin[1][b] = __builtin_amdgcn_raw_buffer_load_b128(rrs, slice_voff(nbx, b, 1), 0, 0);
-  };
-  // acc[.][b] = bias + residual of block b of a tile of nbx pairs.  The compiler tracks the loads behind rin and puts its own counted
-  // vmcnt in front of the first use (VMEM returns in order), so a block can be preloaded while younger stores / loads are in flight.
-  auto load_bias = [&](f32x4 (&bb)[TN]) {   // pinned LDS reads (the compiler would put a vmcnt(0) in front of an ordinary one)
+  // bias of this lane's columns: pinned LDS reads (the compiler would put a vmcnt(0) in front of an ordinary one)
+  auto load_bias = [&](f32x4 (&bb)[TN]) {
     const uint32_t ba = lds_base + (uint32_t)(R::BIAS_OFF + (wave_n * 64 + g4 * 4) * 4);
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:192\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba));
   };
-  auto preload_block = [&](const f32x4 (&bb)[TN], int nbx, int b) {
-    if (blk_live(nbx, b)) {   // uniform
-      const u32x4 hv[2] = {rin[0][b], rin[1][b]};
-      f16x4 res[TN];
-      unpack_slice(hv, res);
+  auto start_tile = [&]() {   // acc = bias: the MFMAs add the products on top, the residual arrives during the K loop
+    f32x4 bb[TN];
+    load_bias(bb);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) acc[i][b] = bb[i] + f32x4{(float)res[i][0], (float)res[i][1], (float)res[i][2], (float)res[i][3]};
-    } else {
-      // a block this tile does not have: no MFMA touches it, but without a definition on this path the previous tile's values
-      // would stay live across the whole tile end (and with them all 160 accumulator registers)
+    for (int b = 0; b < TM; ++b)
 #pragma unroll
-      for (int i = 0; i < TN; ++i) asm volatile("" : "=v"(acc[i][b]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < TN; ++i) acc[i][b] = bb[i];
   };
 
-  // ---- first tile: bias of this unit's 256 columns (once), stage 0, residual
+  // ---- first tile: bias of this unit's 256 columns (once), stage 0
   int kt_tile = 0;
   int m0 = tile_m0(0), nb = tile_nb(0);
   __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
@@ -1650,22 +1664,24 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     CLIPMI_BUFFER_LOAD_LDS16(brs, smem + R::BIAS_OFF, lane * 16, 0);
   }
   stage_all(xrs, nb, 0);
-#pragma unroll
-  for (int b = 0; b < TM; ++b) load_residual(ors, nb, b);
 #ifdef CLIPMI_TUNING
   const bool stamp = a.stamps != nullptr && tid == 0;
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the bias, the residual
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0, the bias
   __builtin_amdgcn_s_barrier();
-  {
-    f32x4 bb[TN];
-    load_bias(bb);
-#pragma unroll
-    for (int b = 0; b < TM; ++b) preload_block(bb, nb, b);
-  }
+  start_tile();
 
-  auto kstep = [&](auto more_tag, int kt) {
+  // The residual TRICKLES IN during the tile's own K loop: K-step c (c = 0 .. 4) requests slices 2c, 2c + 1 of this wave's part
+  // (four 16-byte loads into `rin`, issued behind the K-step's pieces and left in flight by its counted wait), K-step c + 1 adds them
+  // to the accumulators in its third load part (the compiler puts its own counted vmcnt in front of the first use: VMEM returns in
+  // order) and re-uses the registers for the next request.
+  u32x4 rin[2][2];
+  constexpr int NCHUNK = TM / 2;
+  auto kstep = [&](auto more_tag, auto req_tag, auto add_tag, int kt) {
     constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
+    constexpr int REQ = decltype(req_tag)::value;         // >= 0: request residual chunk REQ in this K-step
+    constexpr int ADD = decltype(add_tag)::value;         // >= 0: add residual chunk ADD (requested one K-step ago)
+    constexpr int NREQ = REQ >= 0 ? 4 : 0;                // VMEM operations issued behind the pieces
     const int buf = (first_buf + kt) & 1;
     const int h0 = (nb + 1) >> 1, h1 = nb >> 1;
     const uint32_t sb = lds_base + (uint32_t)(buf * R::STAGE);
@@ -1675,7 +1691,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     auto phase = [&](auto p_tag) {
       constexpr int P = decltype(p_tag)::value;
       constexpr int KS = P >> 1, JH = P & 1;
-      const int hc = JH ? h1 : h0;   // live blocks of this half (uniform)
+      const int hc = JH ? h1 : h0;   // live blocks of this half (uniform): 4 or 5
       // ---- load part
       {
         const uint32_t xa = (JH ? xhi : xlo) + (KS ? f1 : f0);
@@ -1693,18 +1709,40 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
         piece(std::integral_constant<int, P * 3 + 1>{}, xrs, nb, buf ^ 1, kt + 1);
         piece(std::integral_constant<int, P * 3 + 2>{}, xrs, nb, buf ^ 1, kt + 1);
       }
+      if constexpr (P == 2 && ADD >= 0) {
+        // the chunk requested a K-step ago: un-swap, add in fp32 (the last MFMA on these blocks was issued at least two parts ago, the
+        // next one follows the barrier below)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int B = 2 * ADD + q;   // a constant after unrolling (ADD is one)
+          if (blk_live(nb, B)) {   // uniform
+            const u32x4 hv[2] = {rin[0][q], rin[1][q]};
+            f16x4 res[TN];
+            unpack_slice(hv, res);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) add_f16x4(acc[i][B], res[i]);
+          }
+        }
+      }
+      if constexpr (P == 3 && REQ >= 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          rin[0][q] = __builtin_amdgcn_raw_buffer_load_b128(ors, slice_voff(nb, 2 * REQ + q, 0), 0, 0);
+          rin[1][q] = __builtin_amdgcn_raw_buffer_load_b128(ors, slice_voff(nb, 2 * REQ + q, 1), 0, 0);
+        }
+      }
       if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
       lgkm_wait_x<0, H>(xf);
       if constexpr (P == 3) {
-        if (grp == 1) wait_vmcnt<0>();   // this wave's pieces of the next stage have landed
+        if (grp == 1) wait_vmcnt<NREQ>();   // this wave's pieces of the next stage have landed (the request behind them may be in flight)
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel)
+      // ---- compute part: registers only, accumulators tied to the destination (see gemm_stream_kernel).  Tiles have nb >= 8
+      // (launcher): the first four blocks of either half always exist and run back to back; one uniform branch guards the fifth (a
+      // branch in front of every block cost ~8 % of the loop: 2.0 us against 1.7 us per K-step of a 320-row tile)
       __builtin_amdgcn_s_setprio(1);
-      // tiles have nb >= 8 (launcher): the first four blocks of either half always exist and run back to back; one uniform branch
-      // guards the fifth (a branch in front of every block cost ~8 % of the loop: 2.0 us against 1.7 us per K-step of a 320-row tile)
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         if (j < H - 1 || hc == H) {
@@ -1715,7 +1753,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (P == 3) {
-        if (grp == 0) wait_vmcnt<0>();
+        if (grp == 0) wait_vmcnt<NREQ>();
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -1734,49 +1772,45 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
 #endif
     constexpr std::false_type no{};
     constexpr std::true_type yes{};
+    using N1 = std::integral_constant<int, -1>;
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // VALU-written accumulators -> the first asm MFMA that reads them
     if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 start one part later
-    kstep(yes, 0);                                 // nk >= 2 (launcher)
+    static_assert(NCHUNK == 5, "five residual chunks ride on K-steps 0..4 and are added in K-steps 1..5");
+    kstep(yes, std::integral_constant<int, 0>{}, N1{}, 0);
 #ifdef CLIPMI_TUNING
     if (stamp) { sp[1] = (long long)__builtin_amdgcn_s_memrealtime(); sp[6] = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
-    for (int kt = 1; kt < nk - 1; ++kt) kstep(yes, kt);
-    kstep(no, nk - 1);
+    kstep(yes, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, 1);
+    kstep(yes, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, 2);
+    kstep(yes, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, 3);
+    kstep(yes, std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{}, 4);
+    kstep(yes, N1{}, std::integral_constant<int, 4>{}, 5);
+    for (int kt = 6; kt < nk - 1; ++kt) kstep(yes, N1{}, N1{}, kt);   // nk >= 7 (launcher)
+    kstep(no, N1{}, N1{}, nk - 1);
     if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
 #ifdef CLIPMI_TUNING
     if (stamp) { sp[2] = (long long)__builtin_amdgcn_s_memrealtime(); sp[7] = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
 
-    // ---- tile end: nothing is in flight (the last K-step waited for everything).  Order of issue: the next tile's first stage and
-    // residual FIRST, this tile's stores LAST, so that one counted wait covers exactly the former.
+    // ---- tile end: nothing is in flight (the last K-step waited for everything), the accumulators hold bias + residual + products.
+    // The next tile's first stage is requested FIRST, the 2 TM stores of this tile follow it: the counted wait below covers exactly
+    // the former, the stores drain under the next tile's K loop.
     const int last_buf = (first_buf + nk - 1) & 1;
     const int cm0 = m0, cnb = nb;
     const bool has_next = kt_tile + 1 < n_tiles;
-    int m0n = m0, nbn = 0;
-    __amdgpu_buffer_rsrc_t xrs_n = xrs, ors_n = ors;
+    int m0n = m0, nbn = nb;
     if (has_next) {
       m0n = tile_m0(kt_tile + 1);
       nbn = tile_nb(kt_tile + 1);
-      xrs_n = make_rsrc(a.A + (int64_t)m0n * a.lda, ((int64_t)(a.M - m0n) * a.lda) * 2);
-      ors_n = tile_rsrc(m0n);
+      xrs = make_rsrc(a.A + (int64_t)m0n * a.lda, ((int64_t)(a.M - m0n) * a.lda) * 2);
       first_buf = last_buf ^ 1;   // the buffer that was NOT read last is free
-      stage_all(xrs_n, nbn, first_buf);
+      stage_all(xrs, nbn, first_buf);
     }
-    // Per slice, in this order: the slice is converted, its two stores are issued, and the residual of the SAME slice of the NEXT
-    // tile is requested -- into the registers the slice's accumulators have just left: the live set only shrinks (holding the packed
-    // slices back so that the stores are the youngest operations of the queue, or requesting the residual ahead of the conversion,
-    // needs more registers than the allocator finds: it spilled the residual behind a vmcnt(0)).  nbn = 0 (no next tile): every
-    // load offset is out of range, nothing is fetched.
-    // LAG slices later -- its residual has had that long to arrive -- block b - LAG of the NEXT tile is preloaded into its (dead)
-    // accumulators: at most LAG loaded slices wait in registers instead of all ten.
-    constexpr int LAG = 4;
-    f32x4 bb[TN];
-    load_bias(bb);
     const uint32_t red_lane = lds_base + (uint32_t)(R::RED_OFF + (wave_n * 32 * TM + wave_m * 16 * cnb + r16) * 8);
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-      if (blk_live(cnb, b)) {   // uniform
+      if (blk_live(cnb, b)) {   // uniform; both arms issue two stores (the operation count behind the pieces stays static)
         f16x4 cv[TN];
         float rsum = 0.f, rsq = 0.f;
 #pragma unroll
@@ -1785,8 +1819,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
           cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
           fold_row_sums16(cv[i], rsum, rsq);   // the partials are those of the ROUNDED row
         }
-        rsum += __shfl_xor(rsum, 16, 64); rsum += __shfl_xor(rsum, 32, 64);   // the 4 lanes of a row
-        rsq += __shfl_xor(rsq, 16, 64); rsq += __shfl_xor(rsq, 32, 64);
+        rsum = row4_sum(rsum);   // the 4 lanes of a row
+        rsq = row4_sum(rsq);
         if (g4 == 0) {
           const float2 pr = make_float2(rsum, rsq);
           asm volatile("ds_write_b64 %0, %1" ::"v"(red_lane + (uint32_t)(blk_pos(cnb, b) * 128)), "v"(pr) : "memory");   // row 16 pos + r16 of this wave's part
@@ -1795,18 +1829,18 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
         pack_slice(cv, o);
         __builtin_amdgcn_raw_buffer_store_b128(o[0], ors, slice_voff(cnb, b, 0), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o[1], ors, slice_voff(cnb, b, 1), 0, 0);
+      } else {
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(z, ors, (int)0xFFFFFFF0, 0, 0);   // out of range: dropped
+        __builtin_amdgcn_raw_buffer_store_b128(z, ors, (int)0xFFFFFFF0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);   // one slice at a time: the accumulators die as they are converted
-      load_residual(ors_n, nbn, b);
-      __builtin_amdgcn_sched_barrier(0);
-      if (b >= LAG) preload_block(bb, nbn, b - LAG);
     }
 #ifdef CLIPMI_TUNING
     if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    // the next tile's stage 0 and residual have landed (and, the queue being in order, this tile's stores are out); this wave's row
-    // partials are in LDS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the next tile's stage 0 has landed (the 2 TM stores behind it may still be on their way); this wave's row partials are in LDS
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * TM) : "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef CLIPMI_TUNING
     if (stamp) sp[4] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1830,13 +1864,10 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     ++kt_tile;
     m0 = m0n;
     nb = nbn;
-    xrs = xrs_n;
-    ors = ors_n;
-#pragma unroll
-    for (int b = TM - LAG; b < TM; ++b) preload_block(bb, nb, b);
+    ors = tile_rsrc(m0);
+    start_tile();
   }
 }
-
 
 // the row-range kernel takes a shape when every range splits into tiles of 8 .. 10 pairs of rows (its K loop runs the first four
 // blocks of a row half unconditionally): ranges of 8-10, 16-20, 24-30 or >= 32 pairs
@@ -1846,7 +1877,7 @@ inline bool rstream_fits(const KArgs& k) {
   if (n_cu < 8 || tiles_n > n_cu || tiles_n > LN_MAX_PARTS) return false;
   const int groups = n_cu / tiles_n;
   const int64_t pairs = ((int64_t)k.M + 31) / 32;
-  if (!(k.K >= 2 * BK && (k.N & 7) == 0 && (k.ldo & 7) == 0 && stream_offsets_ok(k))) return false;
+  if (!(k.K >= 7 * BK && (k.N & 7) == 0 && (k.ldo & 7) == 0 && stream_offsets_ok(k))) return false;
   for (int64_t len = pairs / groups; len <= (pairs + groups - 1) / groups; ++len) {   // the two range lengths that occur
     if (len < 8) return false;
     const int64_t n_tiles = (len + RStream::TM - 1) / RStream::TM;
@@ -2057,8 +2088,11 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
     if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) return launch_stream<EPI>(k, ln_rows, s);
   }
   if constexpr (EPI == EPI_RESIDUAL_FOLD16) {
-    // fp16-stream residual GEMMs whose row ranges hold at least two tiles each: the persistent row-range kernel
-    const bool want = variant == 16 || (!forced && options().gemm_rstream.load(std::memory_order_relaxed) == 1);
+    // fp16-stream residual GEMMs whose row ranges split into tall tiles: the persistent row-range kernel.  By default for K <= 1536
+    // only: interleaved A/B on two boxes (profiles/r03_residual_gemm_study.txt) has it 2.4-3.9 % ahead on out-proj (12 K-steps: the
+    // hidden tile ends are a fifth of the launch) and level with the tile kernel on c_proj (48 K-steps: what the tile ends return,
+    // the five K-steps that carry the residual take back)
+    const bool want = variant == 16 || (!forced && k.K <= 1536 && options().gemm_rstream.load(std::memory_order_relaxed) == 1);
     if (want && rstream_fits(k)) {
       *parts_out = (k.N + 255) / 256;
       return launch_rstream(k, s);

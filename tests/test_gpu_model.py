@@ -323,11 +323,13 @@ def test_vit_large_towers_vs_oracle(gname, batch):
 
 @pytest.mark.parametrize("batch", [256, 300, 160, 131])
 def test_row_range_residual_kernel_in_tower(clipmi_option, batch):
-    """gemm_rstream_kernel (option gemm_rstream = 1, the default for the fp16-stream residual GEMMs out-proj / c_proj) against the
-    one-tile-per-workgroup kernel (gemm_rstream = 0).  The row-range kernel starts a tile from bias + residual and adds the products
-    on top -- the same fp32 terms in another order, one rounding to fp16 -- so the image features agree to a few 1e-6 in cosine
-    (against 1e-3 of tolerance), and are bit-identical run to run: batch 256 (85 ranges of 18-19 pairs: tiles of 10 + 9 / 9 + 9), 300
-    (22-23 pairs: three tiles), 160 (11-12 pairs: two tiles of 6), 131 (M = 25807, one tile per workgroup, a ragged last pair)."""
+    """gemm_rstream_kernel (option gemm_rstream = 1, the default for the fp16-stream residual GEMMs out-proj / c_proj where every row
+    range splits into tiles of 8-10 pairs) against the one-tile-per-workgroup kernel (gemm_rstream = 0).  The row-range kernel adds
+    the residual to the accumulators during the K loop -- the same fp32 terms in another order, one rounding to fp16: one element in a
+    thousand of a GEMM's output moves by an fp16 ulp, and through 24 residual updates the image features move by the fp16 stream's own
+    noise floor (1-2e-4 per component of the unit vector, against 1e-3 of tolerance).  Bit-identical run to run.  Batch 256 (85
+    ranges of 18-19 pairs: tiles of 10 + 9 / 9 + 9), 300 and 160 (ranges of 22-23 / 11-12 pairs: the tile kernel serves them), 131
+    (M = 25807: one tile of 9-10 pairs per workgroup, a ragged last pair)."""
     sd, model = _build("ViT-B/16")
     images = syn.synthetic_images(batch, "ViT-B/16", seed=9).cuda()
     with torch.no_grad():
@@ -339,7 +341,10 @@ def test_row_range_residual_kernel_in_tower(clipmi_option, batch):
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), f"run-to-run max diff {float((a - b).abs().max())}"
     an, rn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(ref, dim=1)
-    assert float((an - rn).abs().max()) < 5e-5 and float((1 - (an * rn).sum(1)).abs().max()) < 2e-6
+    assert float((an - rn).abs().max()) < 5e-4 and float((1 - (an * rn).sum(1)).abs().max()) < 2e-5
+    with torch.no_grad():
+        o = orc.encode_image(sd, images[:2].cpu()).numpy()
+    _feat_close(a[:2].cpu().numpy(), o, "image tower with the row-range residual kernel")
 
 
 @pytest.mark.parametrize("n_prompts", [1000, 700])
@@ -358,7 +363,7 @@ def test_row_range_residual_kernel_text_tower(n_prompts):
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), f"run-to-run max diff {float((a - b).abs().max())}"
     an, rn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(ref, dim=1)
-    assert float((1 - (an * rn).sum(1)).abs().max()) < 2e-6
+    assert float((1 - (an * rn).sum(1)).abs().max()) < 2e-5
     assert not torch.equal(a, f32)                                # the flag does select the fp16 stream
 
 

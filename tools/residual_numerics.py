@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clip_calibration_amd import _lib, ops
 torch.manual_seed(0)
-for M, N, K, rs in ((8192, 768, 768, 1.0), (8192, 768, 3072, 1.0), (8192, 768, 768, 30.0)):
+for M, N, K, rs in ((50432, 768, 768, 1.0), (50432, 768, 3072, 1.0), (50432, 768, 768, 30.0)):
     a = (torch.randn(M, K) * 0.5).half()
     w = (torch.randn(N, K) * K ** -0.5).half()
     bias = torch.randn(N) * 0.1
