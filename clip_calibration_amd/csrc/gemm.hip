@@ -923,7 +923,14 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   int vb = blockIdx.x;
   int m0, n0;
   coords(vb, m0, n0);
-  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+#ifdef CLIPMI_TUNING
+  // energy ablation (tuning build, knob 64): every tile reads the FIRST 256 activation rows -- the panel stays in L2, nothing of A
+  // comes from beyond it (results wrong)
+#define STREAM_A_ROW(m) ((a.knob & 64) ? 0 : (m))
+#else
+#define STREAM_A_ROW(m) (m)
+#endif
+  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)STREAM_A_ROW(m0) * a.lda, ((int64_t)(a.M - STREAM_A_ROW(m0)) * a.lda) * 2);
   __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
   int first_buf = 0, par = 0;
   stage(xrs, wrs, first_buf, 0);
@@ -973,7 +980,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     const int col = hn0 + wave_n * 64 + lcol + p * 32;
     const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + p * 64);
     const int voff = col < a.N ? in_range : (int)0xFFFFFFF0;
-    __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
+    if constexpr (CLIPMI_ABLATE & 1) asm volatile("" ::"v"(v), "v"(voff));   // (energy ablation: no output stores at all)
+    else __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
   };
   constexpr int SPS = 2;   // stores per slice and wave
 
@@ -1155,7 +1163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     if (has_next) {   // the buffer that is NOT the last one read is free: the next tile's first stage goes there (below)
       vb = nvb;
       coords(vb, m0, n0);
-      xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+      xrs = make_rsrc(a.A + (int64_t)STREAM_A_ROW(m0) * a.lda, ((int64_t)(a.M - STREAM_A_ROW(m0)) * a.lda) * 2);
       wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
       first_buf = last_buf ^ 1;
       params(m0, n0, par ^ 1);
@@ -1251,6 +1259,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     store_piece(HD + j, 1, held[1][j]);
   }
 }
+
+#undef STREAM_A_ROW
 
 template <int EPI>
 int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
@@ -1407,7 +1417,7 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
           ds_read128<6144>(wf[3], wa);
         }
       }
-      if constexpr (MORE && P < 3) {
+      if constexpr (MORE && P < 3 && !(CLIPMI_ABLATE & 2)) {
         stage_piece(std::integral_constant<int, P * PPP + 0>{}, buf ^ 1, kt + 1);
         stage_piece(std::integral_constant<int, P * PPP + 1>{}, buf ^ 1, kt + 1);
         stage_piece(std::integral_constant<int, P * PPP + 2>{}, buf ^ 1, kt + 1);
@@ -1427,7 +1437,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
       for (int j = 0; j < H; ++j) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          if constexpr (FIRSTK && KS == 0)
+          if constexpr (CLIPMI_ABLATE & 4) {   // (energy ablation: the loop without its MFMAs; the accumulators are only defined)
+            if constexpr (FIRSTK && KS == 0) asm volatile("" : "=v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
+            else asm volatile("" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
+          } else if constexpr (FIRSTK && KS == 0)
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
           else
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));

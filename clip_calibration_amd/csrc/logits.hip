@@ -84,33 +84,126 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
   }
 }
 
-// The row pass, one wave per image row (lane = threadIdx & 63):
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
+// result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.
+//   step 1, 2: quad_perm (xor 1, xor 2)   3: row_half_mirror   4: row_mirror   5: rows (0,1) (2,3)   6: halves
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float swap16_f(float v) {   // the value of the lane 16 further / back (rows 0 <-> 1, 2 <-> 3)
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // [0]: rows (0, 0, 2, 2), [1]: rows (1, 1, 3, 3)
+  const bool odd = (threadIdx.x >> 4) & 1;
+  return __builtin_bit_cast(float, (unsigned int)(odd ? a[0] : a[1]));
+}
+__device__ __forceinline__ float swap32_f(float v) {   // the value of the lane 32 further / back
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // [0]: lower half twice, [1]: upper half twice
+  const bool up = (threadIdx.x >> 5) & 1;
+  return __builtin_bit_cast(float, (unsigned int)(up ? a[0] : a[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  v += swap16_f(v);
+  v += swap32_f(v);
+  return v;
+}
+// (value, index) -> the largest value and the LOWEST index that holds it, in every lane
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  auto take = [&](float ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  };
+  take(dpp_f<0xB1>(v), dpp_i<0xB1>(idx));
+  take(dpp_f<0x4E>(v), dpp_i<0x4E>(idx));
+  take(dpp_f<0x141>(v), dpp_i<0x141>(idx));
+  take(dpp_f<0x140>(v), dpp_i<0x140>(idx));
+  take(swap16_f(v), __builtin_bit_cast(int, swap16_f(__builtin_bit_cast(float, idx))));
+  take(swap32_f(v), __builtin_bit_cast(int, swap32_f(__builtin_bit_cast(float, idx))));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The row pass: argmax, DAC factor, softmax top-1.
+//
+// Without DAC the softmax denominator is defined BLOCKWISE, so that the fused kernel can form it from what each of its
+// (row block, 64-column block) workgroups sees, without reading the logits back:
+//     block t = columns 64 t .. 64 t + 63:   m_t = max, a_t = argmax (lowest index), s_t = wave_sum(exp(x - m_t))
+//     M = max_t m_t (first maximum: lowest index),   sum = s_0 exp(m_0 - M) + s_1 exp(m_1 - M) + ...  (t ascending),  conf = 1 / sum
+// One wave per row, lane l holds column 64 t + l in iteration t, computes exactly that.  With DAC (the row is re-scaled by
+// f = dac[argmax] in place, so the logits are read back anyway) the sum runs lane-strided over the scaled row as before:
+// sum = wave_sum_l(sum_t exp(f x - f M)).  The two forms agree to a few 1e-7 relative.
 // probs == nullptr: DAC scales the row in place (predict of distanse_aware_calibration.py); probs != nullptr: the row is
 // left alone and softmax(row * f) is written to probs (which may be the same buffer).  No __restrict__ on these two.
+// ---------------------------------------------------------------------------------------------------------------
+struct TailPartial { float m; int arg; float s; int pad; };   // one (row, column block) of the blockwise form
+
+__device__ __forceinline__ TailPartial block_partial(float x, int col, bool live) {   // x: this lane's logit of the block (live: col < C)
+  TailPartial p;
+  p.m = live ? x : -INFINITY;
+  p.arg = live ? col : 0x7fffffff;
+  wave_argmax(p.m, p.arg);
+  p.s = wave_sum(live ? __expf(x - p.m) : 0.f);
+  p.pad = 0;
+  return p;
+}
+// merge in ascending block order; call with every block of the row
+__device__ __forceinline__ void merge_begin(float& M, int& arg, float& sum) { M = -INFINITY; arg = 0x7fffffff; sum = 0.f; }
+__device__ __forceinline__ void merge_max(const TailPartial& p, float& M, int& arg) {
+  if (p.m > M) { M = p.m; arg = p.arg; }   // ascending blocks: the first maximum keeps the lowest index
+}
+__device__ __forceinline__ void merge_sum(const TailPartial& p, float M, float& sum) { sum = __builtin_fmaf(p.s, __expf(p.m - M), sum); }
+
 __device__ __forceinline__ void calibrate_row(float* lr, const float* __restrict__ dac, int C, float* pr, int lane, float& conf_out, int& pred_out) {
+  if (!dac) {   // uniform: the blockwise form
+    const int nt = (C + 63) >> 6;
+    float M, sum;
+    int arg;
+    merge_begin(M, arg, sum);
+    for (int t = 0; t < nt; ++t) {   // pass 1: the row maximum (first occurrence)
+      const int c = t * 64 + lane;
+      float v = c < C ? lr[c] : -INFINITY;
+      int a = c < C ? c : 0x7fffffff;
+      wave_argmax(v, a);
+      if (v > M) { M = v; arg = a; }
+    }
+    if (arg == 0x7fffffff) arg = 0;   // all-NaN row
+    for (int t = 0; t < nt; ++t) {   // pass 2: block sums against the block maxima, merged against the row maximum
+      const int c = t * 64 + lane;
+      const TailPartial p = block_partial(c < C ? lr[c] : 0.f, c, c < C);
+      merge_sum(p, M, sum);
+    }
+    if (pr) {
+      const float inv = 1.0f / sum;
+      for (int c = lane; c < C; c += 64) pr[c] = __expf(lr[c] - M) * inv;   // same lane reads then writes element c
+    }
+    conf_out = 1.0f / sum;
+    pred_out = arg;
+    return;
+  }
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int c = lane; c < C; c += 64) {
     const float v = lr[c];
     if (v > best) { best = v; bi = c; }   // first occurrence wins inside a lane (ascending c)
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
+  wave_argmax(best, bi);
   if (bi == 0x7fffffff) bi = 0;  // all-NaN row
-  const float f = dac ? dac[bi] : 1.0f;
+  const float f = dac[bi];
   const float mx = best * f;
   float se = 0.f;
   for (int c = lane; c < C; c += 64) {
     const float v = lr[c] * f;
-    if (dac && !pr) lr[c] = v;
+    if (!pr) lr[c] = v;
     se += __expf(v - mx);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  se = wave_sum(se);
   if (pr) {
     const float inv = 1.0f / se;
     for (int c = lane; c < C; c += 64) pr[c] = __expf(lr[c] * f - mx) * inv;   // same lane reads then writes element c
@@ -199,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
                                                             const float* __restrict__ dac, float* logits, float* __restrict__ img_n_out,
                                                             float* __restrict__ conf, int32_t* __restrict__ pred,
                                                             const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
-                                                            int* counters, int B, int C, int E, int lds_bytes) {
+                                                            int* counters, TailPartial* partials, int B, int C, int E, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rsb = E * 2 + 16;                         // bytes per fp16 row of an LDS operand image (16-byte pad)
   char* hi_s = smem;
@@ -382,6 +475,21 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
       }
     }
+    // ---- phase 2b (no DAC): this workgroup's share of the row pass, from the tile while it is still in LDS -- per row the block's
+    //      (max, argmax, sum of exp(x - max)), 16 bytes, write-through.  The last workgroup of the row block merges n_col_blocks of
+    //      them per row instead of reading RB x C logits back (the read-back chain was 14 of the kernel's 23 us at B = 256).
+    if (!dac && (conf || pred || bins)) {   // uniform
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t prs = make_rsrc(partials, (int64_t)B * gridDim.y * (int)sizeof(TailPartial));
+      const int col = blockIdx.y * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int trow = wave * RPW + q;
+        const TailPartial p = block_partial(tile[trow * TAIL_TILE_LD + lane], col, col < C);
+        if (lane == 0 && m0 + trow < B)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), prs, (int)(((int64_t)(m0 + trow) * gridDim.y + blockIdx.y) * (int)sizeof(TailPartial)), 0, 16 /* sc1 */);
+      }
+    }
   } else if (cols_live && n0 + r < C) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
@@ -419,7 +527,68 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
     for (int t = threadIdx.x; t < 3 * (n_bins + 1); t += 256) sbins[t] = 0.0;
     __syncthreads();
   }
-  // the wave's RPW rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same butterflies), with
+  if (!dac && wide) {   // uniform: merge the row block's partials (calibrate_row's blockwise form, block by block in ascending order)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(partials, (int64_t)B * gridDim.y * (int)sizeof(TailPartial));
+    const int row = m0 + threadIdx.x;   // thread t owns row t of the block
+    if (threadIdx.x < RB && row < B) {
+      float M, sum;
+      int arg;
+      merge_begin(M, arg, sum);
+      const int nt = gridDim.y;
+      const int base = (int)((int64_t)row * nt * (int)sizeof(TailPartial));
+      for (int t0 = 0; t0 < nt; t0 += 16) {   // sc1 loads (every store of these bytes was sc1 and drained before its ticket), 16 in flight
+        TailPartial p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (t0 + u < nt) p[u] = __builtin_bit_cast(TailPartial, __builtin_amdgcn_raw_buffer_load_b128(prs, base + (t0 + u) * (int)sizeof(TailPartial), 0, 16 /* sc1 */));
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (t0 + u < nt) merge_max(p[u], M, arg);
+      }
+      if (arg == 0x7fffffff) arg = 0;
+      for (int t0 = 0; t0 < nt; t0 += 16) {
+        TailPartial p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (t0 + u < nt) p[u] = __builtin_bit_cast(TailPartial, __builtin_amdgcn_raw_buffer_load_b128(prs, base + (t0 + u) * (int)sizeof(TailPartial), 0, 16 /* sc1 */));
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (t0 + u < nt) merge_sum(p[u], M, sum);
+      }
+      const float cf = 1.0f / sum;
+      if (conf) conf[row] = cf;
+      if (pred) pred[row] = arg;
+      if (bins) {
+        const double x = (double)cf;
+        const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
+        atomicAdd(&sbins[b], 1.0);
+        atomicAdd(&sbins[nb1 + b], x);
+        atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)arg) ? 1.0 : 0.0);
+      }
+    }
+  } else if (!dac) {   // C % 4 != 0 (plain stores, no partials): the reference row pass itself, one wave per row
+    for (int q = 0; q < RPW; ++q) {
+      const int row = m0 + wave * RPW + q;
+      if (row < B) {   // uniform
+        float cf;
+        int pi;
+        calibrate_row(logits + (int64_t)row * C, nullptr, C, nullptr, lane, cf, pi);
+        if (lane == 0) {
+          if (conf) conf[row] = cf;
+          if (pred) pred[row] = pi;
+          if (bins) {
+            const double x = (double)cf;
+            const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
+            atomicAdd(&sbins[b], 1.0);
+            atomicAdd(&sbins[nb1 + b], x);
+            atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)pi) ? 1.0 : 0.0);
+          }
+        }
+      }
+    }
+  } else
+  // DAC: the wave's RPW rows side by side: calibrate_row's arithmetic per row (same lane-strided order, same reductions), with
   // every load of the pass in flight at once.  C <= 1024: a lane's 16 elements of each row stay in registers between the
   // argmax and the softmax pass (one trip to L2 instead of two chains of dependent round trips).  Larger C: the same
   // arithmetic with the two passes reading memory.
@@ -437,12 +606,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
       se[q] = 0.f;
     }
     auto finish_argmax = [&](int q) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best[q], o, 64);
-        const int oi = __shfl_xor(bi[q], o, 64);
-        if (ob > best[q] || (ob == best[q] && oi < bi[q])) { best[q] = ob; bi[q] = oi; }
-      }
+      wave_argmax(best[q], bi[q]);
       if (bi[q] == 0x7fffffff) bi[q] = 0;
       fac[q] = dac ? dac[bi[q]] : 1.0f;
       mx[q] = best[q] * fac[q];
@@ -489,8 +653,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
     }
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) se[q] += __shfl_xor(se[q], o, 64);
+      se[q] = wave_sum(se[q]);
       const int row = row0 + q;
       if (lane == 0 && row < B) {
         const float cf = 1.0f / se[q];
@@ -528,8 +691,9 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
   return rc;
 }
 
-// [ceil(B/16)] int32 ticket counters (zero between launches)
-size_t fused_tail_workspace_bytes(int B, int /*C*/) { return align256((size_t)((B + 15) / 16) * sizeof(int)); }
+// [ceil(B/16)] int32 ticket counters (zero between launches), then [B][ceil(C/64)] 16-byte row-pass partials (need no initialisation)
+static size_t tail_counter_bytes(int B) { return align256((size_t)((B + 15) / 16) * sizeof(int)); }
+size_t fused_tail_workspace_bytes(int B, int C) { return tail_counter_bytes(B) + align256((size_t)B * ((C + 63) / 64) * sizeof(TailPartial)); }
 
 int launch_fused_tail(const void* img_, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins, void* workspace,
@@ -572,10 +736,13 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   const dim3 grid((B + rb - 1) / rb, (C + 63) / 64);
   CLIPMI_REQUIRE(grid.y <= 65535, CLIPMI_ERR_SHAPE, "fused_tail: too many classes");
   int* counters = static_cast<int*>(workspace);
+  TailPartial* partials = reinterpret_cast<TailPartial*>(static_cast<char*>(workspace) + tail_counter_bytes(B));
+  CLIPMI_REQUIRE((int64_t)B * grid.y * (int64_t)sizeof(TailPartial) < 0x7FFFFFF0ll, CLIPMI_ERR_SHAPE, "fused_tail: partial table too large for 32-bit offsets");
   auto go = [&](auto kernel, DeviceOnce& once, auto* typed) {
-    ensure_dynamic_lds(kernel, lds, once);
+    // the attribute is set once per (instantiation, device): to the CU's whole LDS, not to this call's size -- E and n_bins vary between calls
+    ensure_dynamic_lds(kernel, 160 * 1024, once);
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, typed, txt_n, scale, dac_conf, logits, img_n_out, conf, pred, labels, bins, n_bins,
-                       counters, B, C, E, lds);
+                       counters, partials, B, C, E, lds);
   };
   static DeviceOnce once[16];
   const half_t* img16 = static_cast<const half_t*>(img_);

@@ -150,15 +150,18 @@ def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_con
     return logits, conf, pred
 
 
-_TAIL_WS = {}   # device index -> zeroed int32 ticket counters (the kernel leaves them zero)
+_TAIL_WS = {}   # (device index, stream) -> zeroed int32 ticket counters (the kernel leaves them zero)
 
 
 def _tail_workspace(device: torch.device, batch: int, classes: int) -> torch.Tensor:
+    """Ticket counters of the fused tail: one buffer per (device, stream).  Launches on ONE stream run in order and each leaves the
+    counters zero; two launches in flight on different streams must not share them (a foreign ticket would skip or double a row pass)."""
     need = lib.clipmi_fused_tail_workspace_bytes(batch, classes)
-    ws = _TAIL_WS.get(device.index)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TAIL_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=device)
-        _TAIL_WS[device.index] = ws
+        _TAIL_WS[key] = ws
     return ws
 
 

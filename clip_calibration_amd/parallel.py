@@ -56,9 +56,19 @@ class EmbeddingExchange:
                     uid = [buf.raw]
                 except (_lib.ClipmiError, RuntimeError, AttributeError, OSError) as e:
                     reason = str(e)
+            # the id and the agreement flag travel on CPU tensors when the group has a CPU backend (gloo, or "cpu:gloo,cuda:nccl"),
+            # on tensors of this rank's GPU when it is a plain "nccl" group
+            cpu_ok = self.world == 1 or "gloo" in str(dist.get_backend(group)).lower() or "cpu" in str(dist.get_backend(group)).lower()
+            side = torch.device("cpu") if cpu_ok else self.device
             if self.world > 1:
-                dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
-                                           device=torch.device("cpu"))
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                msg = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8, device=side)
+                if self.rank == 0 and uid[0]:
+                    msg[0] = 1
+                    msg[1:] = torch.frombuffer(bytearray(uid[0]), dtype=torch.uint8).to(side)
+                dist.broadcast(msg, src=src, group=group)
+                msg = msg.cpu()
+                uid = [bytes(msg[1:].numpy().tobytes()) if int(msg[0]) == 1 else b""]
             if uid[0]:
                 try:
                     handle = C.c_void_p()
@@ -70,7 +80,7 @@ class EmbeddingExchange:
                 reason = reason or "rank 0 could not create an RCCL unique id"
             ok = handle is not None
             if self.world > 1:
-                flag = torch.tensor([int(ok)], dtype=torch.int32)
+                flag = torch.tensor([int(ok)], dtype=torch.int32, device=side)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
                 if ok and int(flag.item()) == 0:
                     reason = "another rank could not build its communicator"

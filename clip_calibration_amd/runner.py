@@ -28,37 +28,31 @@ from .proximity import knn_dists_device
 
 def device_batches(loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], device="cuda", depth: int = 2):
     """``parse_batch_test`` for a host loader (Dassl: ``batch["img"].to(device), batch["label"].to(device)``, reference
-    trainers/classification/base_learner.py:84-88,175-182), without its per-batch stall: every (image, label) pair is staged through
-    a ring of ``depth`` PINNED host buffers and copied to the GPU with ``non_blocking=True`` on a side stream, ``depth - 1`` batches
-    ahead of the consumer; the consumer's stream waits on the copy's event, never the host.  A pageable ``image.to(device)`` (what the
-    reference does) is a synchronous staged copy: the GPU idles for 602 KB per image of PCIe time on every batch.  Batches that
-    already live on the device pass through untouched.  Yields (image_on_device, label_on_device)."""
+    trainers/classification/base_learner.py:84-88,175-182) without its per-batch stall: the copy of batch i + 1 is issued on a SIDE
+    stream while batch i computes, and the consumer's stream waits on the copy's event, never the host.
+    * pinned host tensors (a DataLoader with ``pin_memory=True``) are copied ``non_blocking``: the host thread does not wait either;
+    * pageable tensors go through torch's own staged copy on the side stream -- the host blocks for the copy, but by then it has
+      queued the previous batch's launches, so the GPU computes meanwhile (an extra host-side copy into a pinned ring was measured
+      3x SLOWER than that: 154 MB of memcpy per batch of 256 on one host thread, profiles/r03_stream_input.txt);
+    * tensors that already live on the device pass through.
+    Yields (image_on_device, label_on_device), ``depth - 1`` batches ahead."""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("device_batches: the path runs on a ROCm GPU only")
     copy_stream = torch.cuda.Stream(device=dev)
-    ring = [None] * depth           # (pinned image buffer, pinned label buffer, event of the last copy out of them)
-    pending = []                    # (device image, device label, copy-done event) in flight, oldest first
+    pending = []                    # (device image, device label, copy-done event), oldest first
 
-    def stage(slot, image, label):
+    def stage(image, label):
         image, label = torch.as_tensor(image), torch.as_tensor(label)
         if image.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             return image, label.to(dev, non_blocking=True), ev
-        buf = ring[slot]
-        if buf is None or buf[0].shape != image.shape or buf[0].dtype != image.dtype or buf[1].shape != label.shape or buf[1].dtype != label.dtype:
-            buf = (torch.empty(image.shape, dtype=image.dtype, pin_memory=True), torch.empty(label.shape, dtype=label.dtype, pin_memory=True), None)
-        elif buf[2] is not None:
-            buf[2].synchronize()    # the previous copy OUT of this pinned buffer has finished: safe to overwrite it
-        buf[0].copy_(image)
-        buf[1].copy_(label)
         with torch.cuda.stream(copy_stream):
-            d_img = buf[0].to(dev, non_blocking=True)
-            d_lab = buf[1].to(dev, non_blocking=True)
+            d_img = image.to(dev, non_blocking=image.is_pinned())
+            d_lab = label.to(dev, non_blocking=label.is_pinned())
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-        ring[slot] = (buf[0], buf[1], ev)
         return d_img, d_lab, ev
 
     def release(item):
@@ -69,10 +63,8 @@ def device_batches(loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], device="
         d_lab.record_stream(cur)
         return d_img, d_lab
 
-    slot = 0
     for image, label in loader:
-        pending.append(stage(slot, image, label))
-        slot = (slot + 1) % depth
+        pending.append(stage(image, label))
         if len(pending) >= depth:
             yield release(pending.pop(0))
     while pending:

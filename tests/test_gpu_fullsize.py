@@ -78,7 +78,9 @@ def test_equivariance_and_linearity(full):
     l3, _, p3 = ops.logits_fused(imf, txf, 2.0 * zs.scale, None, True)
     assert torch.equal(l3, 2.0 * logits) and torch.equal(p3, pred)
     l4, c4, p4 = ops.logits_fused(imf, txf, zs.scale, torch.ones(C, device="cuda"), True)
-    assert torch.equal(l4, logits) and torch.equal(p4, pred) and torch.equal(c4, conf)
+    assert torch.equal(l4, logits) and torch.equal(p4, pred)
+    # the DAC row pass sums the exponentials lane-strided over the re-scaled row, the plain one blockwise (logits.hip): same value, other order
+    assert (c4 - conf).abs().max() <= 4e-7 * conf.abs().max()
     # conf / pred are the softmax top-1 of the logits that came back
     lg = logits.double().cpu().numpy()
     probs = orc.softmax_probs(lg)
@@ -175,7 +177,8 @@ def test_config3_coop_dac_full_size(full):
 
 def test_config5_vit_l14_336_full_batch():
     """BASELINE configs[4] per-GPU shape: ViT-L/14@336px, batch 64 (577 tokens, 24 layers, width 1024).  Determinism, batch
-    invariance, and one image of the batch against the CPU oracle."""
+    invariance, and four images of the batch (first, last, two interior -- one oracle pass of four images: ~40 s of CPU) against the
+    CPU oracle."""
     from clip_calibration_amd.model import build_model
     gname = "ViT-L/14@336px"
     sd = syn.synthetic_state_dict(gname, seed=0)
@@ -185,14 +188,17 @@ def test_config5_vit_l14_336_full_batch():
         a = model.image_features_f32(images)
         b = model.image_features_f32(images)
         parts = torch.cat([model.image_features_f32(images[i:i + 8]) for i in range(0, 64, 8)])
-        ref = orc.encode_image(sd, images[37:38].cpu()).numpy()
+        picks = [0, 21, 37, 63]
+        ref = orc.encode_image(sd, images[picks].cpu()).numpy()
     assert torch.equal(a, b) and torch.isfinite(a).all()
     an, pn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(parts, dim=1)
     assert (an - pn).abs().max() < 2e-4
     rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
     got = an.cpu().numpy()
-    assert abs(float(got[37] @ rn[0]) - 1.0) < COS_TOL
-    assert np.abs(got @ rn.T)[np.arange(64) != 37].max() < 1.0 - 1e-3               # and the other rows are other images
+    cos = got @ rn.T                                                                # [64, 4]
+    for j, i in enumerate(picks):
+        assert abs(float(cos[i, j]) - 1.0) < COS_TOL, (i, float(cos[i, j]))
+        assert np.abs(np.delete(cos[:, j], i)).max() < 1.0 - 1e-3                   # and the other rows are other images
 
 
 def test_config4_dataset_sweep_class_counts():

@@ -361,12 +361,16 @@ def test_l2_and_logits_dac_conf_pred(ops):
 
 
 @pytest.mark.parametrize("B,C,E", [(256, 1000, 512), (1, 1, 64), (16, 64, 64), (37, 1003, 512), (300, 50, 768), (2048, 1000, 512),
-                                   (128, 397, 1024), (5, 3, 16)])
+                                   (128, 397, 1024), (5, 3, 16), (1024, 199, 512), (64, 4200, 512)])
 @pytest.mark.parametrize("dac", [False, True])
 def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
     """clipmi_fused_tail (one launch: normalise + logits + DAC + softmax top-1 + ECE bins; zsclip.py:99-101,
     distanse_aware_calibration.py:49-58) against the same arithmetic as separate launches: bit-identical outputs, and the
-    ticket counters are left zero.  (5, 3, 16) is a shape the fused kernel does not take: both sides run the launches.)"""
+    ticket counters are left zero.  Without DAC the row pass is BLOCKWISE in both forms (per 64-column block max / argmax / sum of
+    exponentials, merged in ascending block order): the fused kernel forms it from one 16-byte partial per (row, column block) that
+    each of its workgroups writes, the separate launch from the logits.  (5, 3, 16) is a shape the fused kernel does not take: both
+    sides run the launches; (1024, 199, 512) is the gathered batch of BASELINE configs[3] against SUN397's base-class count (199 is
+    not a multiple of 4: plain stores and the reference row pass inside the kernel); (64, 4200, 512): 66 column blocks.)"""
     rng = np.random.default_rng(B * 31 + C + E)
     img = _cuda(torch.from_numpy(rng.normal(size=(B, E)).astype(np.float32)) * 3.0)
     txt_n = ops.l2_normalize(_cuda(torch.from_numpy(rng.normal(size=(C, E)).astype(np.float32))))
@@ -390,7 +394,8 @@ def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
     assert torch.equal(bins_f[:11], bins_u[:11]) and torch.equal(bins_f[22:], bins_u[22:])      # counts, hits: exact
     np.testing.assert_allclose(bins_f[11:22].cpu().numpy(), bins_u[11:22].cpu().numpy(), rtol=1e-13)
     n_counters = (B + 15) // 16
-    assert int(ops._TAIL_WS[torch.cuda.current_device()][: 4 * n_counters].view(torch.int32).abs().sum()) == 0
+    ws = ops._TAIL_WS[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
+    assert int(ws[: 4 * n_counters].view(torch.int32).abs().sum()) == 0
     # against the oracle (fp32 dot products of E terms, |logit| <= 100)
     ref, _, _ = orc.clip_logits(img.cpu(), txt_n.cpu(), 100.0)
     ref = ref.numpy()

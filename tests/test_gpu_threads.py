@@ -1,0 +1,77 @@
+"""Two CLIP handles in one process, driven from two Python threads on two HIP streams -- what the reference does when
+`get_text_features` builds a second CLIP beside the trainer's (trainers/classification/base_learner.py:262-272), each with its own
+precision (cfg.TRAINER.<X>.PREC, trainers/classification/coop.py:243-245).  include/clipmi.h promises: calls on different handles may
+run concurrently; precision is a per-handle setting / per-call flag, no launch path writes process-wide state."""
+import threading
+
+import pytest
+import torch
+
+from clip_calibration_amd import _lib, synthetic as syn
+from clip_calibration_amd.model import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed, residual_f16):
+    m = build_model(dict(syn.synthetic_state_dict("ViT-B/16", seed=seed)), {"trainer": "CoOp"}).cuda()
+    m.set_option("residual_f16", residual_f16)
+    return m
+
+
+def test_two_handles_two_threads_two_streams_bitwise():
+    """Handle A: text tower on the fp32 residual stream (residual_f16 = 0), handle B: fp16 on both towers (1), different weights.
+    Each thread runs its model's text and image towers ROUNDS times on its own stream while the other does the same; every result
+    must equal the single-threaded result of that handle bit for bit, and the process-wide options must be untouched."""
+    ids = syn.synthetic_token_ids(96, "ViT-B/16", seed=3).cuda()
+    images = syn.synthetic_images(24, "ViT-B/16", seed=3).cuda()
+    models = {"a": _model(0, 0), "b": _model(1, 1)}
+    before = {k: _lib.get_option(k) for k in ("residual_f16", "ln_fold", "cls_only_last_block")}
+    with torch.no_grad():
+        want = {k: (m.text_features_f32(ids).clone(), m.image_features_f32(images).clone()) for k, m in models.items()}
+        assert not torch.equal(want["a"][0], want["b"][0])
+        # the settings really differ per handle: handle A with B's setting gives other bits
+        models["a"].set_option("residual_f16", 1)
+        other = models["a"].text_features_f32(ids).clone()
+        models["a"].set_option("residual_f16", 0)
+        assert not torch.equal(other, want["a"][0])
+    torch.cuda.synchronize()
+    ROUNDS, errors, start = 6, [], threading.Barrier(2)
+
+    def work(key):
+        try:
+            m, stream = models[key], torch.cuda.Stream()
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(stream):
+                for r in range(ROUNDS):
+                    t = m.text_features_f32(ids)
+                    i = m.image_features_f32(images)
+                    # per-call flag on top of the handle's setting: the other precision for this call only
+                    flip = m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16 if key == "a" else _lib.CALL_STREAM_F32)
+                    stream.synchronize()
+                    if not (torch.equal(t, want[key][0]) and torch.equal(i, want[key][1])):
+                        errors.append(f"{key}: round {r} differs from the single-threaded result")
+                    if torch.equal(flip, want[key][0]):
+                        errors.append(f"{key}: round {r}: the per-call flag did not switch the stream precision")
+        except Exception as e:   # noqa: BLE001  (reported below: a thread's exception would otherwise vanish)
+            errors.append(f"{key}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in models]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert {k: _lib.get_option(k) for k in before} == before          # nothing process-wide was written
+    assert models["a"].get_option("residual_f16") == 0 and models["b"].get_option("residual_f16") == 1
+
+
+def test_call_flag_f16_needs_the_fold():
+    m = _model(0, -1)
+    ids = syn.synthetic_token_ids(4, "ViT-B/16", seed=1).cuda()
+    m.set_option("ln_fold", 0)
+    with pytest.raises(_lib.ClipmiError):
+        m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16)
+    m.set_option("ln_fold", -1)
+    with torch.no_grad():
+        assert torch.isfinite(m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16)).all()

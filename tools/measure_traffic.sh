@@ -9,8 +9,7 @@ OUT="$ROOT/gpurun_out/traffic"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$ctr" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline \
-      > "$OUT/$ctr.log" 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$ctr" -- python3 "$ROOT/tools/traffic_workload.py" > "$OUT/$ctr.log" 2>&1
 done
 python3 "$ROOT/tools/traffic_json.py" "$OUT/FETCH_SIZE" "$OUT/WRITE_SIZE" > "$ROOT/profiles/gemm_traffic.json"
 cat "$ROOT/profiles/gemm_traffic.json"

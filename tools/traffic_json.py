@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of `bench.py` -> profiles/gemm_traffic.json (stdout).
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of tools/traffic_workload.py -> profiles/gemm_traffic.json (stdout).
 
 Per image-tower GEMM kernel (in_proj, out_proj, c_fc, c_proj at batch 256): mean FETCH_SIZE and WRITE_SIZE (KB) per
 dispatch, HBM-side traffic = 2 * FETCH_SIZE + WRITE_SIZE (gfx950 counts a 128-B read request as 64 B for wide coalesced
@@ -28,33 +28,45 @@ def rows(directory):
 
 
 def classify(rs):
-    """Kernel_Name -> role, from the template arguments gemm_f16_kernel<Tile<..>, EPI, OUT_F32> / gemm_stream_kernel<EPI> (EPI 1 bias = in-proj,
-    2 QuickGELU = c_fc, 101 / 102 residual fold = out-proj and c_proj alternating)."""
+    """Kernel_Name -> role.  The profiled workload is the image tower alone (tools/traffic_workload.py), so every dispatch of these
+    kernels has the bench shape: gemm_stream_kernel<1> = in-proj, <2> = c_fc (QuickGELU), gemm_rstream_kernel = out-proj (the
+    fp16-stream residual GEMM with K <= 1536), the residual-fold tile kernel (epilogue 102) = c_proj -- or out-proj and c_proj
+    alternating, out-proj first in every layer, when the row-range kernel is switched off."""
     per = defaultdict(list)
     alt = defaultdict(int)
+    has_rstream = any("gemm_rstream_kernel" in r["Kernel_Name"] for r in rs)
     for r in rs:
         name = r["Kernel_Name"]
-        if "gemm_f16_kernel" not in name and "gemm_" not in name:
-            continue
-        grid = int(r.get("Grid_Size", 0) or 0)
-        args = name.split(">,")[-1] if ">," in name else ""
-        epi = args.split(",")[0].strip() if args else ""
-        if "gemm_stream_kernel<" in name:   # the ping-pong persistent kernel (default for in-proj / c_fc): gemm_stream_kernel<EPI>, one workgroup per CU
+        val = float(r["Counter_Value"])
+        if "gemm_stream_kernel<" in name:
             epi = name.split("gemm_stream_kernel<")[1].split(">")[0].strip()
-            grid = 256 * 1000
-        if epi == "1" and grid >= 256 * 1000:
-            per["in_proj"].append(float(r["Counter_Value"]))
-        elif epi == "2":
-            per["c_fc"].append(float(r["Counter_Value"]))
-        elif epi in ("101", "102"):
-            role = "out_proj" if alt[name] % 2 == 0 else "c_proj"
-            alt[name] += 1
-            per[role].append(float(r["Counter_Value"]))
+            if epi in ("1", "2"):
+                per["in_proj" if epi == "1" else "c_fc"].append(val)
+        elif "gemm_rstream_kernel" in name:
+            per["out_proj"].append(val)
+        elif ("gemm_pp_kernel" in name or "gemm_f16_kernel" in name) and ">," in name:
+            epi = name.split(">,")[-1].split(",")[0].strip()
+            if epi in ("101", "102"):
+                role = "c_proj" if has_rstream else ("out_proj" if alt[name] % 2 == 0 else "c_proj")
+                alt[name] += 1
+                per[role].append(val)
     return per
+
+
+def runs_of(directory):
+    for path in glob.glob(os.path.join(os.path.dirname(directory.rstrip("/")), os.path.basename(directory.rstrip("/")) + ".log")):
+        for line in open(path):
+            if line.startswith("runs "):
+                return int(line.split()[1])
+    return None
 
 
 def main():
     fetch, write = classify(rows(sys.argv[1])), classify(rows(sys.argv[2]))
+    runs = runs_of(sys.argv[1])
+    for per in (fetch, write):   # 12 layers x RUNS passes of the image tower, nothing else (a text-tower dispatch would have another shape)
+        for role in SHAPES:
+            assert runs is None or len(per.get(role, [])) == 12 * runs, f"{role}: {len(per.get(role, []))} dispatches, expected {12 * runs}"
     sha = hashlib.sha256(open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
     kernels = {}
     for role, (m, n, k) in SHAPES.items():
@@ -66,8 +78,8 @@ def main():
         kernels[role] = {"shape": {"M": m, "N": n, "K": k}, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "dispatches": len(fetch[role]),
                          "traffic_bytes": (2.0 * f + w) * 1024.0, "algorithmic_bytes": 2.0 * (m * k + n * k) + out_bytes}
     print(json.dumps({"gemm_hip_sha256": sha,
-                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-                                "--no-cpu-baseline --no-roofline; tools/measure_traffic.sh",
+                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/traffic_workload.py (image tower only, "
+                                "batch 256: every dispatch has the bench shape); tools/measure_traffic.sh",
                       "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams -> x2; WRITE_SIZE exact for 16-B stores",
                       "kernels": kernels}, indent=1))
 
