@@ -691,9 +691,11 @@ int launch_logits(const float* img_n, const float* txt_n, float scale, const flo
   return rc;
 }
 
-// [ceil(B/16)] int32 ticket counters (zero between launches), then [B][ceil(C/64)] 16-byte row-pass partials (need no initialisation)
-static size_t tail_counter_bytes(int B) { return align256((size_t)((B + 15) / 16) * sizeof(int)); }
-size_t fused_tail_workspace_bytes(int B, int C) { return tail_counter_bytes(B) + align256((size_t)B * ((C + 63) / 64) * sizeof(TailPartial)); }
+// Workspace: a FIXED 64 KiB of int32 ticket counters (one per 16- or 32-row block: batches up to 262 144 rows; zero between launches),
+// then [B][ceil(C/64)] 16-byte row-pass partials (need no initialisation).  The counter region does not move with B: a caller may
+// reuse one buffer for calls of different sizes, and a region that held another call's partials must never be read as counters.
+constexpr size_t TAIL_COUNTER_BYTES = 64 * 1024;
+size_t fused_tail_workspace_bytes(int B, int C) { return TAIL_COUNTER_BYTES + align256((size_t)B * ((C + 63) / 64) * sizeof(TailPartial)); }
 
 int launch_fused_tail(const void* img_, int img_dtype, int normalize, const float* txt_n, float scale, const float* dac_conf, float* logits,
                       float* img_n_out, float* conf, int32_t* pred, const int64_t* labels, double* bins, int n_bins, void* workspace,
@@ -736,7 +738,8 @@ int launch_fused_tail(const void* img_, int img_dtype, int normalize, const floa
   const dim3 grid((B + rb - 1) / rb, (C + 63) / 64);
   CLIPMI_REQUIRE(grid.y <= 65535, CLIPMI_ERR_SHAPE, "fused_tail: too many classes");
   int* counters = static_cast<int*>(workspace);
-  TailPartial* partials = reinterpret_cast<TailPartial*>(static_cast<char*>(workspace) + tail_counter_bytes(B));
+  CLIPMI_REQUIRE((size_t)((B + 15) / 16) * sizeof(int) <= TAIL_COUNTER_BYTES, CLIPMI_ERR_SHAPE, "fused_tail: batch too large for the ticket-counter region");
+  TailPartial* partials = reinterpret_cast<TailPartial*>(static_cast<char*>(workspace) + TAIL_COUNTER_BYTES);
   CLIPMI_REQUIRE((int64_t)B * grid.y * (int64_t)sizeof(TailPartial) < 0x7FFFFFF0ll, CLIPMI_ERR_SHAPE, "fused_tail: partial table too large for 32-bit offsets");
   auto go = [&](auto kernel, DeviceOnce& once, auto* typed) {
     // the attribute is set once per (instantiation, device): to the CU's whole LDS, not to this call's size -- E and n_bins vary between calls

@@ -149,8 +149,10 @@ int clipmi_logits(const float* img_n, const float* txt_n, float scale, const flo
  * pred int32 [B], labels int64 [B] + bins float64 [3*(n_bins+1)]: each may be NULL.  Results are bit-identical to
  * clipmi_l2_normalize + clipmi_logits + clipmi_ece_accumulate (the ECE sums of confidences up to the order of their atomics).  E % 64 == 0 and E <= 2048 run fused; other shapes, and option
  * tail_unfused = 1, run the separate launches (which need img_n_out or fp32 normalised input, and conf + pred when bins are given).
- * workspace: clipmi_fused_tail_workspace_bytes(B, C) bytes of device memory that is ZERO before the first launch; every launch
- * leaves it zero again (ticket counters: room for one int32 per 16 image rows; one per 16- or 32-row block is used).  Re-zero it
+ * workspace: clipmi_fused_tail_workspace_bytes(B, C) bytes of device memory whose first 64 KiB (ticket counters, one int32 per 16- or
+ * 32-row block) are ZERO before the first launch; every launch leaves them zero again.  The rest holds one 16-byte partial (max, argmax,
+ * sum of exponentials) per (row, 64-column block), written and consumed inside a launch: no initialisation.  One workspace serves ONE
+ * launch at a time (launches on one stream are fine; concurrent launches on different streams need a workspace each).  Re-zero the counters
  * after a launch that failed.  Features must be finite with |x| <= 65504 (L2-normalised ones are <= 1): the products run on the
  * fp16 matrix cores with every fp32 operand split into fp16 hi + lo halves, ~1e-6 absolute on logits of scale 100. */
 size_t clipmi_fused_tail_workspace_bytes(int B, int C);

@@ -142,9 +142,9 @@ def _residual_ref(a, w, bias, x):
 
 def _ulp_close(x, ref, what, frac=4e-3):
     """fp16 tensors that are the same fp32 sums added in a different order: equal except at rounding boundaries, never more than one
-    fp16 ulp apart -- or, where terms of size O(1) cancel to almost nothing, a few fp32 roundings of those terms (4e-6)."""
+    fp16 ulp apart -- or, where terms of size O(1) cancel to almost nothing, a few fp32 roundings of those terms (1e-5 at K = 3072)."""
     d = (x.float() - ref.float()).abs()
-    tol = torch.clamp(ref.float().abs() * (1.05 * 2.0 ** -10), min=4e-6)   # 1.05: |ref| * 2^-10 is the ulp only up to float rounding at a binade edge
+    tol = torch.clamp(ref.float().abs() * (1.05 * 2.0 ** -10), min=1e-5)   # 1.05: |ref| * 2^-10 is the ulp only up to float rounding at a binade edge
     assert bool((d <= tol).all()), f"{what}: more than one fp16 ulp apart (max {float((d / tol).max()):.2f} x the tolerance)"
     assert float((x != ref).float().mean()) < frac, f"{what}: {float((x != ref).float().mean()):.2e} of the elements differ"
 
@@ -393,9 +393,8 @@ def test_fused_tail_bitwise_vs_unfused(ops, clipmi_option, B, C, E, dac):
     np.testing.assert_allclose(got[1], own[1], rtol=1e-13)
     assert torch.equal(bins_f[:11], bins_u[:11]) and torch.equal(bins_f[22:], bins_u[22:])      # counts, hits: exact
     np.testing.assert_allclose(bins_f[11:22].cpu().numpy(), bins_u[11:22].cpu().numpy(), rtol=1e-13)
-    n_counters = (B + 15) // 16
     ws = ops._TAIL_WS[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
-    assert int(ws[: 4 * n_counters].view(torch.int32).abs().sum()) == 0
+    assert int(ws[: 64 * 1024].view(torch.int32).abs().sum()) == 0               # the whole ticket-counter region
     # against the oracle (fp32 dot products of E terms, |logit| <= 100)
     ref, _, _ = orc.clip_logits(img.cpu(), txt_n.cpu(), 100.0)
     ref = ref.numpy()
