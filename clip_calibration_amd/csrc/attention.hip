@@ -140,8 +140,26 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
 // stricter, never weaker.  Dense single-block form only (vision towers: no causal mask), with (NKT-1)*32 < L <= (NKT-1)*32 + 8:
 // the last key tile holds at most 8 live keys (193..200 tokens at NKT = 7).
 // ---------------------------------------------------------------------------------------------------------------
+// CLIPMI_ATTN_ABLATE (build-time, diagnostic builds only: results are wrong with any bit set; tools/attn_ablate.sh): 1 no v_exp, 2 no P.V /
+// row-sum MFMAs, 4 no S MFMAs, 8 query waves 4-6 idle (one query wave per SIMD), 16 no row-sum MFMA,
+// 32 no max phase, 64 no LDS fragment reads, 128 operands read as if every (sequence, head) held K | V | Q contiguously (what a head-major
+// in-projection output would give the loader), 256 no output stores,
+// 512 operand DMA marked non-temporal, 1024 output stores non-temporal, 2048 output stores write-through (sc0 sc1)
+#ifndef CLIPMI_ATTN_ABLATE
+#define CLIPMI_ATTN_ABLATE 0
+#endif
+#ifdef CLIPMI_TUNING
+#define CLIPMI_ATTN_STAMP(slot, dep) do { asm volatile("" :: "v"(dep)); if (sp) sp[slot] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CLIPMI_ATTN_STAMP(slot, dep) do { } while (0)
+#endif
+#if CLIPMI_ATTN_ABLATE & 64
+#define CLIPMI_DS_READ_B128(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr), "n"(off))
+#define CLIPMI_DS_READ_TR16_B64(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr), "n"(off))
+#else
 #define CLIPMI_DS_READ_B128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define CLIPMI_DS_READ_TR16_B64(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#endif
 
 template <int N>
 __device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
@@ -172,7 +190,7 @@ __device__ __forceinline__ void read_v(f16x4 (&dst)[4], const uint32_t (&va)[2])
 // segments separated by workgroup barriers with waves 4-6 one segment behind -- profiles/r02_attention_segments_ab.txt.)
 template <int NKT, int GROUP>
 __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const uint32_t (&va)[2], const uint32_t (&qa)[4], int L,
-                                                int hh, f32x16 (&oacc)[2], f32x16& lacc) {
+                                                int hh, f32x16 (&oacc)[2], f32x16& lacc, long long* sp = nullptr) {
   constexpr float C = 0.125f * LOG2E;
   const f16x8 ones = f16x8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
   const f32x16 zero16 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -200,9 +218,15 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
       } else {
         lds_wait4<0>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
       }
-      s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
+      if constexpr (CLIPMI_ATTN_ABLATE & 4) {
+        asm volatile("" :: "v"(kf[CUR][0]), "v"(kf[CUR][1]), "v"(kf[CUR][2]), "v"(kf[CUR][3]));
+        s[T] = zero16;
+        asm volatile("" : "+v"(s[T]));
+      } else {
+        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
 #pragma unroll
-      for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+        for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+      }
       if constexpr (KT == NKT - 1) {   // the only tile that can hold keys at or beyond L
         // L <= (NKT - 1) * 32 + 8 (the caller's contract: 193..200 tokens): registers e >= 4 of this tile are keys >= L in EVERY
         // lane (key = 32 KT + (e & 3) + 8 (e >> 2) + 4 hh) -- P = 0 exactly, so they get no mask, no max, no exponent, and the
@@ -219,16 +243,21 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     if constexpr (G > 2) s_tile(std::integral_constant<int, 2>{});
     if constexpr (G > 3) s_tile(std::integral_constant<int, 3>{});
     static_assert(G <= 4, "softmax groups of at most four key tiles");
+    CLIPMI_ATTN_STAMP(G0 == 0 ? 4 : 6, s[G - 1][0]);
     // the reads that the P.V phase (and the next group's first S tile) open with: behind the exponent work by the time they are needed
     if constexpr (MORE) read_k<G0 + G>(kf[(G0 + G) & 1], ka);
     read_v<G0 * 4096>(vf[0], va);
     // ---- group max of the raw scores, online rescale (nothing to rescale in the first group)
     float mloc = NEG_BIG;
+    if constexpr (CLIPMI_ATTN_ABLATE & 32) {
+      mloc = 40.f;
+    } else {
 #pragma unroll
-    for (int t = 0; t < G; ++t)
+      for (int t = 0; t < G; ++t)
 #pragma unroll
-      for (int e = 0; e < ((G0 + t == NKT - 1) ? 4 : 16); e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        for (int e = 0; e < ((G0 + t == NKT - 1) ? 4 : 16); e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    }
     const float m_new = G0 == 0 ? mloc : fmaxf(m_run, mloc);
     if constexpr (G0 > 0) {
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
@@ -252,17 +281,25 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
       f16x8 pf;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        pf[j] = (TAILT && 8 * SS + j >= 4) ? (half_t)0.f : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
+        pf[j] = (TAILT && 8 * SS + j >= 4) ? (half_t)0.f
+                : (CLIPMI_ATTN_ABLATE & 1) ? (half_t)__builtin_fmaf(s[T][8 * SS + j], C, -mc)
+                                           : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
       if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
       else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
         const f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (G0 == 0 && STEP == 0) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pf, zero16, 0, 0, 0);
+        if constexpr (CLIPMI_ATTN_ABLATE & 2) {
+          asm volatile("" :: "v"(v8), "v"(pf));
+          if (G0 == 0 && STEP == 0) { oacc[dt] = zero16; asm volatile("" : "+v"(oacc[dt])); }
+        } else if (G0 == 0 && STEP == 0) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pf, zero16, 0, 0, 0);
         else oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8, pf, oacc[dt], 0, 0, 0);
       }
-      if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, zero16, 0, 0, 0);
+      if constexpr (CLIPMI_ATTN_ABLATE & (2 | 16)) {
+        asm volatile("" :: "v"(pf));
+        if (G0 == 0 && STEP == 0) { lacc = zero16; lacc[0] = 1.f; asm volatile("" : "+v"(lacc)); }
+      } else if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, zero16, 0, 0, 0);
       else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
     };
     auto pv_tile = [&](auto t_tag) {
@@ -275,6 +312,7 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
     if constexpr (G > 3) pv_tile(std::integral_constant<int, 3>{});
   };
   group(std::integral_constant<int, 0>{});
+  CLIPMI_ATTN_STAMP(5, oacc[0][0]);
   if constexpr (NKT > GROUP) group(std::integral_constant<int, GROUP>{});
   static_assert(NKT <= 2 * GROUP, "at most two softmax groups");
 }
@@ -305,6 +343,59 @@ __device__ __forceinline__ void store_out(half_t* orow, const f32x16 (&oacc)[2],
     auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
     auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
     if (valid) *reinterpret_cast<u32x4*>(row + 16 * k) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+  }
+}
+
+// The same tile as full 128-byte lines: store_out's four instructions each write 32 bytes of 32 different rows, so every output line
+// reaches the L2 as four partial writes, and the 77 MB of output cost the vision kernel a quarter of its launch for a quarter of its
+// bytes (profiles/r03_attention_ablation.txt).  Here the wave parks its tile in LDS -- `stage` = the byte address of 32 rows x 128 B
+// that only this wave touches (its own Q rows of the item: read at the start of the item, dead since), 16-byte pieces XOR-swizzled by
+// ((row >> 1) & 7) like the K rows -- and reads it back with 8 consecutive lanes per row: one store instruction = 8 complete rows.
+// Rows at or beyond `nrows` (relative to the tile) are neither parked nor stored.  Same bits as store_out.
+template <bool NT>
+__device__ __forceinline__ void store_out_lines(half_t* tile_row0, int64_t row_stride_halves, uint32_t stage, const f32x16 (&oacc)[2],
+                                                float l_run, int lane, int nrows) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const int r32 = lane & 31, hh = lane >> 5;
+  const float inv = 1.0f / l_run;
+  u32x2 o2[8];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)(oacc[dt][rr * 4 + e] * inv);
+      o2[dt * 4 + rr] = __builtin_bit_cast(u32x2, o);
+    }
+  const uint32_t wrow = stage + (uint32_t)(r32 * 128);
+  const int wswz = (r32 >> 1) & 7;
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    u32x2 a = o2[k], b = o2[k + 1];
+    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    const u32x4 piece = u32x4{r0[0], r1[0], r0[1], r1[1]};          // 16-byte piece (k + hh) of row r32
+    if (r32 < nrows) asm volatile("ds_write_b128 %0, %1" :: "v"(wrow + (uint32_t)(((k + hh) ^ wswz) << 4)), "v"(piece) : "memory");
+  }
+  const int p = lane & 7, rl = lane >> 3;
+  u32x4 line[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rl + 8 * j;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(line[j]) : "v"(stage + (uint32_t)(r * 128 + ((p ^ ((r >> 1) & 7)) << 4))) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(line[0]), "+v"(line[1]), "+v"(line[2]), "+v"(line[3]) :: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = rl + 8 * j;
+    u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(tile_row0 + r * row_stride_halves) + 16 * p);
+    if (r < nrows) {
+      if constexpr (NT || (CLIPMI_ATTN_ABLATE & 1024)) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(line[j]) : "memory");
+      else if constexpr (CLIPMI_ATTN_ABLATE & 2048) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(line[j]) : "memory");
+      else *dst = line[j];
+    }
   }
 }
 
@@ -436,12 +527,16 @@ constexpr int VARR = VROWS * 128;            // one operand image
 constexpr int VBUF = 3 * VARR;               // K | V | Q
 constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of the last array
 
-__global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items
 #ifdef CLIPMI_TUNING
-                                                                  , long long* stamps   // diagnostic build: [item][wave 0..7 (7 = loader)][8]
+#define CLIPMI_VISION_STAMPS_PARAM , long long* stamps   // diagnostic build: [item][wave 0..7 (7 = loader)][8]
+#define CLIPMI_VISION_STAMPS_ARG , stamps
+#else
+#define CLIPMI_VISION_STAMPS_PARAM
+#define CLIPMI_VISION_STAMPS_ARG
 #endif
-                                                                  ) {
-  constexpr int NKT = 7, NT = 512, GROUP = 4;
+template <bool NT>   // NT: output rows stored non-temporal
+__device__ __forceinline__ void attention_vision_body(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
+  constexpr int NKT = 7, NTHR = 512, GROUP = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -449,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
   const int r32 = lane & 31, hh = lane >> 5;
   const int D = H * 64;
   const int64_t ld = 3 * (int64_t)D;
-  for (int i = tid * 16; i < VSMEM; i += NT * 16) *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid * 16; i < VSMEM; i += NTHR * 16) *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   int item = blockIdx.x;
@@ -462,8 +557,9 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
     const int lr = lane >> 3, cs = lane & 7;
     const int swv = (cs ^ (((lr >> 1) & 1) << 2)) << 4;                                        // V: chunk ^ (((row >> 1) & 1) << 2)
     const int swk[2] = {(cs ^ (lr >> 1)) << 4, (cs ^ (4 + (lr >> 1))) << 4};                    // K, Q: chunk ^ ((row >> 1) & 7), by group parity
-    const int lane_row = lr * (int)ld * 2;
-    const int gstep = 8 * (int)ld * 2;                                                          // one group further
+    constexpr bool FAKE = (CLIPMI_ATTN_ABLATE & 128) != 0;
+    const int lane_row = lr * (FAKE ? 64 : (int)ld) * 2;
+    const int gstep = 8 * (FAKE ? 64 : (int)ld) * 2;                                            // one group further
     auto radd = [](int base, int add) {
       int r;
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
@@ -471,15 +567,17 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
     };
     auto stage = [&](int it_, int buf) {
       const int n = it_ / H, h = it_ - n * H;
-      const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);   // rows >= L: outside, read as zero
+      const half_t* base = FAKE ? qkv + (int64_t)it_ * 3 * L * 64 : qkv + (int64_t)n * L * ld + h * 64;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, FAKE ? (int64_t)3 * L * 64 * 2 : ((int64_t)L * ld - h * 64) * 2);   // rows >= L: outside, read as zero
+      const int koff = FAKE ? L * 64 * 2 : D * 2;
       char* B = smem + buf * VBUF;
 #pragma unroll
       for (int g = 0; g < VROWS / 8; ++g) {
         const int kq = lane_row + swk[g & 1];
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + g * 1024, radd(kq + D * 2, g * gstep), 0);                        // K
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + VARR + g * 1024, radd(lane_row + swv + 2 * D * 2, g * gstep), 0);  // V
-        CLIPMI_BUFFER_LOAD_LDS16(rs, B + 2 * VARR + g * 1024, radd(kq, g * gstep), 0);                      // Q
+        constexpr int AUX = (CLIPMI_ATTN_ABLATE & 512) ? 2 : 0;   // nt
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + g * 1024), 16, radd(kq + koff, g * gstep), 0, 0, AUX);                        // K
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + VARR + g * 1024), 16, radd(lane_row + swv + 2 * koff, g * gstep), 0, 0, AUX);  // V
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + 2 * VARR + g * 1024), 16, radd(kq, g * gstep), 0, 0, AUX);                      // Q
       }
     };
     stage(item, 0);
@@ -510,7 +608,6 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
   // ---- query waves: no VMEM load in their instruction stream
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int q0 = wave * 32;
-  const int q = q0 + r32;
   const int kswz = (r32 >> 1) & 7;
   int kro[4], vro[2], qro[4];   // lane-constant byte offsets inside a buffer
 #pragma unroll
@@ -543,15 +640,25 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
       const uint32_t ka[4] = {lb + (uint32_t)kro[0], lb + (uint32_t)kro[1], lb + (uint32_t)kro[2], lb + (uint32_t)kro[3]};
       const uint32_t va[2] = {lb + (uint32_t)vro[0], lb + (uint32_t)vro[1]};
       const uint32_t qa[4] = {lb + (uint32_t)qro[0], lb + (uint32_t)qro[1], lb + (uint32_t)qro[2], lb + (uint32_t)qro[3]};
+#ifdef CLIPMI_TUNING
+      if ((CLIPMI_ATTN_ABLATE & 8) && wave >= 4) continue;
+      attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc, stamp ? sp : nullptr);
+#else
       attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc);
+#endif
     }
 #ifdef CLIPMI_TUNING
     asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[1][15]), "v"(lacc[0]));
     if (stamp) sp[2] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    if (q < L) {
+    if constexpr (CLIPMI_ATTN_ABLATE & 256) {
+      asm volatile("" :: "v"(oacc[0]), "v"(oacc[1]), "v"(lacc[0]));
+    } else {
+      // the wave's own Q rows of this item are dead (qf was read before the first MFMA): its output tile goes through them as full lines.
+      // Rows >= VROWS of the last tile would lie in the other buffer's K rows (being written by the loader): never parked (nrows <= 5 there).
       const int n = item / H, h = item - n * H;
-      store_out(out + ((int64_t)n * L + q) * D + h * 64, oacc, lacc[0], hh);
+      const int nrows = L - q0 < 32 ? L - q0 : 32;
+      store_out_lines<NT>(out + ((int64_t)n * L + q0) * D + h * 64, D, lds_base + (uint32_t)(buf * VBUF + 2 * VARR + q0 * 128), oacc, lacc[0], lane, nrows);
     }
 #ifdef CLIPMI_TUNING
     if (stamp) sp[3] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -559,12 +666,20 @@ __global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* 
   }
 }
 
+__global__ __launch_bounds__(512, 2) void attention_vision_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
+  attention_vision_body<false>(qkv, out, L, H, n_items CLIPMI_VISION_STAMPS_ARG);
+}
+__global__ __launch_bounds__(512, 2) void attention_vision_nt_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
+  attention_vision_body<true>(qkv, out, L, H, n_items CLIPMI_VISION_STAMPS_ARG);
+}
+
 // Measured on MI355X, B = 256 (tools/block_ab2.py, profiles/r02_attention_ab.txt): persistent kernel without a loader wave
 // 81-83 us, this kernel 74-78 us; two loader waves, compiler-placed fragment reads and the segmented forms were A/B arms of
 // round 2 (same bits, not faster) and are gone.
+template <bool NT>
 int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = attention_vision_kernel;
+  auto fn = NT ? attention_vision_nt_kernel : attention_vision_kernel;
   ensure_dynamic_lds(fn, VSMEM, attr_once);
   const int n_cu = device_cus();
   const int n_items = N * H;
@@ -709,7 +824,8 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
     if (!causal && L > 192) {
       // 193..200 tokens: every operand by DMA from a loader wave (attention_vision_kernel); wider rows do not fit the LDS.
       // Option attn_loader = 0 keeps the persistent kernel (same bits: the bit-identity reference of the tests).
-      if (L <= VROWS && options().attn_loader.load(std::memory_order_relaxed) != 0) return launch_vision(qkv, out, N, L, H, s);
+      const int loader = options().attn_loader.load(std::memory_order_relaxed);
+      if (L <= VROWS && loader != 0) return loader == 2 ? launch_vision<true>(qkv, out, N, L, H, s) : launch_vision<false>(qkv, out, N, L, H, s);
       return launch_persist<7, 4, 1>(qkv, out, N, L, H, causal, s);
     }
     return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);

@@ -53,8 +53,9 @@ struct Options {
                                              // (identical features; not the default: the headline benchmark computes every row)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
-  std::atomic<int> attn_loader{1};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 1 (default) = attention_vision_kernel (all operands by LDS-DMA
-                                       // from a loader wave, fragment reads pinned by inline asm); 0 = persistent kernel (same bits)
+  std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
+                                       // from a loader wave, fragment reads pinned by inline asm, output rows stored non-temporal); 1 = the same with plain
+                                       // stores; 0 = persistent kernel (all three: same bits)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
 };
 // cls_only_last_block, ln_fold and residual_f16 are DEFAULTS: a model handle may override them (clipmi_model_set_option) and a

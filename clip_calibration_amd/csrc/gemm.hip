@@ -16,6 +16,10 @@
 
 #include "common.h"
 
+#ifndef CLIPMI_STORE_AUX
+#define CLIPMI_STORE_AUX 0   // cache policy bits of the big output stores (2 = nt); build-time A/B: make libclipmi_gemmnt.so
+#endif
+
 namespace clipmi {
 
 namespace {
@@ -298,7 +302,10 @@ __device__ __forceinline__ void epilogue_residual_fold(f32x4 (&acc)[T::TN][T::TM
       const int row = t * 8 + rrow;
       const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
       const int m = m0 + wave_m * T::WTM + jc * 32 + row;
-      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      if (m < a.M && n_st < a.N) {
+        if constexpr (CLIPMI_STORE_AUX & 2) __builtin_nontemporal_store(val, reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st));
+        else *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -425,7 +432,10 @@ __device__ __forceinline__ void epilogue_residual_fold16_dma(f32x4 (&acc)[T::TN]
       const f16x8 val = *reinterpret_cast<const f16x8*>(reg + rl * 128 + dslot * 16);
       const int m = row0 + c * 32 + rl;
       const int n_st = col0 + ((dslot ^ ((rl >> 1) & 7)) << 3);
-      if (m < a.M && n_st < a.N) *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      if (m < a.M && n_st < a.N) {
+        if constexpr (CLIPMI_STORE_AUX & 2) __builtin_nontemporal_store(val, reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st));
+        else *reinterpret_cast<f16x8*>(a.x16 + (int64_t)m * a.ldo + n_st) = val;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (c + RD < NCH) dma_chunk(c + RD);   // its region was read (lgkmcnt drained for the stores above) a moment ago
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + p * 64);
     const int voff = col < a.N ? in_range : (int)0xFFFFFFF0;
     if constexpr (CLIPMI_ABLATE & 1) asm volatile("" ::"v"(v), "v"(voff));   // (energy ablation: no output stores at all)
-    else __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, CLIPMI_STORE_AUX);
   };
   constexpr int SPS = 2;   // stores per slice and wave
 
@@ -1617,7 +1627,6 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
   half_t* x16 = a.x16;
   const int lcol = (g4 & 1) * 16 + (g4 >> 1) * 8;
   const int st_lane = (r16 * (int)a.ldo + lcol) * 2;
-  const int slice_bytes = 16 * (int)a.ldo * 2;
   const bool col_ok[2] = {n0 + wave_n * 64 + lcol < a.N, n0 + wave_n * 64 + lcol + 32 < a.N};
   // accumulator block b of a tile of nbx pairs: half 0 holds h0 = ceil(nbx / 2) blocks (b = 0 .. h0 - 1), half 1 the other nbx - h0
   // (b = 5 ..); position = its index among the wave's nbx live blocks, i.e. rows 16 pos .. of the wave's part, which starts at row
@@ -1840,8 +1849,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
         }
         u32x4 o[2];
         pack_slice(cv, o);
-        __builtin_amdgcn_raw_buffer_store_b128(o[0], ors, slice_voff(cnb, b, 0), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o[1], ors, slice_voff(cnb, b, 1), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[0], ors, slice_voff(cnb, b, 0), 0, CLIPMI_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(o[1], ors, slice_voff(cnb, b, 1), 0, CLIPMI_STORE_AUX);
       } else {
         const u32x4 z = u32x4{0u, 0u, 0u, 0u};
         __builtin_amdgcn_raw_buffer_store_b128(z, ors, (int)0xFFFFFFF0, 0, 0);   // out of range: dropped

@@ -71,8 +71,9 @@ const char* clipmi_last_error(void);
  *                                             GEMMs, K >= 512 (in-proj / c_fc); 0 = one tile per workgroup (same bits with the bias epilogue)
  *   gemm_rstream     (CLIPMI_GEMM_RSTREAM)    1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
  *                                             residual GEMMs (out-proj / c_proj); 0 = one 320 x 256 tile per workgroup (same bits)
- *   attn_loader      (CLIPMI_ATTN_LOADER)     1 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
- *                                             by LDS-DMA from a dedicated loader wave; 0 = the persistent kernel (same bits)
+ *   attn_loader      (CLIPMI_ATTN_LOADER)     2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
+ *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
+ *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
  * and the process-wide DEFAULTS of the three per-model settings (clipmi_model_set_option overrides them per handle):
  *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block

@@ -280,16 +280,19 @@ def test_attention(ops, n, l, h, causal):
 @pytest.mark.parametrize("n,l,h", [(3, 197, 12), (2, 199, 12), (1, 193, 2), (5, 200, 1), (40, 197, 12)])
 def test_attention_vision_kernel_vs_persistent(ops, clipmi_option, n, l, h):
     """193..200-token non-causal attention (the image towers at 224 px; clip/model.py:181-183): the all-DMA kernel with a loader
-    wave (attn_loader 1, the default: fragment reads pinned ahead of their MFMAs by inline asm) and the persistent kernel
-    (attn_loader 0) give the SAME bits -- only the operand transport and the instruction order differ -- and match the fp32
+    wave (attn_loader 1: fragment reads pinned ahead of their MFMAs by inline asm; 2, the default: its output rows stored
+    non-temporal) and the persistent kernel (attn_loader 0) give the SAME bits -- only the operand transport and the instruction order differ -- and match the fp32
     reference.  40 sequences x 12 heads = several items per workgroup (both LDS buffers in use)."""
     clipmi_option("attn_loader", 1)
     g = torch.Generator().manual_seed(n * 1000 + l + h)
     qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
     got = ops.attention(_cuda(qkv), n, l, h, False)
+    clipmi_option("attn_loader", 2)   # the same kernel with non-temporal output stores
+    got_nt = ops.attention(_cuda(qkv), n, l, h, False)
     clipmi_option("attn_loader", 0)
     base = ops.attention(_cuda(qkv), n, l, h, False)
     assert torch.equal(got, base)
+    assert torch.equal(got_nt, base)
     ref = _attn_ref(qkv[: 2 * l], 2 if n >= 2 else 1, l, h, False) if n >= 2 else _attn_ref(qkv, n, l, h, False)
     err = (got[: ref.shape[0]].float().cpu() - ref).abs().max().item()
     assert err < 4e-3, f"max err {err}"
