@@ -146,16 +146,19 @@ def kernel_roofline(model, syn, geom, model_name, B, images):
     try:
         with open(os.path.join(ROOT, "profiles", "gemm_traffic.json")) as f:
             prof = json.load(f)
-        with open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "gemm.hip"), "rb") as f:
-            sha = hashlib.sha256(f.read()).hexdigest()
+        h = hashlib.sha256()
+        for name in ("gemm_common.h", "gemm.hip", "gemm_rstream.hip"):   # the GEMM kernels' sources (tools/traffic_json.py hashes the same)
+            with open(os.path.join(ROOT, "clip_calibration_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        sha = h.hexdigest()
         ent = prof.get("kernels", {}).get(dom["kernel"])
         if prof.get("gemm_hip_sha256") == sha and ent and ent["shape"] == dom["shape"]:
             traffic = ent["traffic_bytes"]
             note = ("HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB, rocprofv3 --pmc in separate passes with the gfx950 "
-                    "FETCH_SIZE x2 correction (profiles/gemm_traffic.json, measured on this gemm.hip); algorithmic bytes = "
+                    "FETCH_SIZE x2 correction (profiles/gemm_traffic.json, measured on these GEMM sources); algorithmic bytes = "
                     f"{ent.get('algorithmic_bytes')}")
         else:
-            note = "profiles/gemm_traffic.json was measured on a different gemm.hip: dropped"
+            note = "profiles/gemm_traffic.json was measured on different GEMM sources: dropped"
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "kernel": dom["kernel"] + " (dominant launch: one per layer, 12 per step)", "shape": dom["shape"],
@@ -427,12 +430,17 @@ def main():
         dac_conf = cal.class_confidence_device(dev)
         scale = float(np.exp(4.6052))                                                   # TempScaling scalar (tempscaling.py:34)
 
-        def text_again():
+        def text_fp32_stream():
             tuned_new._cache = None
             tuned_new._cache_key = None
             return tuned_new.text_features()
+        # the reference's schedule: prompt learner + text tower on every batch (coop.py:208-210).  The mirror's cache_text_features=False
+        # runs that per-batch tower call on the fp16 residual stream (per-call flag; the cached features above keep the fp32 stream)
+        per_batch = CoOpCLIP(model, ids_new, n_ctx=n_ctx, logit_scale=1.0, seed=3, cache_text_features=False)
+        text_again = per_batch.text_features
         with torch.no_grad():
-            text_s = timed_ms(text_again, 5) * 1e-3
+            text_s = timed_ms(text_fp32_stream, 5) * 1e-3
+            text_s_per_batch = timed_ms(text_again, 5) * 1e-3
         text_features = tuned_new.text_features()
     else:
         ids = syn.synthetic_token_ids(Cn, args.model, seed=0)
@@ -523,11 +531,30 @@ def main():
             for _ in range(2):
                 step(labels, True)
             elapsed_rt, _ = run(labels, n_rt, True)
+            res_rt = evaluator.evaluate()
+            # how far the per-batch (fp16-stream) text features are from the cached (fp32-stream) ones, on this batch's logits: synthetic
+            # weights give near-tied classes, so a few argmax flips (each inside the top-2 margin printed here) move accuracy / ECE
+            lg16, lg32 = step(None, True)[0].float(), step(None)[0].float()     # logits as the evaluator sees them (DAC row scale applied)
+            p16, p32 = lg16.argmax(1), lg32.argmax(1)
+            top2 = lg32.topk(2, dim=1).values
+            flipped = (p16 != p32).nonzero().flatten()
+            t16, t32 = text_again().double(), text_features.double()             # both L2-normalised [C, E]
+            stream_delta = {"max_text_feature_l2_distance": float((t16 - t32).norm(dim=1).max()),   # bounds every cosine-logit difference
+                            "max_one_minus_cosine": float((1.0 - (t16 * t32).sum(1)).max()),
+                            "max_abs_logit_diff_after_dac": float((lg16 - lg32).abs().max()), "logit_scale": scale,
+                            "note": "a row whose argmax flips takes another class's DAC factor, which rescales the whole row: that is the logit "
+                                    "difference; between the features themselves the distance bounds any cosine-logit difference",
+                            "pred_flips": int(flipped.numel()), "rows": int(p32.numel()),
+                            "max_top2_margin_of_flipped_rows": float((top2[flipped, 0] - top2[flipped, 1]).max()) if flipped.numel() else 0.0}
+            tf = (lambda t: 5.960e9 * Cn / t / 1e12) if args.model == "ViT-B/16" else (lambda t: None)
             extra["coop_dac"] = {
                 "images_per_s_text_cached": world * B * args.steps / elapsed,
                 "images_per_s_text_recomputed_every_batch": world * B * n_rt / elapsed_rt,
-                "text_tower_prompts_per_s": Cn / text_s, "text_tower_ms": 1e3 * text_s,
-                "text_tower_tflops": 5.960e9 * Cn / text_s / 1e12 if args.model == "ViT-B/16" else None,
+                "text_tower_prompts_per_s": Cn / text_s, "text_tower_ms": 1e3 * text_s, "text_tower_tflops": tf(text_s),
+                "per_batch_text_tower": {"stream": "fp16 (CLIPMI_CALL_STREAM_F16; CoOpCLIP(cache_text_features=False))",
+                                         "ms": 1e3 * text_s_per_batch, "prompts_per_s": Cn / text_s_per_batch, "tflops": tf(text_s_per_batch),
+                                         "ece_percent": float(res_rt["ece"]), "accuracy_percent": float(res_rt["accuracy"]),
+                                         "ece_percent_text_cached_fp32_stream": float(res["ece"]), "vs_cached_fp32_stream": stream_delta},
                 "note": "the reference recomputes the text tower on every batch (trainers/classification/coop.py:208-210); "
                         "ctx is frozen at eval, so the features are cached here (precedent: proda.py:315-333)",
                 "n_ctx": 16, "dac": "on (k = 5)", "tempscaling_logit_scale": 4.6052}

@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
     __syncthreads();
   }
   if (!dac && wide) {   // uniform: merge the row block's partials (calibrate_row's blockwise form, block by block in ascending order)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(partials, (int64_t)B * gridDim.y * (int)sizeof(TailPartial));
     const int row = m0 + threadIdx.x;   // thread t owns row t of the block
     if (threadIdx.x < RB && row < B) {

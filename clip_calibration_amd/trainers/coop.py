@@ -81,11 +81,19 @@ class CustomCLIP(nn.Module):
     The reference re-runs the 12-layer text tower on every batch although ``ctx`` is frozen at test time; the text
     features are cached here and recomputed only when ``ctx`` changes (same outputs; precedent in the reference:
     ProDA's set_classifier, proda.py:315-333).  ``logit_scale=1.0`` gives the cosine-logit base model of
-    trainers/calibration/base_model/coop.py:222-224."""
+    trainers/calibration/base_model/coop.py:222-224.
+
+    ``cache_text_features=False`` is the reference's own schedule (coop.py:208-210: prompt learner + text tower on every
+    batch).  The text tower is then per-batch work, and ``text_stream_f16`` (None = "when not cached") runs it on the fp16
+    residual stream -- the reference's own GPU precision, clip/model.py:186-187 -- through the per-call flag
+    CLIPMI_CALL_STREAM_F16, as the CoCoOp mirror does: -17 % per text tower call at 500 classes
+    (profiles/r03_bench_coop_dac.json).  Cached features keep the fp32 stream: they are computed once and feed every logit."""
 
     def __init__(self, clip_model: CLIP, tokenized_prompts: torch.Tensor, n_ctx: int = 16, csc: bool = False,
-                 logit_scale: Optional[float] = None, cache_text_features: bool = True, **kw):
+                 logit_scale: Optional[float] = None, cache_text_features: bool = True,
+                 text_stream_f16: Optional[bool] = None, **kw):
         super().__init__()
+        self.text_stream_f16 = text_stream_f16
         self.prompt_learner = PromptLearner(clip_model, tokenized_prompts, n_ctx, csc, **kw)
         self.tokenized_prompts = self.prompt_learner.tokenized_prompts
         self.image_encoder = clip_model.visual
@@ -105,6 +113,15 @@ class CustomCLIP(nn.Module):
     def _text_inputs(self):
         return self.prompt_learner(), None, 0
 
+    def _text_flags(self) -> int:
+        from .. import _lib
+        want = (not self.cache_text_features) if self.text_stream_f16 is None else self.text_stream_f16
+        m = self.clip_model
+        # a model (or process) set to residual_f16 != 2 or ln_fold = 0 has chosen its streams explicitly: no per-call override
+        if want and m.get_option("residual_f16") == 2 and m.get_option("ln_fold") == 1:
+            return _lib.CALL_STREAM_F16
+        return _lib.CALL_DEFAULT
+
     def _cache_params(self):
         """Everything the cached text features depend on (besides the frozen tower weights)."""
         return list(self.prompt_learner.parameters())
@@ -115,7 +132,7 @@ class CustomCLIP(nn.Module):
         if self.cache_text_features and key == self._cache_key and self._cache is not None:
             return self._cache
         prompts, deep, n_ctx = self._text_inputs()
-        tf = ops.l2_normalize(self.text_encoder(prompts, self.tokenized_prompts, deep, n_ctx))
+        tf = ops.l2_normalize(self.text_encoder(prompts, self.tokenized_prompts, deep, n_ctx, flags=self._text_flags()))
         self._cache_key, self._cache = key, tf
         return tf
 

@@ -217,9 +217,12 @@ def test_zeroshot_pipeline_vs_oracle(B):
         assert top2[1] - top2[0] < 2 * 100 * COS_TOL
 
 
-def test_coop_dac_tempscaling_pipeline_vs_oracle():
+@pytest.mark.parametrize("cached", [True, False])
+def test_coop_dac_tempscaling_pipeline_vs_oracle(cached):
     """BASELINE config 3 (scaled down in C): CoOp prompts -> cached text features; DAC fit on the four text-feature
-    sets; cosine base model + TempScaling scalar; DAC per-sample scale fused into the logits kernel."""
+    sets; cosine base model + TempScaling scalar; DAC per-sample scale fused into the logits kernel.  cached = False is the
+    reference's schedule (text tower on every batch, coop.py:208-210), which the mirror runs on the fp16 residual stream
+    (per-call flag): same tolerances against the fp32 oracle."""
     from clip_calibration_amd.trainers import CoOpCLIP, ZeroshotCLIP, CustomCLIPCalibration
     from clip_calibration_amd.dac import DistanseAwareCalibration
     C, B, n_ctx = 40, 16, 16
@@ -229,8 +232,10 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle():
     ids_coop_base = syn.synthetic_token_ids(C, "ViT-B/16", seed=10, n_ctx_placeholders=n_ctx)
     ids_coop_new = syn.synthetic_token_ids(C, "ViT-B/16", seed=11, n_ctx_placeholders=n_ctx)
     images = syn.synthetic_images(B, "ViT-B/16", seed=7)
-    coop_new = CoOpCLIP(model, ids_coop_new, n_ctx=n_ctx, logit_scale=1.0, seed=3)       # cosine base model
-    coop_base = CoOpCLIP(model, ids_coop_base, n_ctx=n_ctx, logit_scale=1.0, seed=3)
+    coop_new = CoOpCLIP(model, ids_coop_new, n_ctx=n_ctx, logit_scale=1.0, seed=3, cache_text_features=cached)   # cosine base model
+    coop_base = CoOpCLIP(model, ids_coop_base, n_ctx=n_ctx, logit_scale=1.0, seed=3, cache_text_features=cached)
+    from clip_calibration_amd import _lib
+    assert coop_new._text_flags() == (_lib.CALL_DEFAULT if cached else _lib.CALL_STREAM_F16)
     ctx = coop_new.prompt_learner.ctx.detach().float().cpu()
     # oracle text features
     with torch.no_grad():
@@ -239,7 +244,11 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle():
         z_new = orc.l2_normalize(orc.encode_text(sd, ids_zs_new))
         z_base = orc.l2_normalize(orc.encode_text(sd, ids_zs_base))
     got_new = coop_new.text_features()
-    assert coop_new.text_features() is got_new                                   # cached while ctx is unchanged
+    if cached:
+        assert coop_new.text_features() is got_new                               # cached while ctx is unchanged
+    else:
+        again = coop_new.text_features()                                         # recomputed, same bits
+        assert again is not got_new and torch.equal(again, got_new)
     assert np.abs(got_new.cpu().numpy() @ t_new.numpy().T - (t_new @ t_new.t()).numpy()).max() < COS_TOL
     # DAC fit on device-produced features vs oracle-produced features
     zs_new = ZeroshotCLIP(model, ids_zs_new); zs_base = ZeroshotCLIP(model, ids_zs_base)

@@ -3,7 +3,7 @@
 prompts, and a CoCoOp step (B images x C classes -> B*C prompts) -- the f-4 workload whose cost is the TEXT tower."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from clip_calibration_amd import synthetic as syn
+from clip_calibration_amd import _lib, synthetic as syn
 from clip_calibration_amd.model import build_model
 from clip_calibration_amd.trainers import CoCoOpCLIP
 
@@ -24,8 +24,9 @@ def timed(fn, n):
 
 for C in [int(c) for c in os.environ.get("CS", "100,500,1000,2000,4000,8000").split(",")]:
     ids = syn.synthetic_token_ids(C, G, seed=1).cuda()
-    dt = timed(lambda: model.text_features_f32(ids), max(2, 4000 // C))
-    print(f"encode_text C={C:5d}: {dt*1e3:8.2f} ms  {C/dt:9.0f} prompts/s  {C*fpp/dt/1e12:7.1f} TFLOP/s", flush=True)
+    for what, flags in (("fp32 stream (default)", _lib.CALL_DEFAULT), ("fp16 stream (per-call flag)", _lib.CALL_STREAM_F16)):
+        dt = timed(lambda: model.text_features_f32(ids, flags=flags), max(2, 4000 // C))
+        print(f"encode_text C={C:5d} {what:28s}: {dt*1e3:8.2f} ms  {C/dt:9.0f} prompts/s  {C*fpp/dt/1e12:7.1f} TFLOP/s", flush=True)
 
 if os.environ.get("COCOOP", "1") == "1":
     for B, C, per_call in ((32, 100, 3200), (32, 100, 800), (16, 1000, 4000), (16, 1000, 8000)):

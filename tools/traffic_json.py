@@ -67,7 +67,10 @@ def main():
     for per in (fetch, write):   # 12 layers x RUNS passes of the image tower, nothing else (a text-tower dispatch would have another shape)
         for role in SHAPES:
             assert runs is None or len(per.get(role, [])) == 12 * runs, f"{role}: {len(per.get(role, []))} dispatches, expected {12 * runs}"
-    sha = hashlib.sha256(open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for name in ("gemm_common.h", "gemm.hip", "gemm_rstream.hip"):
+        h.update(open(os.path.join(ROOT, "clip_calibration_amd", "csrc", name), "rb").read())
+    sha = h.hexdigest()
     kernels = {}
     for role, (m, n, k) in SHAPES.items():
         if not fetch.get(role) or not write.get(role):
