@@ -89,6 +89,8 @@ class CustomCLIP(nn.Module):
     CLIPMI_CALL_STREAM_F16, as the CoCoOp mirror does: -17 % per text tower call at 500 classes
     (profiles/r03_bench_coop_dac.json).  Cached features keep the fp32 stream: they are computed once and feed every logit."""
 
+    text_stream_f16: Optional[bool] = None   # class default for mirrors that build themselves (MaPLe)
+
     def __init__(self, clip_model: CLIP, tokenized_prompts: torch.Tensor, n_ctx: int = 16, csc: bool = False,
                  logit_scale: Optional[float] = None, cache_text_features: bool = True,
                  text_stream_f16: Optional[bool] = None, **kw):
