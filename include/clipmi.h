@@ -70,7 +70,8 @@ const char* clipmi_last_error(void);
  *   gemm_stream      (CLIPMI_GEMM_STREAM)     1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out
  *                                             GEMMs, K >= 512 (in-proj / c_fc); 0 = one tile per workgroup (same bits with the bias epilogue)
  *   gemm_rstream     (CLIPMI_GEMM_RSTREAM)    1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
- *                                             residual GEMMs (out-proj / c_proj); 0 = one 320 x 256 tile per workgroup (same bits)
+ *                                             residual GEMMs with K <= 1536 (out-proj); 0 = one 320 x 256 tile per workgroup.  The row-range
+ *                                             kernel adds the residual inside its K loop: both round the same fp32 sum once, in another order
  *   attn_loader      (CLIPMI_ATTN_LOADER)     2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
  *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
  *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)
@@ -100,8 +101,9 @@ int clipmi_gemm_f16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
 /* The residual GEMM of a block on the fp16 residual stream (out-proj / c_proj, clip/model.py:186-187: `x = x + f(x)` on fp16 tensors):
  * x16[m,n] = fp16(x16[m,n] + A[m,:] . W[n,:] + bias[n]) IN PLACE (one rounding of the fp32 sum), plus the LayerNorm-fold row
  * partials the next GEMM consumes: stats[(t * M + m) * 2 + {0,1}] = (sum, sum of squares) over the 256 columns of column tile t of
- * the ROUNDED row m; *parts (host int) receives the number of column tiles, (N + 255) / 256 <= 8.  A fp16 [M,K] (lda), W fp16 [N,K]
- * (ldw), bias fp32 [N], x16 fp16 [M,N] (ldx), stats fp32 [parts * M * 2].  K % 64 == 0, N % 8 == 0, ldx % 8 == 0, 16-byte aligned. */
+ * the ROUNDED row m; *parts (host int) receives the number of column tiles of the kernel that ran: (N + 255) / 256 with every default
+ * dispatch, (N + 127) / 128 when gemm_variant = 0 is forced (partials are then per 128 columns); at most 8 either way.  A fp16 [M,K]
+ * (lda), W fp16 [N,K] (ldw), bias fp32 [N], x16 fp16 [M,N] (ldx), stats fp32 [8 * M * 2] (room for the largest count).  K % 64 == 0, N % 8 == 0, ldx % 8 == 0, 16-byte aligned. */
 int clipmi_gemm_residual_f16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* x16, int64_t ldx,
                              float* stats, int* parts, int M, int N, int K, clipmi_stream_t stream);
 
