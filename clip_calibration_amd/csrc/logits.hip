@@ -450,11 +450,12 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
       }
     }
   }
-  // ---- phase 2: the workgroup's 32 x 64 logits tile.  Rows 16-byte aligned (C % 4 == 0): through an LDS tile, two 16-byte
-  //      write-through (sc1) stores per thread -- whole 64-byte row pieces, and no release fence is needed for the hand-off
-  //      below (cdna_hip_programming.md Guideline 16, R1).  Otherwise: 4-byte stores from the accumulator layout + a release.
+  // ---- phase 2: the workgroup's RB x 64 logits tile, through an LDS tile.  Rows 16-byte aligned (C % 4 == 0): 16-byte
+  //      write-through (sc1) stores -- whole 64-byte row pieces, and no release fence is needed for the hand-off below
+  //      (cdna_hip_programming.md Guideline 16, R1).  Ragged class counts: 4-byte plain stores of the same pieces (a release only
+  //      where the last workgroup reads the logits back, i.e. with DAC).
   const bool wide = (C & 3) == 0;   // uniform
-  if (wide) {
+  {
     __syncthreads();                // every wave is done reading the image rows: the tile takes their place
     float* tile = reinterpret_cast<float*>(smem);
     // D layout: col = lane&15 (n), row = (lane>>4)*4 + reg (m)
@@ -470,9 +471,15 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
       const int pidx = h * 256 + threadIdx.x;
       const int trow = pidx >> 4, tq = pidx & 15;
       const int mm = m0 + trow, nn = blockIdx.y * 64 + tq * 4;
-      if (mm < B && nn < C) {       // C % 4 == 0: a 4-column piece is entirely inside or outside
+      if (mm < B && nn < C) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * TAIL_TILE_LD + tq * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
+        if (wide) {                 // C % 4 == 0: rows are 16-byte aligned and a 4-column piece is entirely inside or outside
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), lrs, (int)(((int64_t)mm * C + nn) * 4), 0, 16 /* sc1 */);
+        } else {                    // ragged class counts (e.g. 199): 4-byte stores, the same 64-byte row pieces per 16 threads
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nn + e < C) logits[(int64_t)mm * C + nn + e] = v[e];
+        }
       }
     }
     // ---- phase 2b (no DAC): this workgroup's share of the row pass, from the tile while it is still in LDS -- per row the block's
@@ -490,14 +497,6 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p), prs, (int)(((int64_t)(m0 + trow) * gridDim.y + blockIdx.y) * (int)sizeof(TailPartial)), 0, 16 /* sc1 */);
       }
     }
-  } else if (cols_live && n0 + r < C) {
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int mm = m0 + rb * 16 + g * 4 + e;
-        if (mm < B) logits[(int64_t)mm * C + n0 + r] = scale * acc[rb][e];
-      }
   }
   if (!dac && !conf && !pred && !bins) return;   // logits only (kernel argument: uniform)
 
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (!wide) {   // plain stores: write this XCD's L2 back before the ticket (write-through stores need no release)
+    if (!wide && dac) {   // plain logits stores that the last workgroup reads back: write this XCD's L2 back before the ticket (write-through stores need no release)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keep: the compiler may drop the fence's own wait (Guideline 16, pitfall 12)
     }
@@ -527,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
     for (int t = threadIdx.x; t < 3 * (n_bins + 1); t += 256) sbins[t] = 0.0;
     __syncthreads();
   }
-  if (!dac && wide) {   // uniform: merge the row block's partials (calibrate_row's blockwise form, block by block in ascending order)
+  if (!dac) {   // uniform: merge the row block's partials (calibrate_row's blockwise form, block by block in ascending order)
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(partials, (int64_t)B * gridDim.y * (int)sizeof(TailPartial));
     const int row = m0 + threadIdx.x;   // thread t owns row t of the block
     if (threadIdx.x < RB && row < B) {
@@ -536,7 +535,20 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
       merge_begin(M, arg, sum);
       const int nt = gridDim.y;
       const int base = (int)((int64_t)row * nt * (int)sizeof(TailPartial));
-      for (int t0 = 0; t0 < nt; t0 += 16) {   // sc1 loads (every store of these bytes was sc1 and drained before its ticket), 16 in flight
+      if (nt <= 16) {   // uniform (C <= 1024): ONE trip, both passes from registers -- same order, same bits
+        TailPartial p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)   // sc1 loads: every store of these bytes was sc1 and drained before its ticket
+          if (u < nt) p[u] = __builtin_bit_cast(TailPartial, __builtin_amdgcn_raw_buffer_load_b128(prs, base + u * (int)sizeof(TailPartial), 0, 16 /* sc1 */));
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (u < nt) merge_max(p[u], M, arg);
+        if (arg == 0x7fffffff) arg = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (u < nt) merge_sum(p[u], M, sum);
+      } else {
+      for (int t0 = 0; t0 < nt; t0 += 16) {
         TailPartial p[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
@@ -555,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
         for (int u = 0; u < 16; ++u)
           if (t0 + u < nt) merge_sum(p[u], M, sum);
       }
+      }
       const float cf = 1.0f / sum;
       if (conf) conf[row] = cf;
       if (pred) pred[row] = arg;
@@ -564,26 +577,6 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
         atomicAdd(&sbins[b], 1.0);
         atomicAdd(&sbins[nb1 + b], x);
         atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)arg) ? 1.0 : 0.0);
-      }
-    }
-  } else if (!dac) {   // C % 4 != 0 (plain stores, no partials): the reference row pass itself, one wave per row
-    for (int q = 0; q < RPW; ++q) {
-      const int row = m0 + wave * RPW + q;
-      if (row < B) {   // uniform
-        float cf;
-        int pi;
-        calibrate_row(logits + (int64_t)row * C, nullptr, C, nullptr, lane, cf, pi);
-        if (lane == 0) {
-          if (conf) conf[row] = cf;
-          if (pred) pred[row] = pi;
-          if (bins) {
-            const double x = (double)cf;
-            const int b = ece_bin(x, n_bins), nb1 = n_bins + 1;
-            atomicAdd(&sbins[b], 1.0);
-            atomicAdd(&sbins[nb1 + b], x);
-            atomicAdd(&sbins[2 * nb1 + b], (labels[row] == (int64_t)pi) ? 1.0 : 0.0);
-          }
-        }
       }
     }
   } else
