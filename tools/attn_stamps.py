@@ -10,7 +10,7 @@ assert hasattr(_lib.lib, "clipmi_tuning_set_stamps"), "needs CLIPMI_LIBRARY=.../
 _lib.lib.clipmi_tuning_set_stamps.argtypes = [ctypes.c_void_p]
 n, l, h = 256, 197, 12
 qkv = torch.randn(n * l, 3 * 64 * h, device="cuda").half()
-for mode in [int(x) for x in os.environ.get("MODES", "1").split(",")]:
+for mode in [int(x) for x in os.environ.get("MODES", "2").split(",")]:
     _lib.set_option("attn_loader", mode)
     for _ in range(3):
         ops.attention(qkv, n, l, h, False)

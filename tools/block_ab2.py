@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tuning aid: interleaved A/B of several (option = value) CONFIGURATIONS on the per-layer kernels and the whole image tower.
-    CONFIGS="gemm_stream=0,gemm_persist=0;gemm_stream=0,gemm_persist=2" python tools/block_ab2.py"""
+    CONFIGS="gemm_stream=0,gemm_rstream=0;gemm_stream=1,gemm_rstream=1" python tools/block_ab2.py"""
 import os, statistics, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clip_calibration_amd import _lib, synthetic as syn

@@ -30,8 +30,8 @@ with torch.no_grad():
     model.image_features_f32(images)          # real activations in the workspace
 torch.cuda.synchronize()
 
-CASES = [("in_proj", 0, None), ("out_proj", 2, None), ("c_fc", 3, None), ("c_proj", 4, None),
-         ("in_proj persistent", 0, 11), ("c_fc persistent", 3, 11), ("in_proj stream", 0, 13), ("c_fc stream", 3, 13)]
+# (name, step of the block, forced gemm_variant or None = one tile per workgroup); out-proj's row-range kernel: tools/rstream_stamps.py
+CASES = [("in_proj", 0, None), ("out_proj", 2, 10), ("c_fc", 3, None), ("c_proj", 4, 10), ("in_proj stream", 0, 13), ("c_fc stream", 3, 13)]
 if os.environ.get("CASES"):
     CASES = [c for c in CASES if c[0] in os.environ["CASES"].split(",")]
 for name, step, variant in CASES:
