@@ -2,8 +2,8 @@
 (reference trainers/classification/base_learner.py:59-152, 184-300) -- SURVEY §8(f) rows f-1..f-3, restated around the
 device-side path.  What changes against the reference's loop:
 
-* host batches reach the GPU through pinned staging buffers and a side copy stream, a batch ahead (``device_batches``), instead of
-  a synchronous pageable ``.to(device)`` per batch;
+* host batches reach the GPU on a side copy stream, a batch ahead (``device_batches``: ``non_blocking`` from pinned memory), instead
+  of a synchronous ``.to(device)`` on the compute stream per batch;
 * logits, features and labels stay on the GPU; per batch the fused logits kernel already applies DAC and returns
   (conf, pred), which feed the device ECE accumulators -- no ``.cpu().numpy().tolist()`` per batch;
 * test-image proximity is one kNN kernel launch over the kept [N,E] features instead of a Python loop per query;

@@ -777,6 +777,33 @@ def test_rn50_geometry_vs_oracle():
     _feat_close(got, ref, "RN50 image tower vs oracle")
 
 
+@pytest.mark.parametrize("source", ["pageable", "pinned", "device"])
+def test_device_batches_order_and_values(source):
+    """runner.device_batches (the host -> device leg of the test loop, base_learner.py:84-88,175-182): batches arrive in order and
+    intact from pageable, pinned and device-resident sources, including a ragged last batch, while a kernel queue keeps the compute
+    stream busy (the consumer must wait on the copy's event, not on the host)."""
+    from clip_calibration_amd.runner import device_batches
+    g = torch.Generator().manual_seed(5)
+    sizes = [8, 8, 8, 3]
+    host = [(torch.randn(b, 3, 32, 32, generator=g), torch.randint(0, 10, (b,), generator=g)) for b in sizes]
+    if source == "pinned":
+        src = [(x.pin_memory(), y.pin_memory()) for x, y in host]
+    elif source == "device":
+        src = [(x.cuda(), y.cuda()) for x, y in host]
+    else:
+        src = host
+    busy = torch.randn(1 << 24, device="cuda")
+    seen = []
+    for (x, y) in device_batches(iter(src), "cuda"):
+        busy.mul_(1.0001)                                   # work in flight on the consumer's stream
+        assert x.is_cuda and y.is_cuda
+        seen.append((x.sum(dim=(1, 2, 3)), x.clone(), y.clone()))
+    torch.cuda.synchronize()
+    assert [s[1].shape[0] for s in seen] == sizes
+    for (hx, hy), (_, dx, dy) in zip(host, seen):
+        assert torch.equal(dx.cpu(), hx) and torch.equal(dy.cpu(), hy)
+
+
 def test_runner_base_to_new_calibration_flow(tmp_path):
     """f-1..f-3 around the path, tiny geometry: base-val feature cache -> base_features.pt round trip -> text_feature_dict
     -> VLCalibration(DAC).fit -> test() with proximity; every number against the oracle's restatement of
