@@ -1,10 +1,12 @@
 // Multi-head self attention after the packed in-projection (reference clip/model.py:181-183 ->
 // nn.MultiheadAttention -> scaled_dot_product_attention; SURVEY a-5a), head_dim 64, fp16 in/out, fp32 softmax.
 //
-// One workgroup per (sequence, head); each wave owns one 32-query tile.  Sequences here are short (77 / 197 /
-// 199 / 257 / 577 tokens), so K and V of a key block (NKT*32 keys) are staged ONCE per workgroup into LDS with
-// global_load_lds (K: 128-B rows, XOR swizzle for ds_read_b128 row reads; V: 128-B rows, a second XOR so that
-// ds_read_b64_tr_b16 transposed reads spread over the bank row).  Q fragments come straight from global memory.
+// Three kernels by sequence length (launch_attention): attention_vision_kernel (193..200 tokens, non-causal: the image towers at
+// 224 px), attention_persist_kernel (up to 224 tokens: the text tower and the other vision lengths) and attention_stream_kernel
+// (257 / 577 tokens: ViT-L/14).  In all of them a (sequence, head) item is worked by one workgroup, each wave owning one 32-query
+// tile; K and V of a key block (NKT*32 keys) are staged ONCE per workgroup into LDS by LDS-DMA (buffer_load ... lds; K: 128-B
+// rows, XOR swizzle for ds_read_b128 row reads; V: 128-B rows, a second XOR so that ds_read_b64_tr_b16 transposed reads spread
+// over the bank row).  Q fragments come from global memory, or by DMA too in the vision kernel.
 //
 //   S^T tile = K_tile(32 keys x 64) * Q^T           v_mfma_f32_32x32x16_f16, A = K rows, B = Q rows
 //   softmax over keys                                 keys live in the 16 accumulator registers x NKT tiles of a lane
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(512, 2) void attention_vision_nt_kernel(const half_
 
 // Measured on MI355X, B = 256 (tools/block_ab2.py, profiles/r02_attention_ab.txt): persistent kernel without a loader wave
 // 81-83 us, this kernel 74-78 us; two loader waves, compiler-placed fragment reads and the segmented forms were A/B arms of
-// round 2 (same bits, not faster) and are gone.
+// round 2 (same bits, not faster) and are gone.  Round 3 (profiles/r03_attention_ablation.txt, r03_attention_store_policy.txt): the
+// launch is bounded by its 310 MB, not by either pipe; with full-line non-temporal output stores 64-66 us (NT = true, the default).
 template <bool NT>
 int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
   static DeviceOnce attr_once;
