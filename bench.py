@@ -134,6 +134,12 @@ def kernel_roofline(model, syn, geom, model_name, B, images):
         tf = blk_flop[name] / (blk_ms[name] * 1e-3) / 1e12
         kernels.append({"kernel": name, "shape": blk_shape[name], "flop_per_launch": blk_flop[name], "us_per_launch": 1e3 * blk_ms[name],
                         "achieved": tf, "frac": tf / MFMA_F16_DENSE_PEAK_TFLOPS})
+        if name == "attention":
+            # the kernel's own bound is its bytes, not either pipe (profiles/r03_attention_ablation.txt): q | k | v in once, rows out once, fp16
+            byts = 2.0 * M * (3 * D + D)
+            gbps = byts / (blk_ms[name] * 1e-3) / 1e9
+            kernels[-1]["hbm"] = {"bound": "hbm", "algorithmic_bytes": byts, "achieved": gbps, "peak": (HBM_PEAK_BYTES_PER_S / 1e9), "unit": "GB/s",
+                                  "frac": gbps / (HBM_PEAK_BYTES_PER_S / 1e9)}
     dom = max(kernels, key=lambda k: k["us_per_launch"])
     with torch.no_grad():
         tower_ms = timed_ms(lambda: model.image_features_f32(images), 10)

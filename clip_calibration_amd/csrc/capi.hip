@@ -44,6 +44,7 @@ const OptionDesc kOptions[] = {
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_loader", "CLIPMI_ATTN_LOADER", &Options::attn_loader},
     {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
+    {"vision_pass", "CLIPMI_VISION_PASS", &Options::vision_pass},
 };
 
 // environment spelling -> option value: decimal integers, plus the historical letters of two switches
@@ -598,15 +599,37 @@ int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w) {
   return CLIPMI_OK;
 }
 
+// Images per pass of the image tower.  Throughput per image peaks where one pass works on about 50 432 x 768 stream elements (ViT-B/16:
+// 256 images; ViT-L/14: 128; ViT-L/14@336: 64; ViT-B/32: 992) and falls 8-10 % for passes two to four times that size, whose
+// activations (0.3 GB of MLP hidden state per pass at the peak) no longer find their consumers' reads in the 256 MB Infinity Cache
+// (profiles/r03_batch_passes.txt).  A larger batch is therefore run as consecutive passes on the same stream and workspace; images are
+// independent of their batch (the tests assert batch invariance bit for bit), so the features are the same bits.  Option vision_pass = the
+// element count (0 = never split).
+static int pass_images(int batch, int L, int D) {
+  const int64_t elems = options().vision_pass.load(std::memory_order_relaxed);
+  if (elems <= 0) return batch;
+  int64_t p = elems / ((int64_t)L * D);
+  p = p >= 32 ? p / 32 * 32 : (p < 1 ? 1 : p);
+  if ((int64_t)batch * 2 < p * 3) return batch;   // less than one and a half passes: not worth a ragged second one
+  return (int)p;
+}
+
 size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx) {
   if (!m || batch < 0 || n_ctx < 0) return 0;
-  return carve(nullptr, (int64_t)batch * (m->tokens0() + n_ctx), m->g.vision_width, batch, m->col_bytes(batch)).bytes;
+  const int L = m->tokens0() + n_ctx;
+  const int pass = pass_images(batch, L, m->g.vision_width);
+  const int largest = batch <= pass ? batch : pass + pass / 4;   // a remainder below a quarter pass joins the last pass
+  const int b = largest < batch ? largest : batch;
+  return carve(nullptr, (int64_t)b * L, m->g.vision_width, b, m->col_bytes(b)).bytes;
 }
 
 size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
   if (!m || n_prompts < 0) return 0;
   return carve(nullptr, (int64_t)n_prompts * m->g.context_length, m->g.text_width, n_prompts).bytes;
 }
+
+static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
+                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream);
 
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
                         void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
@@ -615,8 +638,26 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
   CLIPMI_REQUIRE(batch >= 0, CLIPMI_ERR_SHAPE, "encode_image: batch=%d", batch);
   if (batch == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(image && out && workspace, CLIPMI_ERR_ARG, "encode_image: null pointer");
+  CLIPMI_REQUIRE(image_dtype == CLIPMI_F16 || image_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "encode_image: image dtype %d", image_dtype);
   int rc = check_hook(hook, m->g.vision_layers, true);
   if (rc) return rc;
+  const int L = m->tokens0() + (hook ? hook->n_ctx : 0);
+  const int pass = pass_images(batch, L, m->g.vision_width);
+  const size_t image_bytes = (size_t)3 * m->g.image_resolution * m->g.image_resolution * (image_dtype == CLIPMI_F16 ? 2 : 4);
+  for (int lo = 0; lo < batch;) {
+    int n = batch - lo < pass ? batch - lo : pass;
+    if (batch - lo - n < pass / 4) n = batch - lo;   // a short remainder joins this pass
+    rc = encode_image_pass(m, static_cast<const char*>(image) + (size_t)lo * image_bytes, image_dtype, n, hook, out + (size_t)lo * m->g.embed_dim,
+                           workspace, workspace_bytes, flags, stream);
+    if (rc) return rc;
+    lo += n;
+  }
+  return CLIPMI_OK;
+}
+
+static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
+                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
+  int rc = CLIPMI_OK;
   hipStream_t s = (hipStream_t)stream;
   const clipmi_geometry& g = m->g;
   const int G = m->grid(), L0 = m->tokens0(), n_ctx = hook ? hook->n_ctx : 0, L = L0 + n_ctx;

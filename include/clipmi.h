@@ -76,6 +76,10 @@ const char* clipmi_last_error(void);
  *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
  *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
+ *   vision_pass      (CLIPMI_VISION_PASS)     stream elements (token rows x width) of one pass of clipmi_encode_image, default 50432 * 768
+ *                                             (256 images of ViT-B/16, 128 of ViT-L/14, 64 of ViT-L/14@336): a batch of one and a half
+ *                                             passes or more runs as consecutive passes on the same stream and workspace -- same bits,
+ *                                             +8..10 % images/s at 512-1024 images of ViT-B/16; 0 = never split
  * and the process-wide DEFAULTS of the three per-model settings (clipmi_model_set_option overrides them per handle):
  *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block
  *                    runs out-proj, c_fc, c_proj (and ln_2) on the class rows only -- the rows ln_post reads (clip/model.py:419) -- as
@@ -345,12 +349,15 @@ int clipmi_model_get_option(const clipmi_model* m, const char* name, int* value)
 int clipmi_set_vision_weights(clipmi_model* m, const clipmi_vision_weights* w);
 int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w);
 
-/* Bytes of scratch the caller must pass to the tower calls for `batch` images / `n_prompts` prompts. */
+/* Bytes of scratch the caller must pass to the tower calls for `batch` images / `n_prompts` prompts.  clipmi_encode_image works a large
+ * batch in passes (option vision_pass): the vision figure is that of the largest pass, under the option's value at the time of the call to
+ * clipmi_encode_image -- size the workspace after any clipmi_set_option("vision_pass", ...). */
 size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx);
 size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts);
 
 /* CLIP.encode_image / VisionTransformer.forward (clip/model.py:597-598,394-424; MaPLe :447-478 when hook != NULL):
- * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns). */
+ * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns).  Batches of one and a half passes or more
+ * (option vision_pass) run as consecutive passes on `stream`; an image's features do not depend on its batch (bit for bit). */
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
                         unsigned flags, clipmi_stream_t stream);

@@ -777,6 +777,35 @@ def test_rn50_geometry_vs_oracle():
     _feat_close(got, ref, "RN50 image tower vs oracle")
 
 
+@pytest.mark.parametrize("hooked", [False, True])
+def test_image_tower_passes_same_bits(clipmi_option, hooked):
+    """clipmi_encode_image runs a batch beyond one and a half passes as consecutive passes on the same workspace (option vision_pass:
+    stream elements per pass; throughput per image peaks at 256 images for ViT-B/16 and falls 8-10 % for 512-1024 in one pass).  The
+    features are the same bits as one pass over the whole batch, with MaPLe-style prompt tokens too, for a ragged remainder (11 = 4 + 4 +
+    3) and for one that joins the last pass (9 = 4 + 5); the workspace the library asks for shrinks to the largest pass."""
+    from clip_calibration_amd import _lib
+    sd, model = _build("tiny")
+    g = model.geometry
+    kw = {}
+    if hooked:
+        gen = torch.Generator().manual_seed(3)
+        kw = dict(shared_ctx=(0.1 * torch.randn(2, g.vision_width, generator=gen)).cuda(),
+                  deep_prompts=[(0.1 * torch.randn(2, g.vision_width, generator=gen)).cuda() for _ in range(1)])
+    L = g.vision_tokens + (2 if hooked else 0)
+    for B in (11, 9, 5):
+        images = syn.synthetic_images(B, "tiny", seed=B).cuda()
+        clipmi_option("vision_pass", 0)
+        with torch.no_grad():
+            whole = model.image_features_f32(images, **kw).clone()
+        need_whole = _lib.lib.clipmi_vision_workspace_bytes(model._handle, B, 2 if hooked else 0)
+        clipmi_option("vision_pass", 4 * L * g.vision_width)            # 4 images per pass
+        need = _lib.lib.clipmi_vision_workspace_bytes(model._handle, B, 2 if hooked else 0)
+        with torch.no_grad():
+            parts = model.image_features_f32(images, **kw)
+        assert torch.equal(parts, whole), f"B={B}: passes changed the features"
+        assert need < need_whole if B >= 6 else need == need_whole            # 5 images: less than one and a half passes -> one pass
+
+
 @pytest.mark.parametrize("source", ["pageable", "pinned", "device"])
 def test_device_batches_order_and_values(source):
     """runner.device_batches (the host -> device leg of the test loop, base_learner.py:84-88,175-182): batches arrive in order and
