@@ -519,10 +519,12 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t*
 // that issue LDS-DMA themselves do not work either: hipcc puts an s_waitcnt vmcnt(0) in front of the ds_read_b64_tr_b16
 // of the P.V product -- the builtin carries no address-space-precise memory operand, so it may alias the pending DMA.)
 //
-// LDS (dynamic, zeroed once): 2 buffers x (K | V | Q) x 200 rows x 128 B = 153,600 B + 3 KiB tail pad.  The seventh key /
-// query tile spans rows 192-223; rows 200-223 of an array fall into the NEXT array (always finite data: rows at or beyond
-// L lie outside the DMA descriptor and read as zero, the tail pad is zero): keys >= L are masked in the scores, their
-// P = 0 annihilates whatever V row is read, and queries >= L are never stored.
+// LDS (dynamic; the tail pad zeroed once): 2 buffers x (K | V | Q) x 200 rows x 128 B = 153,600 B + 3 KiB tail pad.  The seventh key /
+// query tile spans rows 192-223; rows 200-223 of an array fall into the NEXT array.  For K and V that is always finite data
+// written by this item's DMA (the V array behind K, the Q array behind V; rows at or beyond L lie outside the DMA descriptor
+// and read as zero): keys >= L are masked in the scores and their P = 0 annihilates whatever V row is read.  Behind the Q
+// array lie the other buffer's K rows (in flight, or untouched during the very first item) or the tail pad: they are read only
+// as QUERY rows >= 200 -- columns of S^T and O^T that no other column depends on and that are never stored.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int VROWS = 200;
 constexpr int VARR = VROWS * 128;            // one operand image
@@ -538,7 +540,7 @@ constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of th
 #endif
 template <bool NT>   // NT: output rows stored non-temporal
 __device__ __forceinline__ void attention_vision_body(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
-  constexpr int NKT = 7, NTHR = 512, GROUP = 4;
+  constexpr int NKT = 7, GROUP = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -546,8 +548,11 @@ __device__ __forceinline__ void attention_vision_body(const half_t* __restrict__
   const int r32 = lane & 31, hh = lane >> 5;
   const int D = H * 64;
   const int64_t ld = 3 * (int64_t)D;
-  for (int i = tid * 16; i < VSMEM; i += NTHR * 16) *reinterpret_cast<f32x4*>(smem + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
+  // Only the tail pad is never written by the DMA (every item rewrites rows 0 .. 199 of its three arrays, zeros beyond L): it is read as the
+  // query rows >= 200 of buffer 1's last tile, whose outputs are never stored -- zeroed all the same, so that no NaN pattern left by an
+  // earlier kernel enters an MFMA.  The first item's barrier orders these stores before any read.  (Until round 3 the whole 157 KB image was
+  // zeroed here, with a workgroup barrier, in front of the first DMA: ~1 us per launch.)
+  if (tid * 16 < VSMEM - 2 * VBUF) *reinterpret_cast<f32x4*>(smem + 2 * VBUF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int item = blockIdx.x;
   if (item >= n_items) return;
