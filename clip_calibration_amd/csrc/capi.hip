@@ -618,8 +618,8 @@ size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx
   if (!m || batch < 0 || n_ctx < 0) return 0;
   const int L = m->tokens0() + n_ctx;
   const int pass = pass_images(batch, L, m->g.vision_width);
-  const int largest = batch <= pass ? batch : pass + pass / 4;   // a remainder below a quarter pass joins the last pass
-  const int b = largest < batch ? largest : batch;
+  const int rem = batch % pass;
+  const int b = batch <= pass ? batch : pass + (rem < pass / 4 ? rem : 0);   // a remainder below a quarter pass joins the last pass
   return carve(nullptr, (int64_t)b * L, m->g.vision_width, b, m->col_bytes(b)).bytes;
 }
 

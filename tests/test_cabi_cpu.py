@@ -68,6 +68,17 @@ def test_argument_validation_needs_no_gpu():
     assert L.clipmi_model_set_option(h, b"residual_f16", -1) == _lib.OK
     assert L.clipmi_model_get_option(h, b"residual_f16", ctypes.byref(v)) == _lib.OK and v.value == 2
     assert L.clipmi_vision_workspace_bytes(h, 256, 0) == pytest.approx((22 * 768 + 64) * 256 * 197, rel=1e-3)   # 22*D B of activations + 64 B of LN-fold partials per token row
+    # a batch of one and a half passes or more is worked in passes (option vision_pass, default 50432 * 768 stream elements = 256 images
+    # here): the workspace is that of the largest pass (a pass plus a remainder of under a quarter pass), not of the whole batch
+    ws = lambda b: L.clipmi_vision_workspace_bytes(h, b, 0)
+    assert ws(320) > ws(256) and ws(383) > ws(320)           # less than one and a half passes: still one pass
+    assert ws(384) == ws(256) and ws(1024) == ws(256)        # 256 + 128, 4 x 256
+    assert ws(2048 + 40) == ws(296)                          # the last pass takes the short remainder: 256 + 40
+    _lib.set_option("vision_pass", 0)
+    try:
+        assert ws(1024) == pytest.approx(4 * ws(256), rel=1e-3)
+    finally:
+        _lib.set_option("vision_pass", 50432 * 768)
     assert L.clipmi_destroy(h) == _lib.OK
 
 
