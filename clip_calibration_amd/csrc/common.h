@@ -58,7 +58,7 @@ struct Options {
                                        // stores; 0 = persistent kernel (all three: same bits)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
   std::atomic<int> vision_pass{50432 * 768};   // CLIPMI_VISION_PASS: stream elements (token rows x width) of one pass of the image tower; larger batches run
-                                               // as consecutive passes (same bits); 0 = never split
+                                               // as consecutive passes (each an ordinary call on its images); 0 = never split
 };
 // cls_only_last_block, ln_fold and residual_f16 are DEFAULTS: a model handle may override them (clipmi_model_set_option) and a
 // tower call may override the stream precision (flags) -- nothing on a launch path writes to this struct.

@@ -78,7 +78,9 @@ const char* clipmi_last_error(void);
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
  *   vision_pass      (CLIPMI_VISION_PASS)     stream elements (token rows x width) of one pass of clipmi_encode_image, default 50432 * 768
  *                                             (256 images of ViT-B/16, 128 of ViT-L/14, 64 of ViT-L/14@336): a batch of one and a half
- *                                             passes or more runs as consecutive passes on the same stream and workspace -- same bits,
+ *                                             passes or more runs as consecutive passes on the same stream and workspace -- each pass is an ordinary
+ *                                             call on its images: features equal to the one-pass result up to the library's usual batch
+ *                                             dependence (tile and kernel choice follow the row count: <= 2e-4 on normalised features),
  *                                             +8..10 % images/s at 512-1024 images of ViT-B/16; 0 = never split
  * and the process-wide DEFAULTS of the three per-model settings (clipmi_model_set_option overrides them per handle):
  *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block
@@ -357,7 +359,8 @@ size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts);
 
 /* CLIP.encode_image / VisionTransformer.forward (clip/model.py:597-598,394-424; MaPLe :447-478 when hook != NULL):
  * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns).  Batches of one and a half passes or more
- * (option vision_pass) run as consecutive passes on `stream`; an image's features do not depend on its batch (bit for bit). */
+ * (option vision_pass) run as consecutive passes on `stream`, each an ordinary call on its images (an image's features depend on its batch only through the
+ * tile and kernel choice, which follows the row count: <= 2e-4 on normalised features, as between any two batch sizes). */
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
                         unsigned flags, clipmi_stream_t stream);

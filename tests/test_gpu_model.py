@@ -781,8 +781,10 @@ def test_rn50_geometry_vs_oracle():
 def test_image_tower_passes_same_bits(clipmi_option, hooked):
     """clipmi_encode_image runs a batch beyond one and a half passes as consecutive passes on the same workspace (option vision_pass:
     stream elements per pass; throughput per image peaks at 256 images for ViT-B/16 and falls 8-10 % for 512-1024 in one pass).  The
-    features are the same bits as one pass over the whole batch, with MaPLe-style prompt tokens too, for a ragged remainder (11 = 4 + 4 +
-    3) and for one that joins the last pass (9 = 4 + 5); the workspace the library asks for shrinks to the largest pass."""
+    passes are ordinary calls on their images: on this small geometry every pass selects the same kernels as the whole batch, so the
+    features must be the same bits (at full size tile and kernel choice follow the row count, and passes differ from one pass as any two
+    batch sizes do: test_gpu_fullsize) -- with MaPLe-style prompt tokens too, for a ragged remainder (11 = 4 + 4 + 3) and for one that
+    joins the last pass (9 = 4 + 5); the workspace the library asks for shrinks to the largest pass."""
     from clip_calibration_amd import _lib
     sd, model = _build("tiny")
     g = model.geometry
