@@ -386,6 +386,20 @@ def main():
         # touched if the library's own RCCL communicator cannot be built and the exchange falls back to torch.distributed
         dist.init_process_group("gloo" if same_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
+    def in_turn(fn):
+        """BENCH_SAME_GPU self-test only: the ranks share ONE device, so they take turns on it -- kernels of two processes resident on the
+        same SIMDs is not the configuration under test (one process per GPU is), and on this platform it is not bit-safe
+        (profiles/r03_gpu_sharing.txt).  Everywhere else: just the call."""
+        if not (same_gpu and world > 1):
+            return fn()
+        out = None
+        for r in range(world):
+            if r == rank:
+                out = fn()
+                torch.cuda.synchronize()
+            dist.barrier()
+        return out
+
     from clip_calibration_amd import ops, synthetic as syn
     from clip_calibration_amd.evaluator import DeviceCalibrationEvaluator
     from clip_calibration_amd.model import build_model
@@ -452,11 +466,11 @@ def main():
         ids = syn.synthetic_token_ids(Cn, args.model, seed=0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        zs = ZeroshotCLIP(model, ids)
+        zs = in_turn(lambda: ZeroshotCLIP(model, ids))
         torch.cuda.synchronize()
         text_s_cold = time.perf_counter() - t0
         t0 = time.perf_counter()
-        zs.build_model(ids)
+        in_turn(lambda: zs.build_model(ids))
         torch.cuda.synchronize()
         text_s = time.perf_counter() - t0
         text_features, scale = zs.text_features, zs.scale
@@ -477,10 +491,10 @@ def main():
     def tail(feats, labels, txt):
         bins = evaluator.bins if labels is not None else None
         if f16_exchange:
-            emb = ops.l2_normalize(feats, torch.float16)                               # [B, E] fp16: 2*B*E bytes per rank on the wire
+            emb = in_turn(lambda: ops.l2_normalize(feats, torch.float16))              # [B, E] fp16: 2*B*E bytes per rank on the wire
             if exchange is not None:
                 emb = exchange.all_gather(emb)                                         # [world*B, E], rank-major
-            return ops.fused_tail(emb, txt, scale, dac_conf, True, False, labels, bins, n_bins)
+            return in_turn(lambda: ops.fused_tail(emb, txt, scale, dac_conf, True, False, labels, bins, n_bins))
         return ops.fused_tail(feats, txt, scale, dac_conf, True, True, labels, bins, n_bins)
 
     def step(labels, recompute_text=False):
@@ -489,7 +503,7 @@ def main():
             emb = torch.cat([ops.l2_normalize(model.image_features_f32(x), torch.float16) for x in shards])
             bins = evaluator.bins if labels is not None else None
             return ops.fused_tail(emb, txt, scale, dac_conf, True, False, labels, bins, n_bins)
-        return tail(model.image_features_f32(images), labels, txt)
+        return tail(in_turn(lambda: model.image_features_f32(images)), labels, txt)
 
     def run(labels, n_steps, recompute_text=False):
         evaluator.reset()

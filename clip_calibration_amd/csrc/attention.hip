@@ -411,6 +411,7 @@ __device__ __forceinline__ void store_out_lines(half_t* tile_row0, int64_t row_s
 template <int NKT, int GROUP, int DENSE>
 __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                    int L, int H, int causal, int n_items) {
+  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V
@@ -540,6 +541,7 @@ constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of th
 #endif
 template <bool NT>   // NT: output rows stored non-temporal
 __device__ __forceinline__ void attention_vision_body(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
+  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int NKT = 7, GROUP = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -710,6 +712,7 @@ int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream
 template <int NKT>
 __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                   int L, int H, int causal, int nkb) {
+  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V

@@ -34,6 +34,72 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, CLIPMI_LDS_PTR(lds), 16, voff, soff, 0, 0);
 }
 #define CLIPMI_BUFFER_LOAD_LDS16(rsrc, lds, voff, soff) ::clipmi::buffer_load_lds16((rsrc), (lds), (voff), (soff))
+
+// Every kernel that mixes MFMAs with LDS traffic takes its SIMDs' whole register file (an empty asm that names the last register of
+// the kernel's share: 256 per wave at two waves per SIMD, 128 at four), so that no wave of ANOTHER kernel can be resident beside its
+// waves.  Why: with a second process on the GPU, waves of small kernels (LayerNorm: 56 registers) that shared a SIMD with waves of the
+// vision attention kernel or of the fused tail came back with ONE 16-lane quarter of one register overwritten -- a few launches in a
+// hundred, whole rows of the LayerNorm wrong -- while kernels that fill the register file anyway (the GEMMs) never had such neighbours
+// and never showed it; padded to 256 registers the attention kernel stopped doing it (profiles/r03_gpu_sharing.txt).  No cost: these
+// kernels run two (four) waves per SIMD by design.
+#define CLIPMI_OWN_REGISTERS_2_PER_SIMD() asm volatile("; whole register share of a wave at two waves per SIMD" ::: "v255")
+#define CLIPMI_OWN_REGISTERS_4_PER_SIMD() asm volatile("; whole register share of a wave at four waves per SIMD" ::: "v127")
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
+// result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.
+// Every kernel of the library reduces with these: __shfl_xor (ds_bpermute_b32) gave WRONG row sums in the LayerNorm kernel, a few
+// launches in a hundred, whenever a second process shared the GPU (profiles/r03_gpu_sharing.txt) -- never when the process ran alone.
+//   step 1, 2: quad_perm (xor 1, xor 2)   3: row_half_mirror   4: row_mirror   5: rows (0,1) (2,3)   6: halves
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ float swap16_f(float v) {   // the value of the lane 16 further / back (rows 0 <-> 1, 2 <-> 3)
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // [0]: rows (0, 0, 2, 2), [1]: rows (1, 1, 3, 3)
+  const bool odd = (threadIdx.x >> 4) & 1;
+  return __builtin_bit_cast(float, (unsigned int)(odd ? a[0] : a[1]));
+}
+__device__ __forceinline__ float swap32_f(float v) {   // the value of the lane 32 further / back
+  const unsigned int u = __builtin_bit_cast(unsigned int, v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // [0]: lower half twice, [1]: upper half twice
+  const bool up = (threadIdx.x >> 5) & 1;
+  return __builtin_bit_cast(float, (unsigned int)(up ? a[0] : a[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  v += swap16_f(v);
+  v += swap32_f(v);
+  return v;
+}
+// (value, index) -> the largest value and the LOWEST index that holds it, in every lane
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+  auto take = [&](float ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  };
+  take(dpp_f<0xB1>(v), dpp_i<0xB1>(idx));
+  take(dpp_f<0x4E>(v), dpp_i<0x4E>(idx));
+  take(dpp_f<0x141>(v), dpp_i<0x141>(idx));
+  take(dpp_f<0x140>(v), dpp_i<0x140>(idx));
+  take(swap16_f(v), __builtin_bit_cast(int, swap16_f(__builtin_bit_cast(float, idx))));
+  take(swap32_f(v), __builtin_bit_cast(int, swap32_f(__builtin_bit_cast(float, idx))));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  v = fmaxf(v, swap16_f(v));
+  return fmaxf(v, swap32_f(v));
+}
 #endif
 
 void set_error(const char* fmt, ...);

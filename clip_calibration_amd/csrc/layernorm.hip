@@ -21,7 +21,8 @@ template <> struct Vec4<half_t> {
   }
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
+// (the xor butterfly the kernel has summed with since round 1: the row statistics keep their bits; common.h's DPP tree adds in another order)
+__device__ __forceinline__ float ln_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = ln_wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = rsqrtf(ln_wave_sum(q) / (float)D + eps);
   TO* yr = y + (int64_t)row * out_stride;
   float os = 0.f, oq = 0.f;
 #pragma unroll
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     }
   }
   if (stats_out) {
-    os = wave_sum(os);
-    oq = wave_sum(oq);
+    os = ln_wave_sum(os);
+    oq = ln_wave_sum(oq);
     if (lane == 0) {
       *reinterpret_cast<float2*>(stats_out + 2 * (int64_t)row) = make_float2(os, oq);   // partial 0 (the only one)
     }

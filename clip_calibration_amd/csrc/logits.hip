@@ -85,51 +85,6 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
-// result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.
-//   step 1, 2: quad_perm (xor 1, xor 2)   3: row_half_mirror   4: row_mirror   5: rows (0,1) (2,3)   6: halves
-// ---------------------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
-__device__ __forceinline__ float swap16_f(float v) {   // the value of the lane 16 further / back (rows 0 <-> 1, 2 <-> 3)
-  const unsigned int u = __builtin_bit_cast(unsigned int, v);
-  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // [0]: rows (0, 0, 2, 2), [1]: rows (1, 1, 3, 3)
-  const bool odd = (threadIdx.x >> 4) & 1;
-  return __builtin_bit_cast(float, (unsigned int)(odd ? a[0] : a[1]));
-}
-__device__ __forceinline__ float swap32_f(float v) {   // the value of the lane 32 further / back
-  const unsigned int u = __builtin_bit_cast(unsigned int, v);
-  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // [0]: lower half twice, [1]: upper half twice
-  const bool up = (threadIdx.x >> 5) & 1;
-  return __builtin_bit_cast(float, (unsigned int)(up ? a[0] : a[1]));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_f<0x141>(v);   // row_half_mirror
-  v += dpp_f<0x140>(v);   // row_mirror
-  v += swap16_f(v);
-  v += swap32_f(v);
-  return v;
-}
-// (value, index) -> the largest value and the LOWEST index that holds it, in every lane
-__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
-  auto take = [&](float ov, int oi) {
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  };
-  take(dpp_f<0xB1>(v), dpp_i<0xB1>(idx));
-  take(dpp_f<0x4E>(v), dpp_i<0x4E>(idx));
-  take(dpp_f<0x141>(v), dpp_i<0x141>(idx));
-  take(dpp_f<0x140>(v), dpp_i<0x140>(idx));
-  take(swap16_f(v), __builtin_bit_cast(int, swap16_f(__builtin_bit_cast(float, idx))));
-  take(swap32_f(v), __builtin_bit_cast(int, swap32_f(__builtin_bit_cast(float, idx))));
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // The row pass: argmax, DAC factor, softmax top-1.
 //
 // Without DAC the softmax denominator is defined BLOCKWISE, so that the fused kernel can form it from what each of its
@@ -293,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict
                                                             float* __restrict__ conf, int32_t* __restrict__ pred,
                                                             const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
                                                             int* counters, TailPartial* partials, int B, int C, int E, int lds_bytes) {
+  CLIPMI_OWN_REGISTERS_2_PER_SIMD();   // two workgroups of four waves per CU (LDS-limited): two waves per SIMD
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rsb = E * 2 + 16;                         // bytes per fp16 row of an LDS operand image (16-byte pad)
   char* hi_s = smem;

@@ -17,10 +17,12 @@ def pytest_configure(config):
 
 
 # ---- the N > 1 path on the hardware there is (tests/test_gpu_multirank.py) -------------------------------------------
-# Two fresh rank processes (torch.distributed.run) and one single-process reference run of bench.py are started HERE, at
+# Two fresh rank processes (torch.distributed.run) and one single-process reference run of bench.py are run HERE, at
 # session start, before this process has touched the GPU (torch.cuda.device_count() does not initialise it): a process
-# that has initialised the GPU must not be the one that execs other programs on these boxes.  The test only waits for
-# the children and compares their dumps.
+# that has initialised the GPU must not be the one that execs other programs on these boxes.  They run one after the other
+# and TO COMPLETION before the first test starts: kernels of two processes resident on the same SIMDs are not bit-safe on
+# this platform (profiles/r03_gpu_sharing.txt: a LayerNorm wave beside another process's attention waves came back with a
+# quarter of one register overwritten), and a parity suite must not share its GPU.  The test only compares the dumps.
 MULTIRANK = {}
 
 
@@ -47,8 +49,16 @@ def pytest_sessionstart(session):
     two = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", str(_free_port()), bench, "--gpus", "2", "--dump", os.path.join(tmp, "two.npz")] + common,
                            env=env, stdout=open(os.path.join(tmp, "two.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
+    try:
+        two.wait(timeout=600)
+    except subprocess.TimeoutExpired:
+        two.kill()
     one = subprocess.Popen([sys.executable, bench, "--gpus", "1", "--virtual-ranks", "2", "--exchange-f16", "--dump", os.path.join(tmp, "one.npz")] + common,
                            env=dict(os.environ, OMP_NUM_THREADS="8"), stdout=open(os.path.join(tmp, "one.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
+    try:
+        one.wait(timeout=600)
+    except subprocess.TimeoutExpired:
+        one.kill()
     MULTIRANK.update(tmp=tmp, two=two, one=one)
 
 
