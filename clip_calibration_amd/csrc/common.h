@@ -42,8 +42,13 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 // hundred, whole rows of the LayerNorm wrong -- while kernels that fill the register file anyway (the GEMMs) never had such neighbours
 // and never showed it; padded to 256 registers the attention kernel stopped doing it (profiles/r03_gpu_sharing.txt).  No cost: these
 // kernels run two (four) waves per SIMD by design.
+#ifdef CLIPMI_NO_OWN_REGISTERS   // (A/B builds only: make noown)
+#define CLIPMI_OWN_REGISTERS_2_PER_SIMD() do { } while (0)
+#define CLIPMI_OWN_REGISTERS_4_PER_SIMD() do { } while (0)
+#else
 #define CLIPMI_OWN_REGISTERS_2_PER_SIMD() asm volatile("; whole register share of a wave at two waves per SIMD" ::: "v255")
 #define CLIPMI_OWN_REGISTERS_4_PER_SIMD() asm volatile("; whole register share of a wave at four waves per SIMD" ::: "v127")
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
