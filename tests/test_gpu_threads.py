@@ -75,3 +75,50 @@ def test_call_flag_f16_needs_the_fold():
     m.set_option("ln_fold", -1)
     with torch.no_grad():
         assert torch.isfinite(m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16)).all()
+
+
+def test_small_kernel_beside_mfma_kernels_on_a_second_stream():
+    """Regression guard for the register-share padding of the MFMA + LDS kernels (common.h, CLIPMI_OWN_REGISTERS_*;
+    profiles/r03_gpu_sharing.txt): while the vision attention kernel and the fused tail loop on a second stream, the LayerNorm kernel
+    (one wave per row, 56 registers: it fits on a SIMD beside anything that leaves room) must keep returning the right rows.  Without
+    the padding 5-15 % of these launches came back with a row whose statistics had absorbed a clobbered register quarter."""
+    from clip_calibration_amd import ops
+    g = torch.Generator().manual_seed(0)
+    M, K = 197 * 256, 768
+    x = torch.randn(M, K, generator=g).cuda()
+    gam, bet = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    truth = torch.nn.functional.layer_norm(x.double(), (K,)).float()
+    qkv = torch.randn(24 * 197, 2304, generator=g).half().cuda()
+    feat = torch.randn(256, 512, generator=g).cuda()
+    txt = ops.l2_normalize(torch.randn(1000, 512, generator=g).cuda())
+    stop = threading.Event()
+    errors = []
+
+    def hammer():
+        try:
+            s = torch.cuda.Stream()
+            n = 0
+            with torch.cuda.stream(s):
+                while not stop.is_set():
+                    ops.attention(qkv, 24, 197, 12, False)
+                    if n % 8 == 0:
+                        ops.fused_tail(feat, txt, 100.0, None, True, True)
+                    n += 1
+                    if n % 100 == 0:
+                        s.synchronize()
+                s.synchronize()
+        except Exception as e:      # surface it in the main thread
+            errors.append(e)
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        bad = 0
+        for _ in range(300):
+            out = ops.layernorm(x, gam, bet)
+            bad += int(bool(((out - truth).abs().amax(dim=1) > 1e-3).any()))
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    assert bad == 0, f"{bad} of 300 LayerNorm launches returned a wrong row beside the MFMA kernels of the second stream"
