@@ -49,6 +49,12 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 #define CLIPMI_OWN_REGISTERS_2_PER_SIMD() asm volatile("; whole register share of a wave at two waves per SIMD" ::: "v255")
 #define CLIPMI_OWN_REGISTERS_4_PER_SIMD() asm volatile("; whole register share of a wave at four waves per SIMD" ::: "v127")
 #endif
+// one wave per SIMD (workgroups of four waves that may sit alone on a CU): the wave's share is the whole unified file, 256 + 256
+#ifdef CLIPMI_NO_OWN_REGISTERS
+#define CLIPMI_OWN_REGISTERS_1_PER_SIMD() do { } while (0)
+#else
+#define CLIPMI_OWN_REGISTERS_1_PER_SIMD() asm volatile("; the whole register file of a SIMD" ::: "v255", "a255")
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
