@@ -387,8 +387,8 @@ def main():
         dist.init_process_group("gloo" if same_gpu else "cpu:gloo,cuda:nccl", rank=rank, world_size=world)
 
     def in_turn(fn):
-        """BENCH_SAME_GPU self-test only: the ranks share ONE device, so they take turns on it -- kernels of two processes resident on the
-        same SIMDs is not the configuration under test (one process per GPU is), and on this platform it is not bit-safe
+        """BENCH_SAME_GPU self-test only: the ranks share ONE device, so they take turns on it -- two processes interleaved on one GPU is not
+        the configuration under test (one process per GPU is), and a bitwise comparison should not depend on it
         (profiles/r03_gpu_sharing.txt).  Everywhere else: just the call."""
         if not (same_gpu and world > 1):
             return fn()

@@ -112,6 +112,7 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
           f16x8 pf;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[t][8 * ss + j], C, -mc));
+          CLIPMI_VALU_TO_MFMA_FENCE(pf);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
             const f16x4 lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
@@ -288,6 +289,7 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
                                            : (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
       if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
       else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+      CLIPMI_VALU_TO_MFMA_FENCE(pf);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
@@ -411,7 +413,6 @@ __device__ __forceinline__ void store_out_lines(half_t* tile_row0, int64_t row_s
 template <int NKT, int GROUP, int DENSE>
 __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                    int L, int H, int causal, int n_items) {
-  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V
@@ -541,7 +542,6 @@ constexpr int VSMEM = 2 * VBUF + 24 * 128;   // + tail pad for the overrun of th
 #endif
 template <bool NT>   // NT: output rows stored non-temporal
 __device__ __forceinline__ void attention_vision_body(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items CLIPMI_VISION_STAMPS_PARAM) {
-  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int NKT = 7, GROUP = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -712,7 +712,6 @@ int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream
 template <int NKT>
 __global__ __launch_bounds__(512, 2) void attention_stream_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out,
                                                                   int L, int H, int causal, int nkb) {
-  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int KEYS = NKT * 32;
   constexpr int OPB = KEYS * 128;      // one operand image
   constexpr int BUF = 2 * OPB;         // K + V

@@ -35,26 +35,13 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 }
 #define CLIPMI_BUFFER_LOAD_LDS16(rsrc, lds, voff, soff) ::clipmi::buffer_load_lds16((rsrc), (lds), (voff), (soff))
 
-// Every kernel that mixes MFMAs with LDS traffic takes its SIMDs' whole register file (an empty asm that names the last register of
-// the kernel's share: 256 per wave at two waves per SIMD, 128 at four), so that no wave of ANOTHER kernel can be resident beside its
-// waves.  Why: with a second process on the GPU, waves of small kernels (LayerNorm: 56 registers) that shared a SIMD with waves of the
-// vision attention kernel or of the fused tail came back with ONE 16-lane quarter of one register overwritten -- a few launches in a
-// hundred, whole rows of the LayerNorm wrong -- while kernels that fill the register file anyway (the GEMMs) never had such neighbours
-// and never showed it; padded to 256 registers the attention kernel stopped doing it (profiles/r03_gpu_sharing.txt).  No cost: these
-// kernels run two (four) waves per SIMD by design.
-#ifdef CLIPMI_NO_OWN_REGISTERS   // (A/B builds only: make noown)
-#define CLIPMI_OWN_REGISTERS_2_PER_SIMD() do { } while (0)
-#define CLIPMI_OWN_REGISTERS_4_PER_SIMD() do { } while (0)
-#else
-#define CLIPMI_OWN_REGISTERS_2_PER_SIMD() asm volatile("; whole register share of a wave at two waves per SIMD" ::: "v255")
-#define CLIPMI_OWN_REGISTERS_4_PER_SIMD() asm volatile("; whole register share of a wave at four waves per SIMD" ::: "v127")
-#endif
-// one wave per SIMD (workgroups of four waves that may sit alone on a CU): the wave's share is the whole unified file, 256 + 256
-#ifdef CLIPMI_NO_OWN_REGISTERS
-#define CLIPMI_OWN_REGISTERS_1_PER_SIMD() do { } while (0)
-#else
-#define CLIPMI_OWN_REGISTERS_1_PER_SIMD() asm volatile("; the whole register file of a SIMD" ::: "v255", "a255")
-#endif
+// A register that VALU instructions have just written (conversions, transcendentals: the softmax's P, the tail's hi / lo split) and that
+// an MFMA reads as a SOURCE operand right behind them needs wait states that hipcc does not insert on gfx950 for these sequences.  The
+// wave's own result is right either way -- every parity test passed without them -- but a wave of ANOTHER kernel resident on the same
+// SIMD came back with a 16-lane quarter of one register overwritten (profiles/r03_gpu_sharing.txt: 24-45 of 400 LayerNorm launches beside
+// the attention kernel, 0 of 400 with `s_nop 1` here).  The operand is named "+v" so that every instruction that writes it stays above.
+#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("s_nop 1" : "+v"(x))
+#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("s_nop 1" : "+v"(x), "+v"(y))
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the

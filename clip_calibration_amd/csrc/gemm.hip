@@ -485,7 +485,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
 
 template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_f16_kernel(const KArgs a) {
-  if constexpr (T::OCC >= 4) CLIPMI_OWN_REGISTERS_4_PER_SIMD(); else CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -726,7 +725,6 @@ inline bool stream_raw_ok(const KArgs& k) { return k.ln_parts <= STREAM_RAW_PART
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
-  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   using T = TStream;
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;   // TM = 8, TN = 4
   // LDS behind the stages: 2 x (row parameters of a tile) | 2 x ([BN] bias | [BN] g).  Row parameters are either the finalised
@@ -1216,7 +1214,6 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int EPI, bool OUT_F32>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
-  if constexpr (T::OCC >= 4) CLIPMI_OWN_REGISTERS_4_PER_SIMD(); else CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
   static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
   constexpr int NP = T::XI + T::WI;                       // LDS-DMA pieces per wave and stage
@@ -1462,7 +1459,6 @@ struct ConvArgs {
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_conv3x3_kernel(const KArgs a, const ConvArgs cv) {
-  if constexpr (T::OCC >= 4) CLIPMI_OWN_REGISTERS_4_PER_SIMD(); else CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;

@@ -51,7 +51,6 @@ struct RStream {
 };
 
 __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, const int groups, const int pairs) {
-  CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   using R = RStream;
   constexpr int TM = R::TM, H = R::H, TN = R::TN;
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

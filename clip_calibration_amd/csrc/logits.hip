@@ -39,7 +39,8 @@ __device__ __forceinline__ SplitFrag split8(const f32x4& p, const f32x4& q) {
   }
   return s;
 }
-__device__ __forceinline__ f32x4 split_mfma(const f16x8& a_hi, const f16x8& a_lo, const SplitFrag& b, f32x4 acc) {
+__device__ __forceinline__ f32x4 split_mfma(const f16x8& a_hi, const f16x8& a_lo, SplitFrag b, f32x4 acc) {
+  CLIPMI_VALU_TO_MFMA_FENCE2(b.hi, b.lo);   // split8's conversions wrote them a moment ago
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.hi, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b.lo, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b.hi, acc, 0, 0, 0);
@@ -64,8 +65,9 @@ __global__ __launch_bounds__(256) void cosine_logits_kernel(const float* __restr
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
   int k0 = 0;
   for (; k0 + 32 <= E; k0 += 32) {
-    const SplitFrag a = split8(*reinterpret_cast<const f32x4*>(ap + k0), *reinterpret_cast<const f32x4*>(ap + k0 + 4));
+    SplitFrag a = split8(*reinterpret_cast<const f32x4*>(ap + k0), *reinterpret_cast<const f32x4*>(ap + k0 + 4));
     const SplitFrag b = split8(*reinterpret_cast<const f32x4*>(bp + k0), *reinterpret_cast<const f32x4*>(bp + k0 + 4));
+    CLIPMI_VALU_TO_MFMA_FENCE2(a.hi, a.lo);
     acc = split_mfma(a.hi, a.lo, b, acc);
   }
   if (k0 < E) {   // E % 32 == 16: one exact-f32 step (lane: k = k0 + 4 (l >> 4) .. + 3)
@@ -243,15 +245,11 @@ constexpr int tail_sbins_off(int rb) { return rb * TAIL_TILE_LD * 4 + 16; }
 // RB = image rows per workgroup: 32 for large batches (half the text re-reads from L2), 16 for small ones (twice the
 // workgroups, and a row pass of 4 instead of 8 rows per wave on the critical path of a launch that is all latency)
 template <bool NORMALIZE, typename TI, int RB>
-__global__ __launch_bounds__(256, (RB == 16 ? 1 : 2)) void fused_tail_kernel(const TI* __restrict__ img, const float* __restrict__ txt, float scale,
+__global__ __launch_bounds__(256, 2) void fused_tail_kernel(const TI* __restrict__ img, const float* __restrict__ txt, float scale,
                                                             const float* __restrict__ dac, float* logits, float* __restrict__ img_n_out,
                                                             float* __restrict__ conf, int32_t* __restrict__ pred,
                                                             const int64_t* __restrict__ labels, double* __restrict__ bins, int n_bins,
                                                             int* counters, TailPartial* partials, int B, int C, int E, int lds_bytes) {
-  // Four waves per workgroup.  Small batches (RB = 16: at most 512 rows, grids around the CU count): a workgroup often sits alone on its CU,
-  // so each of its waves takes its SIMD's whole register file.  Large batches (RB = 32: >= 2 workgroups per CU, paired by the LDS size):
-  // the two-waves-per-SIMD share, which keeps both workgroups of a CU resident (41 us instead of 63 us at 2048 rows).
-  if constexpr (RB == 16) CLIPMI_OWN_REGISTERS_1_PER_SIMD(); else CLIPMI_OWN_REGISTERS_2_PER_SIMD();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rsb = E * 2 + 16;                         // bytes per fp16 row of an LDS operand image (16-byte pad)
   char* hi_s = smem;

@@ -20,9 +20,9 @@ def pytest_configure(config):
 # Two fresh rank processes (torch.distributed.run) and one single-process reference run of bench.py are run HERE, at
 # session start, before this process has touched the GPU (torch.cuda.device_count() does not initialise it): a process
 # that has initialised the GPU must not be the one that execs other programs on these boxes.  They run one after the other
-# and TO COMPLETION before the first test starts: kernels of two processes resident on the same SIMDs are not bit-safe on
-# this platform (profiles/r03_gpu_sharing.txt: a LayerNorm wave beside another process's attention waves came back with a
-# quarter of one register overwritten), and a parity suite must not share its GPU.  The test only compares the dumps.
+# and TO COMPLETION before the first test starts: a parity suite keeps its GPU to itself (profiles/r03_gpu_sharing.txt is
+# the story of the one flake that sharing it produced, and of the missing wait state behind it).  The test only compares
+# the dumps.
 MULTIRANK = {}
 
 
