@@ -45,6 +45,7 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
                                              int kb0, int L, int causal, int q0, int q, int hh, float& m_run,
                                              f32x16 (&oacc)[2], f32x16& lacc) {
   constexpr float C = 0.125f * LOG2E;  // softmax(s/8) = 2^(C s - C max)
+  const f32x16 zero16 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const f16x8 ones = f16x8{(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
 #pragma unroll
   for (int g0 = 0; g0 < NKT; g0 += GROUP) {
@@ -63,12 +64,13 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
         // straight-line code.
         live[t] = DENSE ? true : ((k_lo < L) && !(causal && k_lo > q0 + 31));
         if (live[t]) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+          // the first MFMA of the chain takes a constant zero as its accumulator input: no VALU-written register is an MFMA source here
+          // (CLIPMI_VALU_TO_MFMA_FENCE, common.h)
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             const f16x8 kf = *reinterpret_cast<const f16x8*>(kread[ks] + kt * 4096);
-            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
+            if (ks == 0) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], zero16, 0, 0, 0);
+            else s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
           }
           // DENSE == 3: a key block that lies entirely inside the sequence (multi-block sequences): nothing to mask
           const bool partial = DENSE == 3 ? false : DENSE == 1 ? (kt == NKT - 1) : (DENSE == 2 ? true : ((k_lo + 32 > L) || (causal && k_lo + 31 > q0)));   // wave-uniform
@@ -102,6 +104,7 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
     lacc[0] *= alpha;   // every row of the ones-tile holds the same sum; only register 0 is read
+    asm volatile("s_nop 1" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(lacc));   // VALU-written accumulators are MFMA sources (SrcC) below
     // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
 #pragma unroll
     for (int t = 0; t < GROUP; ++t) {
@@ -117,10 +120,13 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
           for (int dt = 0; dt < 2; ++dt) {
             const f16x4 lo = tr_read(vread[dt] + kt * 4096 + ss * 2048);
             const f16x4 hi = tr_read(vread[dt] + kt * 4096 + ss * 2048 + 1024);
-            const f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            f16x8 vf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            CLIPMI_VALU_TO_MFMA_FENCE(vf);   // the two halves may have been moved together by VALU copies
             oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
           }
-          lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+          f16x8 one_rows = ones;
+          CLIPMI_VALU_TO_MFMA_FENCE(one_rows);   // the constant may be re-materialised by a v_mov right in front of its use
+          lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(one_rows, pf, lacc, 0, 0, 0);
         }
       }
     }
@@ -269,6 +275,7 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
       lacc[0] *= alpha;
+      asm volatile("s_nop 1" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(lacc));   // VALU-written accumulators are MFMA sources (SrcC) below
     }
     const float mc = m_new * C;
     m_run = m_new;
@@ -293,7 +300,8 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
-        const f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        f16x8 v8 = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        CLIPMI_VALU_TO_MFMA_FENCE(v8);   // the two halves may have been moved together by VALU copies
         if constexpr (CLIPMI_ATTN_ABLATE & 2) {
           asm volatile("" :: "v"(v8), "v"(pf));
           if (G0 == 0 && STEP == 0) { oacc[dt] = zero16; asm volatile("" : "+v"(oacc[dt])); }
@@ -303,8 +311,12 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
       if constexpr (CLIPMI_ATTN_ABLATE & (2 | 16)) {
         asm volatile("" :: "v"(pf));
         if (G0 == 0 && STEP == 0) { lacc = zero16; lacc[0] = 1.f; asm volatile("" : "+v"(lacc)); }
-      } else if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, zero16, 0, 0, 0);
-      else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+      } else {
+        f16x8 one_rows = ones;
+        CLIPMI_VALU_TO_MFMA_FENCE(one_rows);   // the constant may be re-materialised by a v_mov right in front of its use
+        if (G0 == 0 && STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(one_rows, pf, zero16, 0, 0, 0);
+        else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(one_rows, pf, lacc, 0, 0, 0);
+      }
     };
     auto pv_tile = [&](auto t_tag) {
       pv_step(t_tag, std::integral_constant<int, 0>{});

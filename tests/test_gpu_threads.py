@@ -77,35 +77,39 @@ def test_call_flag_f16_needs_the_fold():
         assert torch.isfinite(m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16)).all()
 
 
-def test_small_kernel_beside_mfma_kernels_on_a_second_stream():
+@pytest.mark.parametrize("hammer_kernel", ["vision attention (197 tokens) + tail", "text attention (77 tokens, causal)", "ViT-L/14 attention (257 tokens)"])
+def test_small_kernel_beside_mfma_kernels_on_a_second_stream(hammer_kernel):
     """Regression guard for CLIPMI_VALU_TO_MFMA_FENCE (common.h; profiles/r03_gpu_sharing.txt): an MFMA that reads a source operand VALU
-    instructions have just written (the softmax's P, the tail's hi / lo split) needs wait states hipcc does not insert on gfx950 -- its own
-    result is right, but a wave of another kernel resident on the same SIMD loses a register quarter.  While the vision attention kernel
-    and the fused tail loop on a second stream, the LayerNorm kernel (one wave per row, 56 registers: it fits beside them) must keep
-    returning the right rows.  Without the fence 28-32 of these 300 launches came back with a wrong row."""
+    instructions have just written (the softmax's P, a re-materialised constant, rescaled accumulators, the tail's hi / lo split) needs wait
+    states hipcc does not insert on gfx950 -- its own result is right, but a wave of another kernel resident on the same SIMD loses a
+    register quarter.  While an attention kernel (and the fused tail) loops on a second stream, the LayerNorm kernel (one wave per row, 56
+    registers: it fits beside them) must keep returning the right rows.  Without the fences: 28-32 of 300 launches wrong beside the vision
+    kernel, 276 of 300 beside the text tower's, 24-26 of 300 beside the 257-token kernel."""
     from clip_calibration_amd import ops
     g = torch.Generator().manual_seed(0)
     M, K = 197 * 256, 768
     x = torch.randn(M, K, generator=g).cuda()
     gam, bet = torch.ones(K).cuda(), torch.zeros(K).cuda()
     truth = torch.nn.functional.layer_norm(x.double(), (K,)).float()
-    qkv = torch.randn(24 * 197, 2304, generator=g).half().cuda()
+    n, l, h, causal = {"vision": (24, 197, 12, False), "text a": (500, 77, 8, True), "ViT-L/": (16, 257, 16, False)}[hammer_kernel[:6]]
+    qkv = torch.randn(n * l, 3 * 64 * h, generator=g).half().cuda()
     feat = torch.randn(256, 512, generator=g).cuda()
     txt = ops.l2_normalize(torch.randn(1000, 512, generator=g).cuda())
+    with_tail = hammer_kernel.endswith("tail")
     stop = threading.Event()
     errors = []
 
     def hammer():
         try:
             s = torch.cuda.Stream()
-            n = 0
+            k = 0
             with torch.cuda.stream(s):
                 while not stop.is_set():
-                    ops.attention(qkv, 24, 197, 12, False)
-                    if n % 8 == 0:
+                    ops.attention(qkv, n, l, h, causal)
+                    if with_tail and k % 8 == 0:
                         ops.fused_tail(feat, txt, 100.0, None, True, True)
-                    n += 1
-                    if n % 100 == 0:
+                    k += 1
+                    if k % 100 == 0:
                         s.synchronize()
                 s.synchronize()
         except Exception as e:      # surface it in the main thread
