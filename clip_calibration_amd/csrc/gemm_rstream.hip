@@ -165,6 +165,15 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     for (int b = 0; b < TM; ++b)
 #pragma unroll
       for (int i = 0; i < TN; ++i) acc[i][b] = bb[i];
+    // the accumulators are MFMA sources (SrcC) of the K-step that follows, and these are VALU copies: have every copy made HERE (the
+    // empty statements name the registers), then the wait states of CLIPMI_VALU_TO_MFMA_FENCE (common.h) -- hipcc sank some of the
+    // copies to three instructions in front of the first MFMA that reads them (tools/mfma_hazard_scan.py)
+    static_assert(TM == 10, "the statements below name TM accumulators each");
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]), "+v"(acc[i][4]), "+v"(acc[i][5]), "+v"(acc[i][6]),
+                   "+v"(acc[i][7]), "+v"(acc[i][8]), "+v"(acc[i][9]));
+    asm volatile("s_nop 3");
   };
 
   // ---- first tile: bias of this unit's 256 columns (once), stage 0
