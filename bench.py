@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec, ViT-B/16 224px zero-shot + ECE on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N rank processes itself, as children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               (the same ranks under an external launcher)
 
 One step = one pass of the hot path over one synthetic batch that is already resident in HBM:
   N = 1:  image tower (HIP)  ->  ONE fused tail launch: L2 normalise, scale * img @ txt^T, softmax top-1 (conf, pred),
@@ -361,6 +361,48 @@ def stream_workload(args, dev, syn, model):
                        "bytes_per_image": bytes_per_batch // B, "pcie_gen5_x16_spec_gbytes_per_s": 63.0}}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes OURSELVES, as children of this process, through
+    `python -m torch.distributed.run` on this same script, and hand back the launcher's return code.  Called before anything here has
+    touched the GPU (importing torch does not): a GPU-initialised process must not be the one that starts other programs on these boxes,
+    and it is never an exec -- the parent stays, relays rank 0's JSON line (the children write to the inherited stdout) and exits with
+    the child's code.  The reference's own multi-GPU mechanism is nn.DataParallel inside one process
+    (trainers/classification/coop.py:268-272); one process per GPU is this repo's replacement for it."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+    def die_with_parent():                                       # the launcher gets SIGTERM if this process dies, however it dies;
+        import ctypes                                            # torch.distributed.run answers SIGTERM by stopping its workers
+        ctypes.CDLL(None).prctl(1, signal.SIGTERM)               # PR_SET_PDEATHSIG
+    # same process group as this process (no new session): a `kill -- -pgid` or a `timeout` aimed at bench.py reaches the ranks too
+    child = subprocess.Popen(cmd, env=env, preexec_fn=die_with_parent)
+
+    def forward(signum, _frame):
+        child.send_signal(signal.SIGTERM)
+    old = {s: signal.signal(s, forward) for s in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        return child.wait()
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
+        if child.poll() is None:
+            child.kill()
+            child.wait()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -369,8 +411,9 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        # plain `python bench.py --gpus N`: this process becomes the launcher of its N ranks (nothing below this line runs here)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    assert torch.cuda.is_available(), f"bench.py needs a GPU (no CPU fallback) [rank {rank} of {world}]"
     # BENCH_SAME_GPU=1 is a functional self-test of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the
     # exchange goes through torch.distributed/gloo (RCCL refuses two ranks on one device).  Never a measurement.
     same_gpu = os.environ.get("BENCH_SAME_GPU") == "1"

@@ -17,20 +17,13 @@ def pytest_configure(config):
 
 
 # ---- the N > 1 path on the hardware there is (tests/test_gpu_multirank.py) -------------------------------------------
-# Two fresh rank processes (torch.distributed.run) and one single-process reference run of bench.py are run HERE, at
+# Two fresh rank processes (`python bench.py --gpus 2`, which launches them) and one single-process reference run are run HERE, at
 # session start, before this process has touched the GPU (torch.cuda.device_count() does not initialise it): a process
 # that has initialised the GPU must not be the one that execs other programs on these boxes.  They run one after the other
 # and TO COMPLETION before the first test starts: a parity suite keeps its GPU to itself (profiles/r03_gpu_sharing.txt is
 # the story of the one flake that sharing it produced, and of the missing wait state behind it).  The test only compares
 # the dumps.
 MULTIRANK = {}
-
-
-def _free_port():
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def pytest_sessionstart(session):
@@ -46,27 +39,26 @@ def pytest_sessionstart(session):
     env = dict(os.environ, BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     bench = os.path.join(ROOT, "bench.py")
-    two = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                            "--master-port", str(_free_port()), bench, "--gpus", "2", "--dump", os.path.join(tmp, "two.npz")] + common,
-                           env=env, stdout=open(os.path.join(tmp, "two.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
-    try:
-        two.wait(timeout=600)
-    except subprocess.TimeoutExpired:
-        two.kill()
-    one = subprocess.Popen([sys.executable, bench, "--gpus", "1", "--virtual-ranks", "2", "--exchange-f16", "--dump", os.path.join(tmp, "one.npz")] + common,
-                           env=dict(os.environ, OMP_NUM_THREADS="8"), stdout=open(os.path.join(tmp, "one.out"), "w"), stderr=subprocess.STDOUT, cwd=ROOT)
-    try:
-        one.wait(timeout=600)
-    except subprocess.TimeoutExpired:
-        one.kill()
+
+    def run_to_completion(cmd, env, log):
+        """One child in a session of its own, so that on a timeout the WHOLE tree (bench.py -> torch.distributed.run -> rank workers) is
+        killed and reaped before the first test runs: an orphaned rank would share the GPU with the parity suite."""
+        import signal
+        p = subprocess.Popen(cmd, env=env, stdout=open(log, "w"), stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True)
+        try:
+            p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            p.wait()
+        return p
+    # exactly the driver's command for N > 1: plain `python bench.py --gpus 2` (bench.py starts its own rank processes)
+    two = run_to_completion([sys.executable, bench, "--gpus", "2", "--dump", os.path.join(tmp, "two.npz")] + common, env, os.path.join(tmp, "two.out"))
+    one = run_to_completion([sys.executable, bench, "--gpus", "1", "--virtual-ranks", "2", "--exchange-f16", "--dump", os.path.join(tmp, "one.npz")] + common,
+                            dict(os.environ, OMP_NUM_THREADS="8"), os.path.join(tmp, "one.out"))
     MULTIRANK.update(tmp=tmp, two=two, one=one)
-
-
-def pytest_sessionfinish(session, exitstatus):
-    for key in ("two", "one"):
-        p = MULTIRANK.get(key)
-        if p is not None and p.poll() is None:
-            p.kill()            # exactly the processes this session started
 
 
 def load_golden(name):
