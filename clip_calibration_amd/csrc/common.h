@@ -36,18 +36,22 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 #define CLIPMI_BUFFER_LOAD_LDS16(rsrc, lds, voff, soff) ::clipmi::buffer_load_lds16((rsrc), (lds), (voff), (soff))
 
 // A register that VALU instructions have just written (conversions, transcendentals: the softmax's P, the tail's hi / lo split) and that
-// an MFMA reads as a SOURCE operand right behind them needs wait states that hipcc does not insert on gfx950 for these sequences.  The
-// wave's own result is right either way -- every parity test passed without them -- but a wave of ANOTHER kernel resident on the same
-// SIMD came back with a 16-lane quarter of one register overwritten (profiles/r03_gpu_sharing.txt: 24-45 of 400 LayerNorm launches beside
-// the attention kernel, 0 of 400 with `s_nop 1` here).  The operand is named "+v" so that every instruction that writes it stays above.
-#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("s_nop 1" : "+v"(x))
-#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("s_nop 1" : "+v"(x), "+v"(y))
+// an MFMA reads as a SOURCE operand right behind them needs wait states that hipcc does not insert on gfx950 for these sequences (it
+// guarantees two).  The wave's own result is right either way -- every parity test passed without them -- but a wave of ANOTHER kernel
+// resident on the same SIMD came back with a 16-lane quarter of one register overwritten (profiles/r03_gpu_sharing.txt: 24-45 of 400
+// LayerNorm launches beside the attention kernel, 0 of 400 with the fence; the stand-alone reproducer and its wait-state table:
+// tools/probes/mfma_hazard_repro.hip, profiles/r04_hazard_repro.txt).  `s_nop 3` = FOUR wait states by itself, which is what
+// tools/mfma_hazard_scan.py (WAIT = 4) demands of every VALU-write -> MFMA-source pair: the guard holds by construction, not by what the
+// scheduler happens to place in between.  The operand is named "+v" so that every instruction that writes it stays above.
+#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("s_nop 3" : "+v"(x))
+#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("s_nop 3" : "+v"(x), "+v"(y))
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
-// result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.
-// Every kernel of the library reduces with these: __shfl_xor (ds_bpermute_b32) gave WRONG row sums in the LayerNorm kernel, a few
-// launches in a hundred, whenever a second process shared the GPU (profiles/r03_gpu_sharing.txt) -- never when the process ran alone.
+// result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.  A LATENCY
+// optimisation, used where a reduction sits on a dependent chain (the fused tail's row pass, logits.hip).  layernorm.hip
+// (ln_wave_sum) and attention.hip (the row maximum) keep the __shfl_xor butterfly, and correctly so: the wrong LayerNorm rows of
+// profiles/r03_gpu_sharing.txt were first blamed on ds_bpermute and turned out to be the VALU -> MFMA hazard above, in the OTHER kernel.
 //   step 1, 2: quad_perm (xor 1, xor 2)   3: row_half_mirror   4: row_mirror   5: rows (0,1) (2,3)   6: halves
 // ---------------------------------------------------------------------------------------------------------------
 template <int CTRL>

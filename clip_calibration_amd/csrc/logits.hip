@@ -106,7 +106,9 @@ __device__ __forceinline__ TailPartial block_partial(float x, int col, bool live
   p.m = live ? x : -INFINITY;
   p.arg = live ? col : 0x7fffffff;
   wave_argmax(p.m, p.arg);
-  p.s = wave_sum(live ? __expf(x - p.m) : 0.f);
+  // a block whose live columns are all -inf (masked classes) contributes nothing: exp(-inf - -inf) would be NaN, where the lane-strided
+  // form (and torch.softmax) has exp(-inf - M) = 0 for those columns.  p.m is wave-uniform here.
+  p.s = wave_sum(live && p.m != -INFINITY ? __expf(x - p.m) : 0.f);
   p.pad = 0;
   return p;
 }

@@ -5,6 +5,7 @@ input is not a ROCm tensor -- nothing here computes on the CPU or with torch ops
 """
 from __future__ import annotations
 
+import collections
 from typing import Optional, Tuple
 
 import torch
@@ -150,19 +151,30 @@ def logits_fused(img_n: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_con
     return logits, conf, pred
 
 
-_TAIL_WS = {}   # (device index, stream) -> zeroed int32 ticket counters (the kernel leaves them zero)
+_TAIL_WS = collections.OrderedDict()   # (device index, stream) -> zeroed int32 ticket counters (the kernel leaves them zero); LRU, bounded
+_TAIL_WS_MAX = 16                       # streams with a live workspace: short-lived per-thread streams must not pin buffers for ever
 
 
-def _tail_workspace(device: torch.device, batch: int, classes: int) -> torch.Tensor:
+def _tail_workspace(device: torch.device, batch: int, classes: int):
     """Ticket counters of the fused tail: one buffer per (device, stream).  Launches on ONE stream run in order and each leaves the
-    counters zero; two launches in flight on different streams must not share them (a foreign ticket would skip or double a row pass)."""
+    counters zero; two launches in flight on different streams must not share them (a foreign ticket would skip or double a row pass).
+    Returns (key, buffer); the least recently used entries beyond _TAIL_WS_MAX are dropped (the caching allocator keeps a dropped buffer
+    alive until the work queued on its stream is done), and `_tail_workspace_failed` drops the entry of a launch that raised."""
     need = lib.clipmi_fused_tail_workspace_bytes(batch, classes)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _TAIL_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=device)
         _TAIL_WS[key] = ws
-    return ws
+    _TAIL_WS.move_to_end(key)
+    while len(_TAIL_WS) > _TAIL_WS_MAX:
+        _TAIL_WS.popitem(last=False)
+    return key, ws
+
+
+def _tail_workspace_failed(key) -> None:
+    """A launch that raised may have left tickets behind: the next call on this stream starts from a freshly zeroed buffer."""
+    _TAIL_WS.pop(key, None)
 
 
 def fused_tail(img: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: Optional[torch.Tensor] = None,
@@ -196,11 +208,15 @@ def fused_tail(img: torch.Tensor, txt_n: torch.Tensor, scale: float, dac_conf: O
         conf = torch.empty(B, dtype=torch.float32, device=img.device)
         pred = torch.empty(B, dtype=torch.int32, device=img.device)
         pc, pp = conf.data_ptr(), pred.data_ptr()
-    ws = _tail_workspace(img.device, B, Cn)
-    with torch.cuda.device(img.device):
-        check(lib.clipmi_fused_tail(img.data_ptr(), _DT[img.dtype], int(normalize), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(),
-                                    img_n.data_ptr() if normalize else None, pc, pp, pl, pb, int(n_bins), ws.data_ptr(), ws.numel(),
-                                    B, Cn, E, _stream()), "clipmi_fused_tail")
+    key, ws = _tail_workspace(img.device, B, Cn)
+    try:
+        with torch.cuda.device(img.device):
+            check(lib.clipmi_fused_tail(img.data_ptr(), _DT[img.dtype], int(normalize), txt_n.data_ptr(), float(scale), pd, logits.data_ptr(),
+                                        img_n.data_ptr() if normalize else None, pc, pp, pl, pb, int(n_bins), ws.data_ptr(), ws.numel(),
+                                        B, Cn, E, _stream()), "clipmi_fused_tail")
+    except Exception:
+        _tail_workspace_failed(key)
+        raise
     return logits, img_n, conf, pred
 
 

@@ -500,6 +500,26 @@ def test_softmax_rows_vs_oracle(ops, B, C, dac):
     assert np.abs(lg.cpu().numpy() - want).max() < 1e-5
 
 
+def test_softmax_rows_masked_class_blocks(ops):
+    """Caller-supplied logits with whole 64-column blocks at -inf (masked classes): the blockwise denominator must treat such a block
+    as contributing nothing (exp(-inf - M) = 0, as torch.softmax does) instead of exp(-inf + inf) = NaN.  Rows: one masked block in the
+    middle, a masked first block, a masked ragged last block, everything but one column masked."""
+    C = 200
+    rng = np.random.default_rng(5)
+    logits = (rng.normal(size=(4, C)) * 3).astype(np.float32)
+    logits[0, 64:128] = -np.inf
+    logits[1, 0:64] = -np.inf
+    logits[2, 192:200] = -np.inf
+    logits[3, :] = -np.inf
+    logits[3, 131] = 0.5
+    probs, conf, pred = ops.softmax_rows(torch.from_numpy(logits).cuda(), None, want_conf_pred=True)
+    want = torch.softmax(torch.from_numpy(logits).double(), dim=1).numpy()
+    got = probs.cpu().numpy()
+    assert np.isfinite(got).all() and np.isfinite(conf.cpu().numpy()).all()
+    assert np.abs(got - want).max() < 1e-6
+    assert np.array_equal(pred.cpu().numpy(), logits.argmax(1)) and pred[3].item() == 131 and abs(conf[3].item() - 1.0) < 1e-6
+
+
 @pytest.mark.parametrize("B,H,W,C,Cout,relu", [(2, 8, 8, 64, 64, 1), (3, 7, 5, 128, 136, 1), (1, 14, 14, 256, 256, 0), (5, 3, 9, 64, 8, 1),
                                                (0, 4, 4, 64, 64, 1)])
 def test_conv3x3_implicit_gemm(B, H, W, C, Cout, relu):

@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
-"""Static check for the hazard of profiles/r03_gpu_sharing.txt: a VGPR written by a VALU instruction and read as a SOURCE operand by a v_mfma
-fewer than WAIT wait states later (hipcc inserts none for some of these sequences on gfx950; the wave's own result is right, a co-resident wave's
-registers are not).  Compiles a translation unit to ISA and walks every kernel; every instruction between the write and the MFMA counts one wait
-state, `s_nop N` counts N + 1.
+"""Static check for the hazard of profiles/r03_gpu_sharing.txt: a VGPR / AGPR written by a VALU instruction and read as a SOURCE operand by a
+v_mfma fewer than WAIT wait states later (hipcc inserts none for some of these sequences on gfx950; the wave's own result is right, a co-resident
+wave's registers are not).  Compiles a translation unit to ISA and runs a small data-flow pass over every kernel's control-flow graph: the set of
+"recent VALU writes" (register -> wait states since) flows along fall-through edges AND along every s_branch / s_cbranch edge, forwards and
+backwards, and is merged at labels with the SMALLEST distance -- so a write at the bottom of a loop that feeds an MFMA at its head through the
+back-edge is seen.  Every instruction between the write and the MFMA counts one wait state, `s_nop N` counts N + 1.
 
-    python tools/mfma_hazard_scan.py attention.hip logits.hip gemm.hip gemm_rstream.hip        (exit status 1 if a site is found)
+    python tools/mfma_hazard_scan.py attention.hip logits.hip gemm.hip gemm_rstream.hip        (exit status 1 if a site is found, 2 if a
+                                                                                                  file did not compile or holds no MFMA kernel)
 """
 import os
 import re
+import shutil
 import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clip_calibration_amd", "csrc")
-WAIT = int(os.environ.get("WAIT", "2"))
+WAIT = int(os.environ.get("WAIT", "4"))
 REG = re.compile(r"\b([va])(?:\[(\d+):(\d+)\]|(\d+)\b)")
+LOADS = ("global_load", "buffer_load", "flat_load", "scratch_load", "ds_read", "ds_bpermute", "ds_swizzle", "ds_permute")
+NO_FALLTHROUGH = ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64")
+
+
+class ScanError(RuntimeError):
+    pass
 
 
 def regs(tok):
@@ -24,44 +34,139 @@ def regs(tok):
     return out
 
 
-def scan(src):
-    asm = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only", src, "-o", "-"],
-                         cwd=CSRC, capture_output=True, text=True).stdout
-    sites, kernel, window = [], None, []      # window: (wait states since, written registers, text) of recent VALU writes
+def compile_to_isa(src, extra=()):
+    hipcc = shutil.which(os.environ.get("HIPCC", "hipcc"))
+    if hipcc is None:
+        raise ScanError("hipcc not found")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", *extra, "-S", "--cuda-device-only", src, "-o", "-"],
+                       cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise ScanError(f"hipcc failed on {src} (rc {r.returncode}):\n{r.stderr[-2000:]}")
+    return r.stdout
+
+
+def split_kernels(asm):
+    """[(kernel symbol, [(op, operands, text)], {label: index of the instruction that follows it})]"""
+    kernels, name, insts, labels = [], None, [], {}
     for line in asm.splitlines():
         t = line.strip()
-        m = re.match(r"^(_Z\S+):", t)
-        if m:
-            kernel, window = m.group(1), []
+        m = re.match(r"^(_Z\S+|[A-Za-z_]\w*):\s*(;.*)?$", t) if not t.startswith(".L") else None
+        if m and not t.startswith("."):
+            if name is not None:
+                kernels.append((name, insts, labels))
+            name, insts, labels = m.group(1), [], {}
             continue
-        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+        if name is None or not t or t.startswith((";", "//")):
+            continue
+        m = re.match(r"^(\.L\w+):", t)
+        if m:
+            labels[m.group(1)] = len(insts)
+            continue
+        if t.startswith("."):
+            if t.startswith((".end_amdhsa_kernel", ".section", ".amdhsa_kernel")) and name is not None and insts:
+                kernels.append((name, insts, labels))
+                name, insts, labels = None, [], {}
             continue
         t = t.split(";")[0].strip()
+        if not t:
+            continue
         op, _, rest = t.partition(" ")
-        ops = [o.strip() for o in rest.split(",")]
-        if op.startswith("v_mfma"):
-            srcs = set().union(*[regs(o) for o in ops[1:4]]) if len(ops) >= 4 else set()
-            for waited, written, text in window:
-                if waited < WAIT and written & srcs:
-                    sites.append((kernel, text, t, waited))
-        if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load", "ds_read", "ds_bpermute", "ds_swizzle")) and "lds" not in ops[-1:]:
-            over = regs(ops[0])          # a later load into the register supersedes the VALU write (its own wait is a counter, not wait states)
-            window = [(w, r - over, x) for (w, r, x) in window]
-        step = int(rest.strip() or 0) + 1 if op == "s_nop" else 1
-        window = [(w + step, r, x) for (w, r, x) in window if w + step < WAIT + 2]
-        if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_cmpx", "v_nop")) and ops and ops[0]:
-            written = regs(ops[0])
-            if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap")) and len(ops) > 1:
-                written |= regs(ops[1])
-            window.append((0, written, t))
-    return sites
+        insts.append((op, [o.strip() for o in rest.split(",")], t))
+    if name is not None and insts:
+        kernels.append((name, insts, labels))
+    return kernels
+
+
+def merge(dst, src):
+    """dst, src: {register: (wait states since the write, text of the write)}; keeps the smaller distance.  True if dst changed."""
+    changed = False
+    for r, (w, x) in src.items():
+        if r not in dst or w < dst[r][0]:
+            dst[r] = (w, x)
+            changed = True
+    return changed
+
+
+def scan_kernel(name, insts, labels):
+    n = len(insts)
+    state_in = [None] * (n + 1)          # None = not reached yet
+    state_in[0] = {}
+    sites, n_mfma = {}, 0
+    dirty = True
+    passes = 0
+    while dirty:
+        dirty = False
+        passes += 1
+        if passes > 64:
+            raise ScanError(f"{name}: data flow did not settle")
+        n_mfma = 0
+        for i, (op, ops, text) in enumerate(insts):
+            st = state_in[i]
+            if st is None:
+                continue
+            if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+                n_mfma += 1
+                if st and len(ops) >= 4:
+                    srcs = set().union(*[regs(o) for o in ops[1:4]])
+                    for r in srcs & st.keys():
+                        w, x = st[r]
+                        if w < WAIT:
+                            sites[(x, text)] = min(w, sites.get((x, text), w))
+            out = st
+            if st or op.startswith("v_"):
+                out = dict(st)
+                if op.startswith(LOADS) and ops[-1:] != ["lds"] and " lds" not in text:
+                    for r in regs(ops[0]):     # a later load into the register supersedes the VALU write (its own wait is a counter, not wait states)
+                        out.pop(r, None)
+                step = (int(ops[0] or 0) + 1) if op == "s_nop" else 1
+                out = {r: (w + step, x) for r, (w, x) in out.items() if w + step < WAIT}
+                if op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac", "v_cmp", "v_cmpx", "v_nop")) and ops and ops[0]:
+                    written = regs(ops[0])
+                    if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap")) and len(ops) > 1:
+                        written |= regs(ops[1])
+                    for r in written:
+                        out[r] = (0, text)
+            targets = []
+            if not op.startswith(NO_FALLTHROUGH):
+                targets.append(i + 1)
+            if op.startswith(("s_branch", "s_cbranch")):
+                lab = ops[-1].strip()
+                if lab in labels:
+                    targets.append(labels[lab])
+            for t in targets:
+                if state_in[t] is None:
+                    state_in[t] = dict(out)
+                    if t <= i:
+                        dirty = True
+                elif merge(state_in[t], out) and t <= i:
+                    dirty = True
+    return [(name, x, m, w) for (x, m), w in sites.items()], n_mfma
+
+
+def scan(src, extra=()):
+    """(sites, kernels with MFMAs, MFMA instructions) of one translation unit; raises ScanError when the file does not compile or holds no MFMA
+    kernel at all (a guard that scans nothing must not pass)."""
+    kernels = split_kernels(compile_to_isa(src, extra))
+    sites, with_mfma, total = [], 0, 0
+    for name, insts, labels in kernels:
+        s, n = scan_kernel(name, insts, labels)
+        sites += s
+        with_mfma += 1 if n else 0
+        total += n
+    if not with_mfma:
+        raise ScanError(f"{src}: no kernel with a v_mfma found in {len(kernels)} functions -- nothing was checked")
+    return sites, with_mfma, total
 
 
 def main():
     bad = 0
     for src in sys.argv[1:]:
-        sites = scan(src)
-        print(f"{src}: {len(sites)} VALU write -> MFMA source sites with fewer than {WAIT} wait states")
+        try:
+            sites, nk, nm = scan(src)
+        except ScanError as e:
+            print(f"{src}: SCAN FAILED: {e}")
+            sys.exit(2)
+        print(f"{src}: {len(sites)} VALU write -> MFMA source sites with fewer than {WAIT} wait states ({nk} MFMA kernels, {nm} MFMA instructions walked)")
         for kernel, w, m, waited in sites[:int(os.environ.get("SHOW", "12"))]:
             name = subprocess.run(["c++filt", kernel or "?"], capture_output=True, text=True).stdout.strip()[:90]
             print(f"   {name}\n      {w}\n      {m}      ({waited} wait states between)")
