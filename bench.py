@@ -143,6 +143,21 @@ def kernel_roofline(model, syn, geom, model_name, B, images):
     dom = max(kernels, key=lambda k: k["us_per_launch"])
     with torch.no_grad():
         tower_ms = timed_ms(lambda: model.image_features_f32(images), 10)
+        # the same five kernels timed IN PLACE: hipEvents behind every launch of real tower passes (clipmi_encode_image_timed), each kernel
+        # behind its real predecessor and on operands that predecessor has just written.  Mean over all layers of 3 passes (1 warm-up).
+        model.image_tower_launch_us(images)
+        passes = [model.image_tower_launch_us(images) for _ in range(3)]
+    for i, k in enumerate(kernels):
+        us = float(np.mean([blk[i] for p in passes for blk in p["blocks"]]))
+        k["us_in_tower"] = us
+        k["achieved_in_tower"] = k["flop_per_launch"] / (us * 1e-6) / 1e12
+        k["frac_in_tower"] = k["achieved_in_tower"] / MFMA_F16_DENSE_PEAK_TFLOPS
+    in_tower = {"embed_us": [float(np.mean([p["embed"][j] for p in passes])) for j in range(len(passes[0]["embed"]))],
+                "post_us": [float(np.mean([p["post"][j] for p in passes])) for j in range(2)],
+                "per_layer_us": float(np.mean([sum(blk) for p in passes for blk in p["blocks"]])),
+                "sum_ms": float(np.mean([p["total_us"] for p in passes])) * 1e-3,
+                "what": "one hipEvent behind every launch of a real pass: an interval = the kernel + the launch gap in front of it, so the "
+                        "intervals add up to the pass (sum_ms; compare tower.ms, the same pass without events)"}
     tower_flop = syn.flops_per_image(model_name) * B
     tower_tf = tower_flop / (tower_ms * 1e-3) / 1e12
     # HBM-side bytes per launch of the dominant kernel come from PMC passes (rocprofv3 cannot run inside this process):
@@ -170,9 +185,53 @@ def kernel_roofline(model, syn, geom, model_name, B, images):
     return {"bound": "mfma", "kernel": dom["kernel"] + " (dominant launch: one per layer, 12 per step)", "shape": dom["shape"],
             "flop_per_launch": dom["flop_per_launch"], "avg_launch_ms": dom["us_per_launch"] * 1e-3, "achieved": dom["achieved"],
             "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_note": note,
-            "kernels": kernels,
+            "kernels": kernels, "in_tower": in_tower,
             "tower": {"ms": tower_ms, "flop": tower_flop, "achieved": tower_tf, "frac": tower_tf / MFMA_F16_DENSE_PEAK_TFLOPS},
             "tower_frac": tower_tf / MFMA_F16_DENSE_PEAK_TFLOPS}
+
+
+def ceilings(dev, local_rank, geom, B, seconds=1.0):
+    """Two reference points for the fractions above, measured in THIS run on THIS box (neither is on the product path):
+    mfma_only   -- clipmi_probe_mfma_f16: a register-only v_mfma_f32_16x16x32_f16 loop (no LDS, no memory) on N(0, 0.25^2) fp16 operands,
+                   8 waves on every CU, back to back for `seconds` with the sysfs power sampler running: what the matrix pipe alone sustains
+                   at the package power cap on toggling data;
+    vendor_gemm -- torch.matmul (hipBLASLt) on the c_fc and c_proj shapes, no bias, no activation, no residual: a comparison only."""
+    from clip_calibration_amd._lib import check, lib
+    import ctypes as C
+    waves, iters = 8, 8000
+    n_cus = C.c_int(0)
+    ops_ = (torch.randn(16, waves * 64, 8, device=dev) * 0.25).half().contiguous()
+    sink = torch.empty(1024 * waves * 64, dtype=torch.float32, device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        check(lib.clipmi_probe_mfma_f16(ops_.data_ptr(), sink.data_ptr(), clk.data_ptr(), waves, iters, C.byref(n_cus), st), "clipmi_probe_mfma_f16")
+    one_ms = timed_ms(launch, 3)
+    n = max(4, int(seconds * 1e3 / one_ms))
+    sampler = PowerSampler(local_rank)
+    sampler.start()
+    ms = timed_ms(launch, n)
+    power = sampler.stop()
+    c = clk.cpu().numpy()
+    flop = 2.0 * 2 * 64 * 64 * 32 * iters * waves * n_cus.value
+    out = {"mfma_only": {"achieved": flop / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "frac_of_peak": flop / (ms * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "seconds": n * ms * 1e-3, "in_kernel_clock_mhz": float(c[0]) / (float(c[1]) / 100.0) if c[1] else None,
+                         "power_w": power.get("avg_w"), "power_cap_w": power.get("cap_w"), "sclk_mhz_sysfs": power.get("sclk_mhz_avg"),
+                         "what": f"v_mfma_f32_16x16x32_f16 from registers only, N(0, 0.25^2) fp16 operands, {waves} waves x {n_cus.value} CUs "
+                                 "(clipmi_probe_mfma_f16)"}}
+    L, D = geom.vision_tokens, geom.vision_width
+    M = B * L
+    vend = {}
+    for name, (N_, K_) in (("c_fc", (4 * D, D)), ("c_proj", (D, 4 * D))):
+        x = torch.randn(M, K_, device=dev).half()
+        w = (torch.randn(N_, K_, device=dev) * 0.03).half()
+        us = 1e3 * timed_ms(lambda: torch.matmul(x, w.t()), 20)
+        vend[name] = {"us": us, "achieved": 2.0 * M * N_ * K_ / (us * 1e-6) / 1e12, "shape": {"M": M, "N": N_, "K": K_}}
+        del x, w
+    out["vendor_gemm"] = dict(vend, what="torch.matmul (hipBLASLt) fp16, randn activations, N(0, 0.03^2) weights, NO epilogue (no bias / QuickGELU / "
+                                         "residual / LayerNorm fold): comparison only, never on the product path")
+    return out
 
 
 class PowerSampler:
@@ -662,6 +721,8 @@ def main():
     if not args.no_roofline:
         with torch.no_grad():
             out["roofline"] = kernel_roofline(model, syn, geom, args.model, B, images)
+            if rank == 0 and world == 1:
+                out["ceiling"] = ceilings(dev, local_rank, geom, B)
             feats = model.image_features_f32(images)
             # device time of the tail: its launches are queued BEHIND a tower pass (10 ms of GPU work), so that the host's
             # ~40 us of Python per call never starves the stream and the events bracket back-to-back executions only

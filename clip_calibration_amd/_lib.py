@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLIPMI_LIBRARY") or os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
@@ -77,6 +77,8 @@ _SIGNATURES = {
     "clipmi_layernorm": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp]),
     "clipmi_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "clipmi_patch_embed": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "clipmi_embed_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipmi_fused_tail_workspace_bytes": (_sz, [_i, _i]),
@@ -116,6 +118,8 @@ _SIGNATURES = {
     "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
     "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _u, _vp]),
     "clipmi_profile_block": (_i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
+    "clipmi_encode_image_timed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _u, C.POINTER(_f), _i, C.POINTER(_i), _vp]),
+    "clipmi_probe_mfma_f16": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -104,7 +104,7 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
     lacc[0] *= alpha;   // every row of the ones-tile holds the same sum; only register 0 is read
-    asm volatile("s_nop 1" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(lacc));   // VALU-written accumulators are MFMA sources (SrcC) below
+    CLIPMI_VALU_TO_MFMA_FENCE3(oacc[0], oacc[1], lacc);   // VALU-written accumulators are MFMA sources (SrcC) below
     // ---- P = 2^(C s - C m); O^T += V^T P^T; l += 1^T P^T
 #pragma unroll
     for (int t = 0; t < GROUP; ++t) {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void attend_dense_pf(const uint32_t (&ka)[4], const u
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
       lacc[0] *= alpha;
-      asm volatile("s_nop 1" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(lacc));   // VALU-written accumulators are MFMA sources (SrcC) below
+      CLIPMI_VALU_TO_MFMA_FENCE3(oacc[0], oacc[1], lacc);   // VALU-written accumulators are MFMA sources (SrcC) below
     }
     const float mc = m_new * C;
     m_run = m_new;

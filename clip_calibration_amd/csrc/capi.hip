@@ -237,11 +237,26 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
   }
 }
 
+// clipmi_encode_image_timed: one hipEvent behind every launch of a real tower pass (recorded asynchronously, read after the pass)
+struct LaunchTimer {
+  hipStream_t s;
+  std::vector<hipEvent_t> ev;
+  bool ok = true;
+  void tick() {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { ok = false; return; }
+    ev.push_back(e);
+    if (hipEventRecord(e, s) != hipSuccess) ok = false;
+  }
+  ~LaunchTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
+
 int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
-              hipStream_t s, bool f16res = false, bool cls_only = false) {
+              hipStream_t s, bool f16res = false, bool cls_only = false, LaunchTimer* timer = nullptr) {
   for (int step = 0; step < 5; ++step) {
     const int rc = run_block_step(step, b, w, n_seq, L, D, causal, folded, parts, s, f16res, cls_only);
     if (rc) return rc;
+    if (timer) timer->tick();
   }
   return CLIPMI_OK;
 }
@@ -426,6 +441,16 @@ int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal
 
 int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad, clipmi_stream_t stream) {
   return launch_patchify(image, image_dtype, (half_t*)col, B, R, P, Kpad, (hipStream_t)stream);
+}
+
+int clipmi_patch_embed(const void* image, int image_dtype, const void* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B, int R,
+                       int P, int D, int tokens, clipmi_stream_t stream) {
+  return launch_patch_embed(image, image_dtype, (const half_t*)conv_w, ldw, pos, x0, x0_dtype, B, R, P, D, tokens, (hipStream_t)stream);
+}
+
+int clipmi_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
+                    float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps, clipmi_stream_t stream) {
+  return launch_embed_ln(x0, x0_dtype, cls, pos, shallow, gamma, beta, y, (half_t*)y16, stats, B, L, tokens0, D, eps, (hipStream_t)stream);
 }
 
 int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, clipmi_stream_t stream) {
@@ -630,7 +655,8 @@ size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
 }
 
 static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
-                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream);
+                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream, LaunchTimer* timer = nullptr,
+                             int* n_pre = nullptr);
 
 int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
                         void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
@@ -657,8 +683,9 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
 }
 
 static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
-                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream, LaunchTimer* timer, int* n_pre) {
   int rc = CLIPMI_OK;
+  auto tick = [&] { if (timer) timer->tick(); };
   hipStream_t s = (hipStream_t)stream;
   const clipmi_geometry& g = m->g;
   const int G = m->grid(), L0 = m->tokens0(), n_ctx = hook ? hook->n_ctx : 0, L = L0 + n_ctx;
@@ -668,42 +695,103 @@ static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype
   CLIPMI_REQUIRE(workspace_bytes >= w.bytes, CLIPMI_ERR_WORKSPACE, "vision workspace too small: %zu < %zu", workspace_bytes, w.bytes);
   CLIPMI_REQUIRE((uintptr_t)workspace % 256 == 0, CLIPMI_ERR_ARG, "workspace must be 256-byte aligned");
 
-  half_t* col = w.hid;                             // [B*G*G, Kpad]
-  float* x0 = reinterpret_cast<float*>(w.qkv);     // [B*L, D] embeddings before ln_pre
-  if ((rc = launch_patchify(image, image_dtype, col, batch, g.image_resolution, g.patch_size, Kpad, s))) return rc;
-  GemmArgs a{};
-  a.A = col; a.lda = Kpad; a.W = (const half_t*)m->vw.conv_w; a.ldw = Kpad; a.out = x0; a.ldo = D; a.out_dtype = CLIPMI_F32;
-  a.M = batch * G * G; a.N = D; a.K = Kpad; a.epilogue = EPI_PATCH_POS;
-  a.pos = m->vw.positional_embedding; a.patches = G * G; a.tokens = L;
-  if ((rc = launch_gemm(a, s))) return rc;
-  if ((rc = launch_cls_and_ctx_rows(x0, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, batch, L0,
-                                    n_ctx, D, s)))
-    return rc;
   const bool folded = fold_enabled(m, m->vblocks);
   const bool f16res = residual_f16_enabled(m, folded, true, flags, &rc);
   if (rc) return rc;
   int parts = 1;
-  // fp16 residual stream: nothing reads the fp32 copy of ln_pre's output (the blocks work on w.xn) -- 155 MB less to write at batch 256
-  if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, f16res ? nullptr : w.xres, CLIPMI_F32, D, batch * L, D,
-                             1e-5f, s, folded ? w.xn : nullptr, folded ? w.stats : nullptr)))
-    return rc;
+  tick();   // start of the pass
+  if (patch_embed_fits(batch, g.image_resolution, g.patch_size, D, image_dtype) && Kpad == 3 * g.patch_size * g.patch_size) {
+    // Two launches (patch_embed.hip): the patch GEMM reads the NCHW image itself (the im2col matrix is an address map; fp32 pixels are cast
+    // on their way to LDS), adds pos and scatters the token rows -- fp16 rows when the stream is fp16 (the precision the reference's GPU
+    // path holds them in), fp32 rows otherwise; ln_pre then runs over every token row, forming the class row and MaPLe's shallow prompt
+    // rows on the fly, and leaves the stream (and / or its fp16 operand copy + row sums for the first in-projection's fold).
+    const int x0_dtype = f16res ? CLIPMI_F16 : CLIPMI_F32;
+    void* x0 = w.qkv;                              // [B*L, D] embeddings before ln_pre (fp16 or fp32: at most 4 of the region's 6 bytes per element)
+    if ((rc = launch_patch_embed(image, image_dtype, (const half_t*)m->vw.conv_w, Kpad, m->vw.positional_embedding, x0, x0_dtype, batch,
+                                 g.image_resolution, g.patch_size, D, L, s)))
+      return rc;
+    tick();
+    if ((rc = launch_embed_ln(x0, x0_dtype, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, m->vw.ln_pre_g,
+                              m->vw.ln_pre_b, f16res ? nullptr : w.xres, folded ? w.xn : nullptr, folded ? w.stats : nullptr, batch, L, L0, D, 1e-5f, s)))
+      return rc;
+    tick();
+    if (n_pre) *n_pre = 2;
+  } else {
+    // patch sizes that are not a multiple of 8 (ViT-L/14: a row segment of 14 pixels is not a whole number of 16-byte LDS slots): im2col
+    // matrix + GEMM + class rows + ln_pre as four launches
+    half_t* col = w.hid;                             // [B*G*G, Kpad]
+    float* x0 = reinterpret_cast<float*>(w.qkv);     // [B*L, D] embeddings before ln_pre
+    if ((rc = launch_patchify(image, image_dtype, col, batch, g.image_resolution, g.patch_size, Kpad, s))) return rc;
+    tick();
+    GemmArgs a{};
+    a.A = col; a.lda = Kpad; a.W = (const half_t*)m->vw.conv_w; a.ldw = Kpad; a.out = x0; a.ldo = D; a.out_dtype = CLIPMI_F32;
+    a.M = batch * G * G; a.N = D; a.K = Kpad; a.epilogue = EPI_PATCH_POS;
+    a.pos = m->vw.positional_embedding; a.patches = G * G; a.tokens = L;
+    if ((rc = launch_gemm(a, s))) return rc;
+    tick();
+    if ((rc = launch_cls_and_ctx_rows(x0, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, batch, L0,
+                                      n_ctx, D, s)))
+      return rc;
+    tick();
+    // fp16 residual stream: nothing reads the fp32 copy of ln_pre's output (the blocks work on w.xn) -- 155 MB less to write at batch 256
+    if ((rc = launch_layernorm(x0, CLIPMI_F32, D, nullptr, m->vw.ln_pre_g, m->vw.ln_pre_b, f16res ? nullptr : w.xres, CLIPMI_F32, D, batch * L, D,
+                               1e-5f, s, folded ? w.xn : nullptr, folded ? w.stats : nullptr)))
+      return rc;
+    tick();
+    if (n_pre) *n_pre = 4;   // patchify, patch-embedding GEMM, class / context rows, ln_pre
+  }
   for (int i = 0; i < g.vision_layers; ++i) {
     if (hook && i > 0 && i - 1 < hook->n_deep) {
       if ((rc = launch_overwrite_tokens(w.xres, hook->deep + (int64_t)(i - 1) * n_ctx * D, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
       if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, parts, batch, L, D, L - n_ctx, n_ctx, s))) return rc;
     }
     const bool cls_only = i == g.vision_layers - 1 && m->cls_only() == 1;
-    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res, cls_only))) return rc;
+    if ((rc = run_block(m->vblocks[i], w, batch, L, D, 0, folded, &parts, s, f16res, cls_only, timer))) return rc;
   }
   // ln_post on the class token only, then @ proj (clip/model.py:419-422)
   half_t* cls_rows = f16res ? w.att : w.xn;
   if (f16res) rc = launch_layernorm(w.xn, CLIPMI_F16, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, cls_rows, CLIPMI_F16, D, batch, D, 1e-5f, s);
   else rc = launch_layernorm(w.xres, CLIPMI_F32, (int64_t)L * D, nullptr, m->vw.ln_post_g, m->vw.ln_post_b, cls_rows, CLIPMI_F16, D, batch, D, 1e-5f, s);
   if (rc) return rc;
-  a = GemmArgs{};
+  tick();
+  GemmArgs a{};
   a.A = cls_rows; a.lda = D; a.W = (const half_t*)m->vw.proj_t; a.ldw = D; a.out = out; a.ldo = E; a.out_dtype = CLIPMI_F32;
   a.M = batch; a.N = E; a.K = D; a.epilogue = CLIPMI_EPI_NONE;
-  return launch_gemm(a, s);
+  rc = launch_gemm(a, s);
+  tick();
+  return rc;
+}
+
+int clipmi_encode_image_timed(clipmi_model* m, const void* image, int image_dtype, int batch, float* out, void* workspace, size_t workspace_bytes,
+                              unsigned flags, float* us_out, int n_us, int* n_pre_out, clipmi_stream_t stream) {
+  CLIPMI_REQUIRE(m && image && out && workspace && us_out && n_pre_out, CLIPMI_ERR_ARG, "encode_image_timed: null pointer");
+  CLIPMI_REQUIRE(m->has_vision, CLIPMI_ERR_STATE, "vision weights not bound (clipmi_set_vision_weights)");
+  CLIPMI_REQUIRE(image_dtype == CLIPMI_F16 || image_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "encode_image_timed: image dtype %d", image_dtype);
+  const int L = m->tokens0();
+  CLIPMI_REQUIRE(batch > 0 && pass_images(batch, L, m->g.vision_width) >= batch, CLIPMI_ERR_SHAPE,
+                 "encode_image_timed: batch=%d must be one pass of the tower (option vision_pass)", batch);
+  LaunchTimer timer;
+  timer.s = (hipStream_t)stream;
+  int n_pre = 0;
+  int rc = encode_image_pass(m, image, image_dtype, batch, nullptr, out, workspace, workspace_bytes, flags, stream, &timer, &n_pre);
+  if (rc) return rc;
+  const int n = (int)timer.ev.size() - 1;
+  CLIPMI_REQUIRE(timer.ok && n == n_pre + 5 * m->g.vision_layers + 2, CLIPMI_ERR_HIP, "encode_image_timed: event bookkeeping failed");
+  CLIPMI_REQUIRE(n_us >= n, CLIPMI_ERR_ARG, "encode_image_timed: us_out holds %d entries, %d needed", n_us, n);
+  if (hipEventSynchronize(timer.ev.back()) != hipSuccess) {
+    set_error("encode_image_timed: hipEventSynchronize failed");
+    return CLIPMI_ERR_HIP;
+  }
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, timer.ev[i], timer.ev[i + 1]) != hipSuccess) {
+      set_error("encode_image_timed: hipEventElapsedTime failed");
+      return CLIPMI_ERR_HIP;
+    }
+    us_out[i] = 1e3f * ms;
+  }
+  *n_pre_out = n_pre;
+  return n;
 }
 
 int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, const clipmi_prompt_hook* hook,

@@ -43,8 +43,20 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 // tools/probes/mfma_hazard_repro.hip, profiles/r04_hazard_repro.txt).  `s_nop 3` = FOUR wait states by itself, which is what
 // tools/mfma_hazard_scan.py (WAIT = 4) demands of every VALU-write -> MFMA-source pair: the guard holds by construction, not by what the
 // scheduler happens to place in between.  The operand is named "+v" so that every instruction that writes it stays above.
-#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("s_nop 3" : "+v"(x))
-#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("s_nop 3" : "+v"(x), "+v"(y))
+// CLIPMI_FENCE_SNOP (build-time, diagnostic builds only -- `make fence_sweep`, tools/probes/hazard_fence_sweep.py): the s_nop operand of
+// the fence, -1 = no wait states at all (what the library was until round 3).  The product build never defines it.
+#ifndef CLIPMI_FENCE_SNOP
+#define CLIPMI_FENCE_SNOP 3
+#endif
+#if CLIPMI_FENCE_SNOP < 0
+#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("" : "+v"(x))
+#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("" : "+v"(x), "+v"(y))
+#define CLIPMI_VALU_TO_MFMA_FENCE3(x, y, z) asm volatile("" : "+v"(x), "+v"(y), "+v"(z))
+#else
+#define CLIPMI_VALU_TO_MFMA_FENCE(x) asm volatile("s_nop %1" : "+v"(x) : "n"(CLIPMI_FENCE_SNOP))
+#define CLIPMI_VALU_TO_MFMA_FENCE2(x, y) asm volatile("s_nop %2" : "+v"(x), "+v"(y) : "n"(CLIPMI_FENCE_SNOP))
+#define CLIPMI_VALU_TO_MFMA_FENCE3(x, y, z) asm volatile("s_nop %3" : "+v"(x), "+v"(y), "+v"(z) : "n"(CLIPMI_FENCE_SNOP))
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
@@ -201,6 +213,13 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
 int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
+// patch_embed.hip: conv1 as a GEMM that reads the NCHW image directly (+ pos, token-row scatter) and ln_pre over every token row with the
+// class / shallow-prompt rows formed on the fly   (clip/model.py:394-402,413)
+bool patch_embed_fits(int B, int R, int P, int D, int image_dtype);
+int launch_patch_embed(const void* image, int image_dtype, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B,
+                       int R, int P, int D, int tokens, hipStream_t s);
+int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
+                    float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s);
 // x0[b, 0, :] = cls + pos[0]; x0[b, tokens0 + j, :] = shallow[j] (MaPLe)     (clip/model.py:398-402,459-460)
 int launch_cls_and_ctx_rows(float* x0, const float* cls, const float* pos, const float* shallow, int B, int tokens0,
                             int n_ctx, int D, hipStream_t s);

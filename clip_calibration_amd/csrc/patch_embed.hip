@@ -1,0 +1,386 @@
+// Patch embedding of the image tower as ONE GEMM that reads the image itself, and ln_pre as one row pass  (reference clip/model.py:394-402:
+// conv1 -> reshape -> permute -> cat(class_embedding) -> + positional_embedding; :413 ln_pre; :597-598 the dtype cast of encode_image).
+//
+//   patch_embed_kernel   x0[b, 1 + p, :] = patch(b, p) @ conv_w^T + pos[1 + p]          (MFMA GEMM, M = B * G * G patches, N = width, K = 3 P^2)
+//   embed_ln_kernel      x[b, l, :] = ln_pre(l == 0 ? cls + pos[0] : l < 1 + G^2 ? x0[b, l] : shallow[l - 1 - G^2])   -> the residual stream
+//
+// conv1 has stride = kernel = P, so its im2col matrix is a pure ADDRESS MAP of the NCHW image: column k = c P^2 + ky P + kx of patch
+// (b, py, px) is pixel (b, c, py P + ky, px P + kx).  With P % 8 == 0 every 8-element K chunk (one 16-byte LDS slot) is 8 consecutive
+// pixels of one image row, and the 4 (P = 16) row segments of a 64-deep K-step of the 8 patches a wave-instruction covers are four
+// contiguous 512-byte runs of the image.  The activation operand is therefore staged THROUGH REGISTERS -- two 16-byte loads of fp32 pixels,
+// four v_cvt_pk_f16_f32, one ds_write_b128 into the same XOR-swizzled LDS image the LDS-DMA kernels use -- which is where the fp32 -> fp16
+// cast of encode_image happens; an fp16 image takes the same path without the conversion.  The weight operand arrives by LDS-DMA as in
+// gemm.hip.  No im2col matrix (77 MB written and read back at batch 256), no patchify launch, no fp32 embedding buffer: the epilogue adds
+// the positional embedding in fp32 and stores the token rows -- in fp16 when the residual stream is fp16 (the reference's own GPU path
+// holds the conv output, the class token and the positional sum in fp16: clip/model.py:395-401 on a convert_weights model), in fp32
+// when the stream is fp32.  The class row and MaPLe's shallow prompt rows are the same for every image and never pass through memory:
+// embed_ln_kernel forms them on the fly.  embed_ln_kernel is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same
+// butterfly) with those three row sources and the outputs the blocks want: fp32 stream and / or fp16 operand copy + the LayerNorm-fold
+// row sums of the output.
+//
+// Algorithmic bytes per image (ViT-B/16, fp32 input): 602 KB of pixels read (x the n-tiles that miss L2), 302 KB of fp16 rows written;
+// ln_pre: 302 KB read, 302 KB written.  Before: patchify 602 + 301 KB, GEMM 301 KB + 605 KB of fp32 rows, cls rows, ln_pre 605 + 302 KB.
+#include "gemm_common.h"
+
+namespace clipmi {
+namespace {
+
+using namespace gemm;
+
+struct PEArgs {
+  const void* image;           // [B, 3, R, R] fp32 or fp16
+  const half_t* W; int64_t ldw;   // conv1.weight packed [N, K], K index c P^2 + ky P + kx
+  const float* pos;            // [tokens0, N]
+  void* out; int64_t ldo;      // token rows [B * tokens, N], fp16 or fp32
+  int M, N, K;                 // patches, width, 3 P^2
+  int R, P, G, GG, tokens;     // resolution, patch size, grid, G^2, tokens per sequence (1 + G^2 + n_ctx)
+  int tiles_n, nwg, band;
+};
+
+constexpr int PE_BM = 256, PE_BN = 256, PE_NT = 512;
+constexpr int PE_XBYTES = PE_BM * BK * 2, PE_WBYTES = PE_BN * BK * 2, PE_STAGE = PE_XBYTES + PE_WBYTES;
+constexpr int PE_SMEM = 2 * PE_STAGE;
+constexpr int PE_XI = PE_BM * 8 / PE_NT;   // 16-byte activation chunks per thread and stage (4)
+constexpr int PE_WI = PE_BN * 8 / PE_NT;   // LDS-DMA pieces per wave and stage (4)
+
+template <typename TI> struct PixelChunk;   // 8 consecutive pixels -> one f16x8 LDS slot
+template <> struct PixelChunk<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rs, int voff) {
+    lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0));
+  }
+  __device__ __forceinline__ f16x8 pack() const {
+    return f16x8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+  }
+};
+template <> struct PixelChunk<half_t> {
+  f16x8 v;
+  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rs, int voff) {
+    v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+  }
+  __device__ __forceinline__ f16x8 pack() const { return v; }
+};
+
+// 256 x 256 tile, eight waves of 128(m) x 64(n) (two per SIMD), two LDS stages.  Per K-step: the barrier that hands over stage kt, then
+// the pixel loads of stage kt + 1 go out (registers) and its weight pieces (LDS-DMA), then the 64 MFMAs of stage kt, then the pixels are
+// converted and written to the other stage buffer -- whose last reader passed this K-step's barrier.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
+  constexpr int TM = 8, TN = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave & 1, wave_n = wave >> 1;
+
+  // tile traversal: XCD label = blockIdx % 8 gets a contiguous range of tiles, bands of `band` n-tiles, m slow / n fast inside a band
+  // (gemm.hip tile_coords): the n-tiles of an m-tile run together on one XCD, whose L2 then serves the pixel rows to all but the first
+  int tile_m, tile_n;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tiles_m = a.nwg / a.tiles_n;
+    const int per_band = tiles_m * a.band;
+    const int b = wg / per_band;
+    const int within = wg - b * per_band;
+    const int rem = a.tiles_n - b * a.band;
+    const int gw = rem < a.band ? rem : a.band;
+    tile_m = within / gw;
+    tile_n = b * a.band + (within - tile_m * gw);
+  }
+  const int m0 = tile_m * PE_BM, n0 = tile_n * PE_BN;
+
+  // ---- activation staging: thread t, chunk i covers patch row i * 64 + (t >> 3) of the tile, LDS slot (t & 7) of that row, which holds
+  //      data chunk (t & 7) ^ ((row >> 1) & 7) -- the same for all four rows of a thread (rows differ by 64)
+  const int srow = tid >> 3;
+  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+  const int isz = (int)sizeof(TI);
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.image, (int64_t)(a.M / a.GG) * 3 * a.R * a.R * isz);
+  int prow[PE_XI];   // byte offset of pixel (b, 0, py P, px P) of the thread's patches; rows past M point past the descriptor (read as 0)
+#pragma unroll
+  for (int i = 0; i < PE_XI; ++i) {
+    const int m = m0 + i * (PE_NT / 8) + srow;
+    const int b = m / a.GG, p = m - b * a.GG;
+    const int py = p / a.G, px = p - py * a.G;
+    prow[i] = m < a.M ? (((b * 3) * a.R + py * a.P) * a.R + px * a.P) * isz : (int)0xFFFFFF00;
+  }
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int woff[PE_WI];
+#pragma unroll
+  for (int i = 0; i < PE_WI; ++i) woff[i] = ((i * (PE_NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
+  const int lds_wave_off = wave * 1024;
+  const int PP = a.P * a.P;
+
+  PixelChunk<TI> px[PE_XI];
+  auto load_pixels = [&](int kt) {   // k0 = kt * 64 + schunk * 8 -> (c, ky, kx): one division pair per thread and K-step
+    const int k0 = kt * BK + schunk * 8;
+    const int c = k0 / PP, rem = k0 - c * PP;
+    const int ky = rem / a.P, kx = rem - ky * a.P;
+    const int koff = ((c * a.R + ky) * a.R + kx) * isz;
+#pragma unroll
+    for (int i = 0; i < PE_XI; ++i) px[i].load(irs, prow[i] < 0 ? prow[i] : prow[i] + koff);
+  };
+  auto write_pixels = [&](int buf) {
+    char* xs = smem + buf * PE_STAGE + tid * 16;
+#pragma unroll
+    for (int i = 0; i < PE_XI; ++i) *reinterpret_cast<f16x8*>(xs + i * (PE_NT * 16)) = px[i].pack();
+  };
+  auto stage_w = [&](int buf, int kt) {
+    char* ws = smem + buf * PE_STAGE + PE_XBYTES + lds_wave_off;
+    const int k0 = kt * BK * 2;
+#pragma unroll
+    for (int i = 0; i < PE_WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (PE_NT * 16), woff[i], k0);
+  };
+
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int swz = (r16 >> 1) & 7;
+  int foff[2];
+  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
+  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
+  const int xbase = wave_m * 128 * 128;
+  const int wbase = PE_XBYTES + wave_n * 64 * 128;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  load_pixels(0);
+  stage_w(0, 0);
+  write_pixels(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's weight pieces have landed, its pixel slots are written
+    __syncthreads();                                               // ... and everybody's; the other buffer's readers are done
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_pixels(kt + 1);
+      stage_w((kt + 1) & 1, kt + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the loads go out in front of the MFMAs, not where their results are first used
+    const char* st = smem + (kt & 1) * PE_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 xf[TM], wf[TN];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) write_pixels((kt + 1) & 1);
+  }
+
+  // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m 128 + 16 j + r16][n = n0 + wave_n 64 + 16 i + 4 g4 + e]; + pos, token-row scatter
+  TO* out = static_cast<TO*>(a.out);
+  if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wave_m * 128 + j * 16 + r16;
+      if (m >= a.M) continue;
+      const int b = m / a.GG, t = m - b * a.GG + 1;
+      const int64_t orow = (int64_t)b * a.tokens + t;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
+        if (n >= a.N) continue;
+        *reinterpret_cast<f32x4*>(out + orow * a.ldo + n) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.pos + (int64_t)t * a.N + n);
+      }
+    }
+  } else {
+    // fp16 rows: 32 rows x 64 columns at a time through a wave-private LDS patch, so that a store instruction writes 128 contiguous
+    // bytes of 8 rows (16 B per lane) instead of 8-byte pieces (gemm.hip epilogue_f16_staged)
+    constexpr int ROWB = 64 * 2 + 16;
+    __syncthreads();   // every wave is done with the main-loop LDS image
+    char* patch = smem + wave * (32 * ROWB);
+    const int rrow = lane >> 3, rcol = lane & 7;
+    const int n_st = n0 + wave_n * 64 + rcol * 8;
+#pragma unroll
+    for (int jc = 0; jc < TM / 2; ++jc) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int m = m0 + wave_m * 128 + (jc * 2 + jj) * 16 + r16;
+        const int mm = m < a.M ? m : a.M - 1;
+        const int t = mm - (mm / a.GG) * a.GG + 1;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
+          f32x4 v = acc[i][jc * 2 + jj];
+          if (n < a.N) v += *reinterpret_cast<const f32x4*>(a.pos + (int64_t)t * a.N + n);
+          *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+      }
+      // same wave, LDS is in order: the reads below see the writes above (and the next slice's writes follow these reads)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + rrow;
+        const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+        const int m = m0 + wave_m * 128 + jc * 32 + row;
+        if (m < a.M && n_st < a.N) {
+          const int b = m / a.GG;
+          *reinterpret_cast<f16x8*>(out + ((int64_t)b * a.tokens + (m - b * a.GG + 1)) * a.ldo + n_st) = val;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ln_pre over every token row, one wave per row (layernorm.hip's arithmetic and reduction order).  Row sources:
+//   l == 0            cls + pos[0]                     (clip/model.py:398-401; identical for every image)
+//   1 <= l < tokens0  x0[b, l, :] as the GEMM above left it (fp16 or fp32)
+//   l >= tokens0      shallow[l - tokens0, :]          (MaPLe's shallow prompt tokens, clip/model.py:459-460: appended after pos is added)
+// Outputs: y (fp32 stream, optional) and / or y16 + stats (fp16 operand copy + LayerNorm-fold row sums of the output, partial 0).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float eln_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename TI, int NV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const TI* __restrict__ x0, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                       const float* __restrict__ shallow, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y, half_t* __restrict__ y16,
+                                                       float* __restrict__ stats_out, int rows, int L, int tokens0, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int l = row % L;
+  const int nvec = D >> 2;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      if (l == 0) {
+        v[i] = *reinterpret_cast<const f32x4*>(cls + c * 4) + *reinterpret_cast<const f32x4*>(pos + c * 4);
+      } else if (l >= tokens0) {
+        v[i] = *reinterpret_cast<const f32x4*>(shallow + (int64_t)(l - tokens0) * D + c * 4);
+      } else if constexpr (sizeof(TI) == 4) {
+        v[i] = *reinterpret_cast<const f32x4*>(x0 + (int64_t)row * D + c * 4);
+      } else {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(x0 + (int64_t)row * D + c * 4);
+        v[i] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = eln_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(eln_wave_sum(q) / (float)D + eps);
+  float os = 0.f, oq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (y) *reinterpret_cast<f32x4*>(y + (int64_t)row * D + c * 4) = o;
+      if (y16) {
+        *reinterpret_cast<f16x4*>(y16 + (int64_t)row * D + c * 4) = f16x4{(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+        os += (o[0] + o[1]) + (o[2] + o[3]);
+        oq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+      }
+    }
+  }
+  if (stats_out) {
+    os = eln_wave_sum(os);
+    oq = eln_wave_sum(oq);
+    if (lane == 0) *reinterpret_cast<float2*>(stats_out + 2 * (int64_t)row) = make_float2(os, oq);
+  }
+}
+
+template <typename TI, typename TO>
+int launch_pe(const PEArgs& a, hipStream_t s) {
+  static DeviceOnce attr_once;
+  auto fn = patch_embed_kernel<TI, TO>;
+  ensure_dynamic_lds(fn, PE_SMEM, attr_once);
+  hipLaunchKernelGGL(fn, dim3(a.nwg), dim3(PE_NT), PE_SMEM, s, a);
+  return check_launch("patch_embed_kernel");
+}
+
+}  // namespace
+
+bool patch_embed_fits(int B, int R, int P, int D, int image_dtype) {
+  const int64_t image_bytes = (int64_t)B * 3 * R * R * (image_dtype == CLIPMI_F16 ? 2 : 4);
+  return P > 0 && P % 8 == 0 && R % P == 0 && D % 8 == 0 && image_bytes < 0x7FFFFF00ll && (3 * P * P) % BK == 0 &&
+         (int64_t)3 * P * P < (1ll << 31) / (2 * 257);
+}
+
+int launch_patch_embed(const void* image, int image_dtype, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B,
+                       int R, int P, int D, int tokens, hipStream_t s) {
+  if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(image && conv_w && pos && x0, CLIPMI_ERR_ARG, "patch_embed: null pointer");
+  CLIPMI_REQUIRE(image_dtype == CLIPMI_F16 || image_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "patch_embed: image dtype %d", image_dtype);
+  CLIPMI_REQUIRE(x0_dtype == CLIPMI_F16 || x0_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "patch_embed: output dtype %d", x0_dtype);
+  CLIPMI_REQUIRE(patch_embed_fits(B, R, P, D, image_dtype), CLIPMI_ERR_SHAPE,
+                 "patch_embed: needs P %% 8 == 0, R %% P == 0, width %% 8 == 0 and an image batch below 2 GB (B=%d R=%d P=%d D=%d)", B, R, P, D);
+  CLIPMI_REQUIRE((uintptr_t)image % 16 == 0 && (uintptr_t)conv_w % 16 == 0 && (uintptr_t)pos % 16 == 0 && (uintptr_t)x0 % 16 == 0,
+                 CLIPMI_ERR_ARG, "patch_embed: pointers must be 16-byte aligned");
+  CLIPMI_REQUIRE((R * (image_dtype == CLIPMI_F16 ? 2 : 4)) % 16 == 0 && ldw % 8 == 0 && ldw >= 3 * P * P, CLIPMI_ERR_SHAPE,
+                 "patch_embed: image rows and weight rows must keep 16-byte alignment");
+  const int G = R / P;
+  CLIPMI_REQUIRE(tokens >= G * G + 1, CLIPMI_ERR_SHAPE, "patch_embed: tokens=%d < 1 + %d patches", tokens, G * G);
+  PEArgs a;
+  a.image = image; a.W = conv_w; a.ldw = ldw; a.pos = pos; a.out = x0; a.ldo = D;
+  a.M = B * G * G; a.N = D; a.K = 3 * P * P; a.R = R; a.P = P; a.G = G; a.GG = G * G; a.tokens = tokens;
+  const int tiles_m = (a.M + PE_BM - 1) / PE_BM;
+  a.tiles_n = (a.N + PE_BN - 1) / PE_BN;
+  a.band = a.tiles_n <= 6 ? a.tiles_n : 4;
+  const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
+  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "patch_embed: grid too large");
+  a.nwg = (int)nwg;
+  const bool i32 = image_dtype == CLIPMI_F32, o32 = x0_dtype == CLIPMI_F32;
+  if (i32 && o32) return launch_pe<float, float>(a, s);
+  if (i32) return launch_pe<float, half_t>(a, s);
+  if (o32) return launch_pe<half_t, float>(a, s);
+  return launch_pe<half_t, half_t>(a, s);
+}
+
+int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
+                    float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s) {
+  if (B == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(x0 && cls && pos && gamma && beta && (y || y16), CLIPMI_ERR_ARG, "embed_ln: null pointer");
+  CLIPMI_REQUIRE((!y16 && !stats_out) || (y16 && stats_out), CLIPMI_ERR_ARG, "embed_ln: y16 and stats_out come together");
+  CLIPMI_REQUIRE(L >= tokens0 && tokens0 >= 1 && (L == tokens0 || shallow), CLIPMI_ERR_ARG, "embed_ln: L=%d tokens0=%d / shallow prompt missing", L, tokens0);
+  CLIPMI_REQUIRE(D > 0 && D % 4 == 0 && D <= 4096, CLIPMI_ERR_SHAPE, "embed_ln: D=%d unsupported (D %% 4 == 0, D <= 4096)", D);
+  CLIPMI_REQUIRE((int64_t)B * L < (1ll << 31), CLIPMI_ERR_SHAPE, "embed_ln: too many rows");
+  const int rows = B * L;
+  const dim3 grid((rows + 3) / 4), block(256);
+  const bool wide = D / 4 > 64 * 4;
+#define ELN_LAUNCH(TI, NV) \
+  hipLaunchKernelGGL((embed_ln_kernel<TI, NV>), grid, block, 0, s, (const TI*)x0, cls, pos, shallow, gamma, beta, y, y16, stats_out, rows, L, tokens0, D, eps)
+  if (x0_dtype == CLIPMI_F32) { if (wide) ELN_LAUNCH(float, 16); else ELN_LAUNCH(float, 4); }
+  else { if (wide) ELN_LAUNCH(half_t, 16); else ELN_LAUNCH(half_t, 4); }
+#undef ELN_LAUNCH
+  return check_launch("embed_ln_kernel");
+}
+
+}  // namespace clipmi

@@ -463,6 +463,28 @@ class CLIP(nn.Module):
               "clipmi_profile_block")
         return {name: float(ms[i]) for i, name in enumerate(self.BLOCK_KERNELS)}
 
+    def image_tower_launch_us(self, image: torch.Tensor) -> Dict[str, object]:
+        """Device time of every launch of ONE real image-tower pass, each kernel in place behind its real predecessor
+        (clipmi_encode_image_timed): {"embed": [us per embedding launch], "blocks": [[in_proj, attention, out_proj, c_fc, c_proj] per
+        layer], "post": [ln_post, proj], "total_us": their sum, "features": the pass's fp32 features}."""
+        self._ensure_bound()
+        g = self.geometry
+        image = ops._dev(image, "image", (torch.float16, torch.float32))
+        B = image.shape[0]
+        out = torch.empty(B, g.embed_dim, dtype=torch.float32, device=image.device)
+        ws = self._workspace("vision", lib.clipmi_vision_workspace_bytes(self._handle, B, 0))
+        cap = 16 + 5 * g.vision_layers + 2
+        us = (C.c_float * cap)()
+        n_pre = C.c_int(0)
+        n = lib.clipmi_encode_image_timed(self._handle, image.data_ptr(), _DT[image.dtype], B, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          int(_lib.CALL_DEFAULT), us, cap, C.byref(n_pre), ops._stream())
+        if n < 0:
+            check(n, "clipmi_encode_image_timed")
+        v = [float(us[i]) for i in range(n)]
+        p = n_pre.value
+        return {"embed": v[:p], "blocks": [v[p + 5 * i:p + 5 * i + 5] for i in range(g.vision_layers)], "post": v[n - 2:], "total_us": sum(v),
+                "features": out}
+
 
 def convert_weights(model: nn.Module) -> None:
     """Apply the reference dtype policy in place (clip/model.py:632-653)."""

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 11
+#define CLIPMI_ABI_VERSION 12
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -129,6 +129,26 @@ int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal
 /* image.type(dtype) + the im2col half of conv1 (clip/model.py:598,395-397): image [B,3,R,R] (fp32 or fp16,
  * NCHW) -> col fp16 [B*(R/P)^2, Kpad], column c*P*P + ky*P + kx, zero padded up to Kpad (a multiple of 64). */
 int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad,
+                    clipmi_stream_t stream);
+
+/* image.type(dtype) + conv1 + reshape / permute + positional embedding of the PATCH rows in one GEMM that reads the image itself
+ * (clip/model.py:598,395-397,401; conv1 has stride = kernel = P, so its im2col matrix is an address map of the NCHW image):
+ *   x0[b * tokens + 1 + p, :] = sum_k pixel(b, p, k) * conv_w[:, k] + pos[1 + p, :]        p = py * (R/P) + px,  k = c*P*P + ky*P + kx
+ * image [B,3,R,R] fp32 or fp16; conv_w fp16 [D, ldw] = conv1.weight.reshape(D, 3*P*P) (ldw >= 3*P*P); pos fp32 [1 + (R/P)^2, D];
+ * x0 fp16 or fp32 (x0_dtype) [B * tokens, D]: only the patch rows are written -- row 0 (class token) and rows beyond 1 + (R/P)^2
+ * (prompt tokens) of every sequence are left to clipmi_embed_ln.  fp16 operands, fp32 accumulation, pos added in fp32, one rounding.
+ * Requires P % 8 == 0, R % P == 0, D % 8 == 0, an image batch below 2 GB; 16-byte aligned pointers.  CLIPMI_ERR_SHAPE otherwise
+ * (clipmi_encode_image then takes clipmi_patchify + clipmi_gemm_f16: ViT-L/14). */
+int clipmi_patch_embed(const void* image, int image_dtype, const void* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
+                       int B, int R, int P, int D, int tokens, clipmi_stream_t stream);
+
+/* cat(class_embedding) + positional embedding of the class row + ln_pre over every token row (clip/model.py:398-402,413; MaPLe's shallow
+ * prompt rows, :459-460), one wave per row:  row (b, l) = l == 0 ? cls + pos[0] : l < tokens0 ? x0[b * L + l] : shallow[l - tokens0];
+ * out = LayerNorm(row) with fp32 statistics.  x0 fp16 / fp32 [B * L, D] as clipmi_patch_embed left it; cls fp32 [D]; pos fp32 [>= 1, D];
+ * shallow fp32 [L - tokens0, D] or NULL when L == tokens0; y fp32 [B * L, D] or NULL; y16 fp16 [B * L, D] + stats fp32 [B * L * 2]
+ * ((sum, sum of squares) of each output row: the LayerNorm-fold partial the first in-projection consumes) or both NULL. */
+int clipmi_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma,
+                    const float* beta, float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps,
                     clipmi_stream_t stream);
 
 /* Row L2 normalisation  f / ||f||  (zsclip.py:99; coop.py:212-213): in (fp16|fp32) [rows,E] -> out fp32. */
@@ -389,6 +409,27 @@ int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float
  * all five, 0..4 just that one (the others report 0).  Synchronises the stream; overwrites the activations in the workspace. */
 int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* workspace, size_t workspace_bytes,
                          float* ms_out, clipmi_stream_t stream);
+
+/* Timing aid for bench.py (`roofline.kernels[].us_in_tower`): ONE real pass of clipmi_encode_image on `batch` images (no prompt hook;
+ * the batch must be a single pass of the tower, option vision_pass) with a hipEvent recorded on `stream` behind every launch, so that
+ * each kernel is timed IN PLACE -- behind its real predecessor, on operands that predecessor has just written -- instead of back to
+ * back with itself as clipmi_profile_block does.  us_out (host float[n_us]) receives the microseconds between consecutive events:
+ *   [0 .. *n_pre_out)                       the embedding launches in front of the first block (today: patch embedding, ln_pre)
+ *   [*n_pre_out + 5 * layer + step]         step 0 in-proj, 1 attention, 2 out-proj, 3 c_fc, 4 c_proj of each residual block
+ *   the last two                            ln_post on the class rows, the final projection
+ * (an interval holds the kernel and the launch gap in front of it, so the entries add up to the pass).  Returns the number of
+ * entries written (> 0) or a negative error code; synchronises the stream; `out` receives the features as usual. */
+int clipmi_encode_image_timed(clipmi_model* m, const void* image, int image_dtype, int batch, float* out, void* workspace,
+                              size_t workspace_bytes, unsigned flags, float* us_out, int n_us, int* n_pre_out, clipmi_stream_t stream);
+
+/* Ceiling probe for bench.py (`ceiling.mfma_only`; not on any product path): a register-only loop of v_mfma_f32_16x16x32_f16 -- no LDS, no
+ * memory inside the loop -- on one workgroup of `waves` waves (1..8: two per SIMD, 256 registers each) per CU, every wave holding two register-resident sets of 4 + 4
+ * operand fragments loaded once from `operands` (fp16 [16][waves * 64][8]: whatever distribution the caller wants the matrix pipe to
+ * multiply, e.g. N(0, 0.25^2) like the tower's operands) and issuing iters x 32 MFMAs (one operand held for four instructions, as the GEMM
+ * loops do).  2 * 2 * 64 * 64 * 32 flop per wave and iteration.  `sink` (fp32 [CUs * waves * 64]) keeps the results live; `clocks` (NULL or
+ * 2 x uint64) receives workgroup 0's elapsed shader cycles and 100 MHz ticks.  *n_cus_out (host, may be NULL) = workgroups launched. */
+int clipmi_probe_mfma_f16(const void* operands, float* sink, unsigned long long* clocks, int waves, int iters, int* n_cus_out,
+                          clipmi_stream_t stream);
 
 #ifdef __cplusplus
 }

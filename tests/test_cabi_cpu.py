@@ -269,7 +269,7 @@ def test_modified_resnet_boundary_surface():
         m.encode_image(torch.zeros(1, 3, 64, 64))                       # no CPU path
 
 
-MFMA_SOURCES = ("attention.hip", "logits.hip", "gemm.hip", "gemm_rstream.hip")
+MFMA_SOURCES = ("attention.hip", "logits.hip", "gemm.hip", "gemm_rstream.hip", "patch_embed.hip", "probe.hip")
 
 
 def _hazard_scan():
@@ -304,7 +304,7 @@ def test_no_valu_written_mfma_source_closer_than_four_wait_states():
     assert len(lines) == len(MFMA_SOURCES), r.stdout
     for ln in lines:
         m = re.search(r": 0 VALU write .* \((\d+) MFMA kernels, (\d+) MFMA instructions walked\)", ln)
-        assert m and int(m.group(1)) >= 1 and int(m.group(2)) >= 64, ln
+        assert m and int(m.group(1)) >= 1 and int(m.group(2)) >= 32, ln
 
 
 def test_hazard_scan_follows_branches_and_fails_loudly():

@@ -817,6 +817,44 @@ def test_image_tower_passes_same_bits(clipmi_option, hooked):
         assert need < need_whole if B >= 6 else need == need_whole            # 5 images: less than one and a half passes -> one pass
 
 
+def test_timed_tower_pass_is_the_ordinary_pass():
+    """clipmi_encode_image_timed (bench.py's `us_in_tower`): the same launches as clipmi_encode_image with a hipEvent behind each -- same
+    bits out, one positive interval per launch (embedding launches + 5 per layer + ln_post + proj), and a batch beyond one pass is refused
+    rather than timed as something else."""
+    sd, model = _build("tiny")
+    g = model.geometry
+    images = syn.synthetic_images(6, "tiny", seed=2).cuda()
+    with torch.no_grad():
+        want = model.image_features_f32(images).clone()
+        t = model.image_tower_launch_us(images)
+    assert torch.equal(t["features"], want)
+    assert len(t["blocks"]) == g.vision_layers and all(len(b) == 5 for b in t["blocks"]) and len(t["post"]) == 2 and len(t["embed"]) >= 1
+    flat = t["embed"] + [u for b in t["blocks"] for u in b] + t["post"]
+    assert all(u > 0.0 for u in flat) and abs(sum(flat) - t["total_us"]) < 1e-3
+    from clip_calibration_amd import _lib
+    with _lib.option("vision_pass", 2 * g.vision_tokens * g.vision_width):      # 2 images per pass: 6 images are three passes
+        with pytest.raises(_lib.ClipmiError):
+            model.image_tower_launch_us(images)
+
+
+def test_mfma_ceiling_probe_runs():
+    """clipmi_probe_mfma_f16 (bench.py's `ceiling.mfma_only`): the loop runs, fills its sink with finite sums that depend on the operands,
+    and reports its clocks.  A rate is not asserted here -- bench.py measures it."""
+    import ctypes as C
+    from clip_calibration_amd._lib import check, lib
+    waves = 4
+    ops_ = (torch.randn(16, waves * 64, 8, device="cuda") * 0.25).half().contiguous()
+    n_cus = C.c_int(0)
+    sink = torch.full((1024 * waves * 64,), float("nan"), device="cuda")
+    clk = torch.zeros(2, dtype=torch.int64, device="cuda")
+    check(lib.clipmi_probe_mfma_f16(ops_.data_ptr(), sink.data_ptr(), clk.data_ptr(), waves, 10, C.byref(n_cus), torch.cuda.current_stream().cuda_stream), "probe")
+    torch.cuda.synchronize()
+    n = n_cus.value * waves * 64
+    assert n_cus.value >= 1 and torch.isfinite(sink[:n]).all() and sink[:n].abs().max() > 0 and torch.isnan(sink[n:]).all()
+    assert (clk > 0).all()
+    assert lib.clipmi_probe_mfma_f16(ops_.data_ptr(), sink.data_ptr(), None, 9, 10, None, None) < 0      # more waves than the probe's register budget allows
+
+
 @pytest.mark.parametrize("source", ["pageable", "pinned", "device"])
 def test_device_batches_order_and_values(source):
     """runner.device_batches (the host -> device leg of the test loop, base_learner.py:84-88,175-182): batches arrive in order and

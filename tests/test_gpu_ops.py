@@ -326,6 +326,68 @@ def test_patchify(ops, B, R, P, dt):
     assert (col[:, k:] == 0).all()
 
 
+@pytest.mark.parametrize("B,R,P,D,n_ctx,dt_in,dt_out", [(2, 224, 16, 768, 0, torch.float32, torch.float16), (3, 64, 16, 128, 2, torch.float16, torch.float16),
+                                                        (5, 64, 32, 64, 0, torch.float32, torch.float32), (1, 32, 8, 72, 0, torch.float32, torch.float16),
+                                                        (7, 96, 16, 200, 3, torch.float16, torch.float32), (40, 224, 16, 768, 0, torch.float32, torch.float16)])
+def test_patch_embed_vs_conv2d(B, R, P, D, n_ctx, dt_in, dt_out):
+    """clipmi_patch_embed (conv1 as a GEMM that reads the NCHW image itself, + positional embedding, token-row scatter; clip/model.py:395-401)
+    against F.conv2d in fp32 on the same fp16-rounded pixels and weights.  Ragged M (patch count not a multiple of the 256-row tile),
+    ragged N, patch sizes 8 / 16 / 32, fp16 and fp32 images and outputs; the class row and the prompt rows of every sequence are not touched."""
+    import torch.nn.functional as F
+    from clip_calibration_amd._lib import F16, F32, check, lib
+    g = torch.Generator().manual_seed(B * 131 + R + P)
+    G = R // P
+    L = 1 + G * G + n_ctx
+    image = torch.randn(B, 3, R, R, generator=g).to(dt_in)
+    w = (torch.randn(D, 3, P, P, generator=g) * (3 * P * P) ** -0.5).half()
+    pos = torch.randn(1 + G * G, D, generator=g) * 0.3
+    x0 = torch.full((B * L, D), float("nan"), dtype=dt_out, device="cuda")
+    wd = w.reshape(D, 3 * P * P).contiguous().cuda()
+    check(lib.clipmi_patch_embed(image.cuda().data_ptr(), F32 if dt_in == torch.float32 else F16, wd.data_ptr(), 3 * P * P, pos.cuda().data_ptr(),
+                                 x0.data_ptr(), F32 if dt_out == torch.float32 else F16, B, R, P, D, L, torch.cuda.current_stream().cuda_stream),
+          "clipmi_patch_embed")
+    ref = F.conv2d(image.half().float(), w.float(), stride=P).reshape(B, D, G * G).permute(0, 2, 1) + pos[1:]
+    got = x0.float().cpu().reshape(B, L, D)
+    assert torch.isnan(got[:, 0]).all() and (n_ctx == 0 or torch.isnan(got[:, 1 + G * G:]).all())       # class / prompt rows untouched
+    err = (got[:, 1:1 + G * G] - ref).abs().max().item()
+    assert err < (2e-3 if dt_out == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("B,L0,n_ctx,D,dt", [(3, 197, 0, 768, torch.float16), (2, 17, 2, 128, torch.float32), (5, 50, 4, 1024, torch.float16),
+                                            (1, 5, 0, 1280, torch.float32)])
+@pytest.mark.parametrize("outs", ["y", "y16", "both"])
+def test_embed_ln_vs_layer_norm(B, L0, n_ctx, D, dt, outs):
+    """clipmi_embed_ln: cat(class_embedding) + pos[0], the patch rows as the GEMM left them, MaPLe's shallow prompt rows, then ln_pre
+    (clip/model.py:398-402,413,459-460) against F.layer_norm in fp32; the fold row sums are those of the output."""
+    import torch.nn.functional as F
+    from clip_calibration_amd._lib import F16, F32, check, lib
+    g = torch.Generator().manual_seed(B * 7 + D)
+    L = L0 + n_ctx
+    x0 = (torch.randn(B * L, D, generator=g) * 2 + 0.5).to(dt)
+    cls, pos = torch.randn(D, generator=g), torch.randn(L0, D, generator=g) * 0.2
+    shallow = torch.randn(max(n_ctx, 1), D, generator=g)
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    y = torch.full((B * L, D), float("nan"), device="cuda") if outs != "y16" else None
+    y16 = torch.full((B * L, D), float("nan"), dtype=torch.float16, device="cuda") if outs != "y" else None
+    stats = torch.full((B * L, 2), float("nan"), device="cuda") if outs != "y" else None
+    dev = [t.cuda() for t in (x0, cls, pos, shallow, gamma, beta)]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    check(lib.clipmi_embed_ln(dev[0].data_ptr(), F32 if dt == torch.float32 else F16, dev[1].data_ptr(), dev[2].data_ptr(),
+                              dev[3].data_ptr() if n_ctx else None, dev[4].data_ptr(), dev[5].data_ptr(), ptr(y), ptr(y16), ptr(stats), B, L, L0, D,
+                              1e-5, torch.cuda.current_stream().cuda_stream), "clipmi_embed_ln")
+    rows = x0.float().reshape(B, L, D).clone()
+    rows[:, 0] = cls + pos[0]
+    if n_ctx:
+        rows[:, L0:] = shallow[:n_ctx]
+    want = F.layer_norm(rows, (D,), gamma, beta, 1e-5).reshape(B * L, D)
+    if y is not None:
+        assert (y.cpu() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    if y16 is not None:
+        assert (y16.float().cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+        st = stats.cpu()
+        assert torch.allclose(st[:, 0], want.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[:, 1], (want * want).sum(1), rtol=1e-4, atol=1e-2)
+
+
 def test_l2_and_logits_dac_conf_pred(ops):
     g = load_golden("dac_cases.npz")
     rng = np.random.default_rng(1)

@@ -8,6 +8,8 @@ back-edge is seen.  Every instruction between the write and the MFMA counts one 
 
     python tools/mfma_hazard_scan.py attention.hip logits.hip gemm.hip gemm_rstream.hip        (exit status 1 if a site is found, 2 if a
                                                                                                   file did not compile or holds no MFMA kernel)
+    WAIT=16 EXTRA=-DCLIPMI_FENCE_SNOP=1 python tools/mfma_hazard_scan.py attention.hip         (EXTRA: more hipcc flags; every run also prints
+                                                                                                  the SMALLEST distance it met below WAIT)
 """
 import os
 import re
@@ -162,11 +164,12 @@ def main():
     bad = 0
     for src in sys.argv[1:]:
         try:
-            sites, nk, nm = scan(src)
+            sites, nk, nm = scan(src, tuple(os.environ.get("EXTRA", "").split()))
         except ScanError as e:
             print(f"{src}: SCAN FAILED: {e}")
             sys.exit(2)
-        print(f"{src}: {len(sites)} VALU write -> MFMA source sites with fewer than {WAIT} wait states ({nk} MFMA kernels, {nm} MFMA instructions walked)")
+        print(f"{src}: {len(sites)} VALU write -> MFMA source sites with fewer than {WAIT} wait states ({nk} MFMA kernels, {nm} MFMA instructions walked)"
+              + (f"; smallest distance {min(w for _, _, _, w in sites)}" if sites else ""))
         for kernel, w, m, waited in sites[:int(os.environ.get("SHOW", "12"))]:
             name = subprocess.run(["c++filt", kernel or "?"], capture_output=True, text=True).stdout.strip()[:90]
             print(f"   {name}\n      {w}\n      {m}      ({waited} wait states between)")
