@@ -197,8 +197,18 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
   const int64_t Mfull = (int64_t)n_seq * L;
   int rc;
   GemmArgs a{};
+  // option attn_loader = 3: steps 0 and 1 are ONE launch (in-projection fused into the vision attention kernel); step 1 is then empty
+  const bool fused_qkv = !causal && !cls_only && options().attn_loader.load(std::memory_order_relaxed) == 3 &&
+                         qkv_attention_fits(L, D, folded ? *parts : 0);   // (*parts is what step 4 of the previous block left: the same for steps 0 and 1)
   switch (step) {
     case 0:
+      if (fused_qkv) {
+        if (!folded) {
+          if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
+          return launch_qkv_attention(w.xn, (const half_t*)b.w_qkv, nullptr, b.b_qkv, nullptr, 0, w.att, n_seq, L, H, 1e-5f, 1, s);
+        }
+        return launch_qkv_attention(w.xn, (const half_t*)b.w_qkv_f, b.g_qkv, b.c_qkv, w.stats, *parts, w.att, n_seq, L, H, 1e-5f, 1, s);
+      }
       if (!folded) {
         if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
         a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
@@ -211,6 +221,7 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
       return launch_gemm(a, s);
     case 1:
+      if (fused_qkv) return CLIPMI_OK;
       return launch_attention(w.qkv, w.att, n_seq, L, H, causal, s);
     case 2:
       a.A = w.att; a.lda = rowD; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
@@ -439,13 +450,20 @@ int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal
   return launch_attention((const half_t*)qkv, (half_t*)out, N, L, H, causal, (hipStream_t)stream);
 }
 
+int clipmi_qkv_attention(const void* x16, const void* w_qkv, const float* g, const float* c, const float* stats, int parts, void* out, int N, int L,
+                         int H, float eps, int nt_stores, clipmi_stream_t stream) {
+  return launch_qkv_attention((const half_t*)x16, (const half_t*)w_qkv, g, c, stats, parts, (half_t*)out, N, L, H, eps, nt_stores, (hipStream_t)stream);
+}
+
 int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad, clipmi_stream_t stream) {
   return launch_patchify(image, image_dtype, (half_t*)col, B, R, P, Kpad, (hipStream_t)stream);
 }
 
-int clipmi_patch_embed(const void* image, int image_dtype, const void* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B, int R,
-                       int P, int D, int tokens, clipmi_stream_t stream) {
-  return launch_patch_embed(image, image_dtype, (const half_t*)conv_w, ldw, pos, x0, x0_dtype, B, R, P, D, tokens, (hipStream_t)stream);
+size_t clipmi_patch_embed_scratch_bytes(int B, int R, int image_dtype) { return (B < 0 || R < 0) ? 0 : patch_embed_scratch_bytes(B, R, image_dtype); }
+
+int clipmi_patch_embed(const void* image, int image_dtype, void* scratch, const void* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
+                       int B, int R, int P, int D, int tokens, clipmi_stream_t stream) {
+  return launch_patch_embed(image, image_dtype, scratch, (const half_t*)conv_w, ldw, pos, x0, x0_dtype, B, R, P, D, tokens, (hipStream_t)stream);
 }
 
 int clipmi_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
@@ -700,17 +718,17 @@ static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype
   if (rc) return rc;
   int parts = 1;
   tick();   // start of the pass
-  if (patch_embed_fits(batch, g.image_resolution, g.patch_size, D, image_dtype) && Kpad == 3 * g.patch_size * g.patch_size) {
-    // Two launches (patch_embed.hip): the patch GEMM reads the NCHW image itself (the im2col matrix is an address map; fp32 pixels are cast
-    // on their way to LDS), adds pos and scatters the token rows -- fp16 rows when the stream is fp16 (the precision the reference's GPU
-    // path holds them in), fp32 rows otherwise; ln_pre then runs over every token row, forming the class row and MaPLe's shallow prompt
-    // rows on the fly, and leaves the stream (and / or its fp16 operand copy + row sums for the first in-projection's fold).
+  if (patch_embed_fits(batch, g.image_resolution, g.patch_size, D) && Kpad == 3 * g.patch_size * g.patch_size) {
+    // patch_embed.hip: (an fp32 image is cast to fp16 in one streaming pass, into the MLP hidden buffer;) the patch GEMM's loader reads the
+    // NCHW image itself -- the im2col matrix is an address map --, adds pos and scatters the token rows: fp16 rows when the stream is fp16 (the
+    // precision the reference's GPU path holds them in), fp32 rows otherwise; ln_pre then runs over every token row, forming the class row and
+    // MaPLe's shallow prompt rows on the fly, and leaves the stream (and / or its fp16 operand copy + row sums for the first in-projection's fold).
     const int x0_dtype = f16res ? CLIPMI_F16 : CLIPMI_F32;
     void* x0 = w.qkv;                              // [B*L, D] embeddings before ln_pre (fp16 or fp32: at most 4 of the region's 6 bytes per element)
-    if ((rc = launch_patch_embed(image, image_dtype, (const half_t*)m->vw.conv_w, Kpad, m->vw.positional_embedding, x0, x0_dtype, batch,
-                                 g.image_resolution, g.patch_size, D, L, s)))
+    if ((rc = launch_patch_embed(image, image_dtype, w.hid /* >= col_bytes = the fp16 image's size */, (const half_t*)m->vw.conv_w, Kpad,
+                                 m->vw.positional_embedding, x0, x0_dtype, batch, g.image_resolution, g.patch_size, D, L, s)))
       return rc;
-    tick();
+    tick();   // (one interval: the cast of an fp32 image + the GEMM)
     if ((rc = launch_embed_ln(x0, x0_dtype, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, m->vw.ln_pre_g,
                               m->vw.ln_pre_b, f16res ? nullptr : w.xres, folded ? w.xn : nullptr, folded ? w.stats : nullptr, batch, L, L0, D, 1e-5f, s)))
       return rc;

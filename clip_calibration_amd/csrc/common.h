@@ -133,7 +133,8 @@ struct Options {
                                              // (identical features; not the default: the headline benchmark computes every row)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
-  std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
+  std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 3 = the block's in-projection FUSED into the attention kernel
+                                       // (qkv_attention_kernel: q | k | v never reach memory; tower blocks only); 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
                                        // from a loader wave, fragment reads pinned by inline asm, output rows stored non-temporal); 1 = the same with plain
                                        // stores; 0 = persistent kernel (all three: same bits)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
@@ -212,12 +213,17 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
 // n*L + first + j, j < n_ctx.  M = N*L is the partial stride.
 int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
+// in-projection (optionally with the LayerNorm fold: stats != nullptr) + attention of one block in one launch, q | k | v never leave the CU
+bool qkv_attention_fits(int L, int D, int parts);
+int launch_qkv_attention(const half_t* x16, const half_t* W, const float* g, const float* c, const float* stats, int parts, half_t* out, int N, int L,
+                         int H, float eps, int nt_stores, hipStream_t s);
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
-// patch_embed.hip: conv1 as a GEMM that reads the NCHW image directly (+ pos, token-row scatter) and ln_pre over every token row with the
+// patch_embed.hip: conv1 as a GEMM whose loader reads the (fp16) NCHW image directly (+ pos, token-row scatter) and ln_pre over every token row with the
 // class / shallow-prompt rows formed on the fly   (clip/model.py:394-402,413)
-bool patch_embed_fits(int B, int R, int P, int D, int image_dtype);
-int launch_patch_embed(const void* image, int image_dtype, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B,
-                       int R, int P, int D, int tokens, hipStream_t s);
+bool patch_embed_fits(int B, int R, int P, int D);
+size_t patch_embed_scratch_bytes(int B, int R, int image_dtype);   // fp16 copy of an fp32 image batch (0 for an fp16 image)
+int launch_patch_embed(const void* image, int image_dtype, void* scratch, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
+                       int B, int R, int P, int D, int tokens, hipStream_t s);
 int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
                     float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s);
 // x0[b, 0, :] = cls + pos[0]; x0[b, tokens0 + j, :] = shallow[j] (MaPLe)     (clip/model.py:398-402,459-460)

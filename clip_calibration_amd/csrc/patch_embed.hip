@@ -1,25 +1,30 @@
-// Patch embedding of the image tower as ONE GEMM that reads the image itself, and ln_pre as one row pass  (reference clip/model.py:394-402:
+// Patch embedding of the image tower as a GEMM that reads the image itself, and ln_pre as one row pass  (reference clip/model.py:394-402:
 // conv1 -> reshape -> permute -> cat(class_embedding) -> + positional_embedding; :413 ln_pre; :597-598 the dtype cast of encode_image).
 //
+//   cast_image_kernel    fp32 NCHW pixels -> fp16 NCHW pixels (image.type(self.dtype), clip/model.py:598); skipped for an fp16 image
 //   patch_embed_kernel   x0[b, 1 + p, :] = patch(b, p) @ conv_w^T + pos[1 + p]          (MFMA GEMM, M = B * G * G patches, N = width, K = 3 P^2)
 //   embed_ln_kernel      x[b, l, :] = ln_pre(l == 0 ? cls + pos[0] : l < 1 + G^2 ? x0[b, l] : shallow[l - 1 - G^2])   -> the residual stream
 //
 // conv1 has stride = kernel = P, so its im2col matrix is a pure ADDRESS MAP of the NCHW image: column k = c P^2 + ky P + kx of patch
-// (b, py, px) is pixel (b, c, py P + ky, px P + kx).  With P % 8 == 0 every 8-element K chunk (one 16-byte LDS slot) is 8 consecutive
-// pixels of one image row, and the 4 (P = 16) row segments of a 64-deep K-step of the 8 patches a wave-instruction covers are four
-// contiguous 512-byte runs of the image.  The activation operand is therefore staged THROUGH REGISTERS -- two 16-byte loads of fp32 pixels,
-// four v_cvt_pk_f16_f32, one ds_write_b128 into the same XOR-swizzled LDS image the LDS-DMA kernels use -- which is where the fp32 -> fp16
-// cast of encode_image happens; an fp16 image takes the same path without the conversion.  The weight operand arrives by LDS-DMA as in
-// gemm.hip.  No im2col matrix (77 MB written and read back at batch 256), no patchify launch, no fp32 embedding buffer: the epilogue adds
-// the positional embedding in fp32 and stores the token rows -- in fp16 when the residual stream is fp16 (the reference's own GPU path
-// holds the conv output, the class token and the positional sum in fp16: clip/model.py:395-401 on a convert_weights model), in fp32
-// when the stream is fp32.  The class row and MaPLe's shallow prompt rows are the same for every image and never pass through memory:
-// embed_ln_kernel forms them on the fly.  embed_ln_kernel is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same
-// butterfly) with those three row sources and the outputs the blocks want: fp32 stream and / or fp16 operand copy + the LayerNorm-fold
-// row sums of the output.
+// (b, py, px) is pixel (b, c, py P + ky, px P + kx).  With P in {8, 16, 32} every 16-byte LDS slot of the activation operand (8 consecutive
+// k) is 8 consecutive fp16 pixels of one image row, and a 64-deep K-step is 64 / P whole row segments of one channel: the operand is staged by
+// LDS-DMA (buffer_load ... lds) exactly like a dense GEMM's, with the per-lane source offset = patch origin + (ky, kx) of the slot and the
+// scalar offset = (channel, first ky) of the K-step.  No im2col matrix is written or read (77 MB each way at batch 256) and the GEMM's
+// loader moves the same bytes the im2col GEMM's did.  The epilogue adds the positional embedding in fp32 and stores the token rows -- in
+// fp16 through a wave-private LDS transpose (16 B per lane, 128 contiguous bytes per row) when the residual stream is fp16 (the reference's
+// own GPU path holds the conv output, the class token and the positional sum in fp16: clip/model.py:395-401 on a convert_weights model), in
+// fp32 when the stream is fp32.  The class row and MaPLe's shallow prompt rows are the same for every image and never pass through memory:
+// embed_ln_kernel forms them on the fly; it is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same butterfly) with those
+// three row sources and the outputs the blocks want (fp32 stream and / or fp16 operand copy + the LayerNorm-fold row sums of the output).
 //
-// Algorithmic bytes per image (ViT-B/16, fp32 input): 602 KB of pixels read (x the n-tiles that miss L2), 302 KB of fp16 rows written;
-// ln_pre: 302 KB read, 302 KB written.  Before: patchify 602 + 301 KB, GEMM 301 KB + 605 KB of fp32 rows, cls rows, ln_pre 605 + 302 KB.
+// Why the cast is its own pass (profiles/r04_patch_embed.txt): the first form of this kernel staged fp32 pixels THROUGH REGISTERS (two
+// 16-byte loads, four v_cvt_pk_f16_f32, one ds_write_b128 per slot) -- correct, and 140 us at batch 256: with 128 accumulator registers
+// per lane a wave can hold one K-step of pixels in flight, 1 us of MFMAs to cover a load that takes ~3 us when every CU pulls 64 KB of
+// fp32 per K-step through its L1, three times over (one per n-tile).  A 231 MB streaming cast (38 us) in front of an all-DMA GEMM is faster.
+//
+// Algorithmic bytes per image (ViT-B/16, fp32 input): cast 602 KB in + 301 KB out; GEMM 301 KB of pixels (x the n-tiles that miss L2) in,
+// 302 KB of fp16 rows out; ln_pre 302 KB in, 302 KB out.  Before: patchify 602 + 301 KB, GEMM 301 KB + 605 KB of fp32 rows, class rows,
+// ln_pre 605 + 302 KB.
 #include "gemm_common.h"
 
 namespace clipmi {
@@ -28,7 +33,7 @@ namespace {
 using namespace gemm;
 
 struct PEArgs {
-  const void* image;           // [B, 3, R, R] fp32 or fp16
+  const half_t* image;         // [B, 3, R, R] fp16 (the caller's, or cast_image_kernel's output)
   const half_t* W; int64_t ldw;   // conv1.weight packed [N, K], K index c P^2 + ky P + kx
   const float* pos;            // [tokens0, N]
   void* out; int64_t ldo;      // token rows [B * tokens, N], fp16 or fp32
@@ -43,29 +48,18 @@ constexpr int PE_SMEM = 2 * PE_STAGE;
 constexpr int PE_XI = PE_BM * 8 / PE_NT;   // 16-byte activation chunks per thread and stage (4)
 constexpr int PE_WI = PE_BN * 8 / PE_NT;   // LDS-DMA pieces per wave and stage (4)
 
-template <typename TI> struct PixelChunk;   // 8 consecutive pixels -> one f16x8 LDS slot
-template <> struct PixelChunk<float> {
-  f32x4 lo, hi;
-  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rs, int voff) {
-    lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
-    hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 0));
-  }
-  __device__ __forceinline__ f16x8 pack() const {
-    return f16x8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
-  }
-};
-template <> struct PixelChunk<half_t> {
-  f16x8 v;
-  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rs, int voff) {
-    v = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
-  }
-  __device__ __forceinline__ f16x8 pack() const { return v; }
-};
+// fp32 -> fp16 pixels, 8 per thread (two 16-byte loads, one 16-byte store)
+__global__ __launch_bounds__(256) void cast_image_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(src + i * 8), hi = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+  *reinterpret_cast<f16x8*>(dst + i * 8) =
+      f16x8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
+}
 
-// 256 x 256 tile, eight waves of 128(m) x 64(n) (two per SIMD), two LDS stages.  Per K-step: the barrier that hands over stage kt, then
-// the pixel loads of stage kt + 1 go out (registers) and its weight pieces (LDS-DMA), then the 64 MFMAs of stage kt, then the pixels are
-// converted and written to the other stage buffer -- whose last reader passed this K-step's barrier.
-template <typename TI, typename TO>
+// 256 x 256 tile, eight waves of 128(m) x 64(n) (two per SIMD), two LDS stages, both operands by LDS-DMA: per K-step the barrier that hands
+// over stage kt, the DMA of stage kt + 1 into the other buffer, the 64 MFMAs of stage kt (gemm.hip gemm_f16_kernel's loop).
+template <typename TO>
 __global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
   constexpr int TM = 8, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,46 +86,37 @@ __global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
   }
   const int m0 = tile_m * PE_BM, n0 = tile_n * PE_BN;
 
-  // ---- activation staging: thread t, chunk i covers patch row i * 64 + (t >> 3) of the tile, LDS slot (t & 7) of that row, which holds
-  //      data chunk (t & 7) ^ ((row >> 1) & 7) -- the same for all four rows of a thread (rows differ by 64)
+  // ---- activation staging: thread t, piece i covers patch row i * 64 + (t >> 3) of the tile, LDS slot (t & 7) of that row, which holds
+  //      data chunk j = (t & 7) ^ ((row >> 1) & 7) -- the same for all four rows of a thread (rows differ by 64).  Chunk j of a K-step is
+  //      row segment ky_l = j / (P / 8) of the step, pixels kx0 = (j % (P / 8)) * 8 .. + 7.
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  const int isz = (int)sizeof(TI);
-  const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.image, (int64_t)(a.M / a.GG) * 3 * a.R * a.R * isz);
-  int prow[PE_XI];   // byte offset of pixel (b, 0, py P, px P) of the thread's patches; rows past M point past the descriptor (read as 0)
+  const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.image, (int64_t)(a.M / a.GG) * 3 * a.R * a.R * 2);
+  const int cps = a.P >> 3;                                   // 16-byte chunks per row segment
+  const int lane_k = ((schunk / cps) * a.R + (schunk % cps) * 8) * 2;
+  int xoff[PE_XI];   // byte offset of the lane's 8 pixels for K-step 0; rows past M point past the descriptor (read as zero)
 #pragma unroll
   for (int i = 0; i < PE_XI; ++i) {
     const int m = m0 + i * (PE_NT / 8) + srow;
     const int b = m / a.GG, p = m - b * a.GG;
     const int py = p / a.G, px = p - py * a.G;
-    prow[i] = m < a.M ? (((b * 3) * a.R + py * a.P) * a.R + px * a.P) * isz : (int)0xFFFFFF00;
+    xoff[i] = m < a.M ? (((b * 3) * a.R + py * a.P) * a.R + px * a.P) * 2 + lane_k : (int)0xFFFFFF00;
   }
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
   int woff[PE_WI];
 #pragma unroll
   for (int i = 0; i < PE_WI; ++i) woff[i] = ((i * (PE_NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
   const int lds_wave_off = wave * 1024;
-  const int PP = a.P * a.P;
-
-  PixelChunk<TI> px[PE_XI];
-  auto load_pixels = [&](int kt) {   // k0 = kt * 64 + schunk * 8 -> (c, ky, kx): one division pair per thread and K-step
-    const int k0 = kt * BK + schunk * 8;
-    const int c = k0 / PP, rem = k0 - c * PP;
-    const int ky = rem / a.P, kx = rem - ky * a.P;
-    const int koff = ((c * a.R + ky) * a.R + kx) * isz;
+  const int spc = (a.P * a.P) >> 6, rps = 64 / a.P;           // K-steps per channel, image rows per K-step
+  auto stage = [&](int buf, int kt) {
+    char* xs = smem + buf * PE_STAGE + lds_wave_off;
+    const int c = kt / spc, ky0 = (kt - c * spc) * rps;        // scalar
+    const int soff = ((c * a.R + ky0) * a.R) * 2;
 #pragma unroll
-    for (int i = 0; i < PE_XI; ++i) px[i].load(irs, prow[i] < 0 ? prow[i] : prow[i] + koff);
-  };
-  auto write_pixels = [&](int buf) {
-    char* xs = smem + buf * PE_STAGE + tid * 16;
-#pragma unroll
-    for (int i = 0; i < PE_XI; ++i) *reinterpret_cast<f16x8*>(xs + i * (PE_NT * 16)) = px[i].pack();
-  };
-  auto stage_w = [&](int buf, int kt) {
-    char* ws = smem + buf * PE_STAGE + PE_XBYTES + lds_wave_off;
+    for (int i = 0; i < PE_XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(irs, xs + i * (PE_NT * 16), xoff[i], soff);
     const int k0 = kt * BK * 2;
 #pragma unroll
-    for (int i = 0; i < PE_WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (PE_NT * 16), woff[i], k0);
+    for (int i = 0; i < PE_WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + PE_XBYTES + i * (PE_NT * 16), woff[i], k0);
   };
 
   const int r16 = lane & 15, g4 = lane >> 4;
@@ -149,18 +134,11 @@ __global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = a.K / BK;
-  load_pixels(0);
-  stage_w(0, 0);
-  write_pixels(0);
+  stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's weight pieces have landed, its pixel slots are written
-    __syncthreads();                                               // ... and everybody's; the other buffer's readers are done
-    const bool more = kt + 1 < nk;
-    if (more) {
-      load_pixels(kt + 1);
-      stage_w((kt + 1) & 1, kt + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the loads go out in front of the MFMAs, not where their results are first used
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // stage kt landed for every wave; everyone finished reading the other buffer
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
     const char* st = smem + (kt & 1) * PE_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -176,8 +154,6 @@ __global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
         for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) write_pixels((kt + 1) & 1);
   }
 
   // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m 128 + 16 j + r16][n = n0 + wave_n 64 + 16 i + 4 g4 + e]; + pos, token-row scatter
@@ -317,10 +293,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TI* __restrict__ x0
   }
 }
 
-template <typename TI, typename TO>
+template <typename TO>
 int launch_pe(const PEArgs& a, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = patch_embed_kernel<TI, TO>;
+  auto fn = patch_embed_kernel<TO>;
   ensure_dynamic_lds(fn, PE_SMEM, attr_once);
   hipLaunchKernelGGL(fn, dim3(a.nwg), dim3(PE_NT), PE_SMEM, s, a);
   return check_launch("patch_embed_kernel");
@@ -328,28 +304,38 @@ int launch_pe(const PEArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool patch_embed_fits(int B, int R, int P, int D, int image_dtype) {
-  const int64_t image_bytes = (int64_t)B * 3 * R * R * (image_dtype == CLIPMI_F16 ? 2 : 4);
-  return P > 0 && P % 8 == 0 && R % P == 0 && D % 8 == 0 && image_bytes < 0x7FFFFF00ll && (3 * P * P) % BK == 0 &&
-         (int64_t)3 * P * P < (1ll << 31) / (2 * 257);
+bool patch_embed_fits(int B, int R, int P, int D) {
+  const int64_t image_bytes = (int64_t)B * 3 * R * R * 2;   // as fp16
+  return (P == 8 || P == 16 || P == 32) && R % P == 0 && D % 8 == 0 && image_bytes < 0x7FFFFF00ll;
 }
 
-int launch_patch_embed(const void* image, int image_dtype, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype, int B,
-                       int R, int P, int D, int tokens, hipStream_t s) {
+size_t patch_embed_scratch_bytes(int B, int R, int image_dtype) { return image_dtype == CLIPMI_F32 ? align256((size_t)B * 3 * R * R * 2) : 0; }
+
+int launch_patch_embed(const void* image, int image_dtype, void* scratch, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
+                       int B, int R, int P, int D, int tokens, hipStream_t s) {
   if (B == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(image && conv_w && pos && x0, CLIPMI_ERR_ARG, "patch_embed: null pointer");
+  CLIPMI_REQUIRE(image_dtype != CLIPMI_F32 || (scratch && (uintptr_t)scratch % 16 == 0), CLIPMI_ERR_ARG,
+                 "patch_embed: an fp32 image needs a 16-byte aligned scratch buffer of patch_embed_scratch_bytes for its fp16 copy");
   CLIPMI_REQUIRE(image_dtype == CLIPMI_F16 || image_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "patch_embed: image dtype %d", image_dtype);
   CLIPMI_REQUIRE(x0_dtype == CLIPMI_F16 || x0_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "patch_embed: output dtype %d", x0_dtype);
-  CLIPMI_REQUIRE(patch_embed_fits(B, R, P, D, image_dtype), CLIPMI_ERR_SHAPE,
-                 "patch_embed: needs P %% 8 == 0, R %% P == 0, width %% 8 == 0 and an image batch below 2 GB (B=%d R=%d P=%d D=%d)", B, R, P, D);
+  CLIPMI_REQUIRE(patch_embed_fits(B, R, P, D), CLIPMI_ERR_SHAPE,
+                 "patch_embed: needs P in {8, 16, 32}, R %% P == 0, width %% 8 == 0 and an fp16 image batch below 2 GB (B=%d R=%d P=%d D=%d)", B, R, P, D);
   CLIPMI_REQUIRE((uintptr_t)image % 16 == 0 && (uintptr_t)conv_w % 16 == 0 && (uintptr_t)pos % 16 == 0 && (uintptr_t)x0 % 16 == 0,
                  CLIPMI_ERR_ARG, "patch_embed: pointers must be 16-byte aligned");
-  CLIPMI_REQUIRE((R * (image_dtype == CLIPMI_F16 ? 2 : 4)) % 16 == 0 && ldw % 8 == 0 && ldw >= 3 * P * P, CLIPMI_ERR_SHAPE,
-                 "patch_embed: image rows and weight rows must keep 16-byte alignment");
+  CLIPMI_REQUIRE(ldw % 8 == 0 && ldw >= 3 * P * P, CLIPMI_ERR_SHAPE, "patch_embed: weight rows must keep 16-byte alignment");
   const int G = R / P;
   CLIPMI_REQUIRE(tokens >= G * G + 1, CLIPMI_ERR_SHAPE, "patch_embed: tokens=%d < 1 + %d patches", tokens, G * G);
+  const half_t* image16 = static_cast<const half_t*>(image);
+  if (image_dtype == CLIPMI_F32) {
+    const int64_t n8 = (int64_t)B * 3 * R * R / 8;   // R % 8 == 0
+    hipLaunchKernelGGL(cast_image_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(image), static_cast<half_t*>(scratch), n8);
+    const int rc = check_launch("cast_image_kernel");
+    if (rc) return rc;
+    image16 = static_cast<const half_t*>(scratch);
+  }
   PEArgs a;
-  a.image = image; a.W = conv_w; a.ldw = ldw; a.pos = pos; a.out = x0; a.ldo = D;
+  a.image = image16; a.W = conv_w; a.ldw = ldw; a.pos = pos; a.out = x0; a.ldo = D;
   a.M = B * G * G; a.N = D; a.K = 3 * P * P; a.R = R; a.P = P; a.G = G; a.GG = G * G; a.tokens = tokens;
   const int tiles_m = (a.M + PE_BM - 1) / PE_BM;
   a.tiles_n = (a.N + PE_BN - 1) / PE_BN;
@@ -357,11 +343,7 @@ int launch_patch_embed(const void* image, int image_dtype, const half_t* conv_w,
   const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "patch_embed: grid too large");
   a.nwg = (int)nwg;
-  const bool i32 = image_dtype == CLIPMI_F32, o32 = x0_dtype == CLIPMI_F32;
-  if (i32 && o32) return launch_pe<float, float>(a, s);
-  if (i32) return launch_pe<float, half_t>(a, s);
-  if (o32) return launch_pe<half_t, float>(a, s);
-  return launch_pe<half_t, half_t>(a, s);
+  return x0_dtype == CLIPMI_F32 ? launch_pe<float>(a, s) : launch_pe<half_t>(a, s);
 }
 
 int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
