@@ -76,7 +76,6 @@ _SIGNATURES = {
     "clipmi_gemm_residual_f16": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, C.POINTER(_i), _i, _i, _i, _vp]),
     "clipmi_layernorm": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp]),
     "clipmi_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "clipmi_qkv_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp]),
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_patch_embed_scratch_bytes": (_sz, [_i, _i, _i]),
     "clipmi_patch_embed": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -153,8 +153,7 @@ __device__ __forceinline__ void attend_block(const char* const (&kread)[4], cons
 // row-sum MFMAs, 4 no S MFMAs, 8 query waves 4-6 idle (one query wave per SIMD), 16 no row-sum MFMA,
 // 32 no max phase, 64 no LDS fragment reads, 128 operands read as if every (sequence, head) held K | V | Q contiguously (what a head-major
 // in-projection output would give the loader), 256 no output stores,
-// 512 operand DMA marked non-temporal, 1024 output stores non-temporal, 2048 output stores write-through (sc0 sc1);
-// qkv_attention_kernel: 4096 no LDS-DMA inside the K loop, 8192 no MFMAs inside the K loop, 16384 no fragment reads inside the K loop
+// 512 operand DMA marked non-temporal, 1024 output stores non-temporal, 2048 output stores write-through (sc0 sc1)
 #ifndef CLIPMI_ATTN_ABLATE
 #define CLIPMI_ATTN_ABLATE 0
 #endif
@@ -715,343 +714,9 @@ int launch_vision(const half_t* qkv, half_t* out, int N, int L, int H, hipStream
   return check_launch("attention_vision_kernel");
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// In-projection FUSED into the vision attention kernel (round 4; reference clip/model.py:181-186: ln_1 -> in_proj -> attention): a
-// persistent workgroup per (image, head) item computes the head's q | k | v itself -- [197 -> 208 token rows] x [192 = q | k | v columns
-// of head h] x K = width, from the LayerNorm-folded fp16 operand copy of the residual stream and the folded weights, with the fold
-// epilogue rstd * acc - rstd * mean * g + c of gemm.hip -- writes them as fp16 into the SAME swizzled LDS image [K | V | Q] x 200 rows x
-// 128 B that attention_vision_kernel's loader wave fills by DMA, and runs that kernel's query-wave code (attend_dense_pf,
-// store_out_lines) on it.  The 232 MB of q | k | v per layer at batch 256 are never written to memory and never read back.
-//
-// Per item:   GEMM phase (all 8 waves; two-stage LDS ring of (208 + 192) rows x 64 k = 51,200 B stages, W = MFMA A operand, x = B operand,
-//             waves 0-3 the token blocks 0..6, waves 4-7 blocks 7..12, three 16-column blocks each: 84 accumulator registers)
-//             -> epilogue into the image (it aliases stage buffers 0 and 1: their last reads are a barrier behind)
-//             -> attention phase: waves 0-6 one 32-query tile each; wave 7 meanwhile is the LOADER of the next item -- its first stage
-//                (50 LDS-DMA pieces into stage buffer 2), its LayerNorm row parameters (reduced from the producer's row partials) and its
-//                column parameters (c, g) into small LDS tables -- so that no wave ever waits for memory at the start of an item.
-// Items are dealt so that the 12 heads of an image run on ONE XCD (blockIdx % 8 labels the XCD): the image's 300 KB row panel and the
-// 3.5 MB of folded weights are served by that XCD's L2.
-// LDS: 3 x 51,200 (stages) + 2 x 208 x 8 (row parameters) + 2 x 192 x 8 (column parameters) = 160,000 B.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int QA_ROWS = 208, QA_COLS = 192;
-constexpr int QA_MAX_PARTS = 4;   // row partials per row the loader wave reduces (producers of up to 1024 columns)
-constexpr int QA_XB = QA_ROWS * 128, QA_WB = QA_COLS * 128, QA_STAGE = QA_XB + QA_WB;   // 26,624 + 24,576
-constexpr int QA_XP = QA_ROWS / 8, QA_WP = QA_COLS / 8;   // 1 KiB DMA pieces per stage: 26 + 24
-constexpr int QA_ROWPAR = 3 * QA_STAGE, QA_COLPAR = QA_ROWPAR + 2 * QA_ROWS * 8;
-constexpr int QA_SMEM = QA_COLPAR + 2 * QA_COLS * 8;
-static_assert(3 * VARR + 24 * 128 <= 2 * QA_STAGE && QA_SMEM <= 160 * 1024, "the attention image must fit stage buffers 0 and 1");
-
-struct QAArgs {
-  const half_t* x16;      // [N * L, D] fp16: the LayerNorm-fold operand copy of the residual stream (or ln_1's output when stats == nullptr)
-  const half_t* W;        // [3 D, D] fp16: gamma-folded in_proj_weight (or in_proj_weight itself)
-  const float* g;         // [3 D] column sums of the folded weights (unused when stats == nullptr)
-  const float* c;         // [3 D] W beta + b (or in_proj_bias)
-  const float* stats;     // [parts][M][2] row partials (sum, sum of squares) of the stream, or nullptr: no fold
-  half_t* out;            // [N * L, D]
-  int parts, N, L, H, D, M;
-  float inv_d, eps;
-#ifdef CLIPMI_TUNING
-  long long* stamps;   // diagnostic build: [workgroup][round][8] s_memrealtime stamps of wave 0 and wave 7 (tools/fusion_stamps.py)
-#endif
-};
-
-template <bool NT>
-__global__ __launch_bounds__(512, 2) void qkv_attention_kernel(const QAArgs a) {
-  constexpr int NKT = 7, GROUP = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int r32 = lane & 31, hh = lane >> 5;
-  const int wave_m = wave >> 2, wave_n = wave & 3;
-  const int mb0 = wave_m ? 7 : 0;                       // first 16-row token block of this wave (waves 4-7: blocks 7..12, six of them)
-  const int D = a.D, L = a.L, H = a.H;
-  const int nk = D / 64;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-  // ---- items: XCD label x = blockIdx % 8 works on the images n = x, x + 8, ...; slot = blockIdx / 8; the XCD's s-th item is
-  //      (image x + 8 (s / H), head s % H), s = slot, slot + slots, ...
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  auto item_of = [&](int s, int& n, int& h) {
-    const int q = s / H;
-    n = xcd + 8 * q;
-    h = s - q * H;
-    return n < a.N;
-  };
-
-  // ---- the loader's work for one item (wave 7 during the previous item's attention phase; in the prologue for the first item)
-  auto load_item = [&](int n, int h, int par, bool with_dma) {
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x16 + (int64_t)n * L * D, (int64_t)L * D * 2);             // rows >= L read as zero
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)h * 64 * D, ((int64_t)(3 * D - h * 64) * D) * 2);
-    const int lr = lane >> 3, cs = lane & 7;
-    char* st = smem + 2 * QA_STAGE;                     // stage buffer 2 always receives an item's first stage
-    if (with_dma) {   // (the K loop of the previous item issues these itself when its tail leaves buffer 2 free: see `pre_kt`)
-#pragma unroll 2
-      for (int p = 0; p < QA_XP; ++p) {
-        const int row = p * 8 + lr;
-        CLIPMI_BUFFER_LOAD_LDS16(xrs, st + p * 1024, (row * D + ((cs ^ ((row >> 1) & 7)) << 3)) * 2, 0);
-      }
-#pragma unroll 2
-      for (int p = 0; p < QA_WP; ++p) {
-        const int j = p * 8 + lr;
-        CLIPMI_BUFFER_LOAD_LDS16(wrs, st + QA_XB + p * 1024, ((((j >> 6) * D + (j & 63)) * D) + ((cs ^ ((j >> 1) & 7)) << 3)) * 2, 0);
-      }
-    }
-    float2* rowp = reinterpret_cast<float2*>(smem + QA_ROWPAR) + par * QA_ROWS;
-    float2* colp = reinterpret_cast<float2*>(smem + QA_COLPAR) + par * QA_COLS;
-    // every load of the tables goes out before the first result is used (fully unrolled: one memory round trip, not one per row)
-    constexpr int RPL = (QA_ROWS + 63) / 64, CPL = QA_COLS / 64;
-    float2 sp[RPL][QA_MAX_PARTS];
-    float cc[CPL], gg[CPL];
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const int t = lane + 64 * i;
-#pragma unroll
-      for (int pp = 0; pp < QA_MAX_PARTS; ++pp) {
-        sp[i][pp] = make_float2(0.f, 0.f);
-        if (a.stats && t < L && pp < a.parts) sp[i][pp] = *reinterpret_cast<const float2*>(a.stats + 2 * ((int64_t)pp * a.M + (int64_t)n * L + t));
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      const int col = i * D + h * 64 + lane;   // t = lane + 64 i: segment i (q, k, v), column lane of the head
-      cc[i] = a.c[col];
-      gg[i] = a.stats ? a.g[col] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) {
-      const int t = lane + 64 * i;
-      float rs = 1.f, mrs = 0.f;
-      if (a.stats && t < L) {   // the arithmetic of gemm.hip ln_row_params / ln_params_from_sums (explicit fused multiply-adds: same bits)
-        double sm = 0.0, ss = 0.0;
-#pragma unroll
-        for (int pp = 0; pp < QA_MAX_PARTS; ++pp) {
-          if (pp < a.parts) {
-            sm += (double)sp[i][pp].x;
-            ss += (double)sp[i][pp].y;
-          }
-        }
-        const double mean = sm * (double)a.inv_d;
-        double var = __builtin_fma(ss, (double)a.inv_d, -(mean * mean));
-        var = var > 0.0 ? var : 0.0;
-        rs = rsqrtf((float)var + a.eps);
-        mrs = (float)mean * rs;
-      }
-      if (t < QA_ROWS) rowp[t] = make_float2(rs, mrs);
-    }
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) colp[lane + 64 * i] = make_float2(cc[i], gg[i]);
-  };
-
-  int s_idx = slot, n = 0, h = 0, n2, h2;
-  bool has_next = item_of(s_idx, n2, h2);   // the "next" item of the empty first round is the first item
-  if (!has_next) return;                    // (whole workgroup: uniform)
-
-  // ---- GEMM phase addresses (lane constants)
-  // this wave's DMA pieces of a K-step: X pieces px = wave + 8 i (i < 4; the fourth only for waves 0 and 1: 26 pieces), W pieces pw = wave + 8 i
-  // (i < 3: 24 pieces) -- byte offset of the lane's 16 bytes inside the operand
-  int xvoff[4], wvoff[3];
-  {
-    const int lr = lane >> 3, cs = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave + 8 * i) * 8 + lr;
-      xvoff[i] = (row * D + ((cs ^ ((row >> 1) & 7)) << 3)) * 2;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int j = (wave + 8 * i) * 8 + lr;
-      wvoff[i] = ((((j >> 6) * D + (j & 63)) * D) + ((cs ^ ((j >> 1) & 7)) << 3)) * 2;
-    }
-  }
-  const int swz = (r16 >> 1) & 7;
-  const int foff0 = r16 * 128 + (((0 + g4) ^ swz) << 4), foff1 = r16 * 128 + (((4 + g4) ^ swz) << 4);
-  const int xfb = mb0 * 2048, wfb = QA_XB + wave_n * 3 * 2048;
-  // attention-phase addresses (attention_vision_body's)
-  const int q0 = wave * 32;
-  const int kswz = (r32 >> 1) & 7;
-  uint32_t ka[4], va[2], qa[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    ka[ks] = lds_base + (uint32_t)(r32 * 128 + (((2 * ks + hh) ^ kswz) << 4));
-    qa[ks] = lds_base + (uint32_t)(2 * VARR + (q0 + r32) * 128 + (((2 * ks + hh) ^ kswz) << 4));
-  }
-  {
-    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
-    const int fq = (qq >> 1) & 1;
-    const int lane_base = VARR + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
-    va[0] = lds_base + (uint32_t)(lane_base + fq * 64);
-    va[1] = lds_base + (uint32_t)(lane_base + (1 - fq) * 64);
-  }
-
-  // One round = [attention phase of the current item on waves 0-6 || wave 7 loads the next item] -> barrier -> [GEMM phase + epilogue of that
-  // next item, now current].  The first round has no current item: only the loader works (ONE call site of load_item).
-  // the K-step whose DMA slot is free for the next item's first stage: the one after the last reader of buffer 2 (K-steps kt = 0 mod 3),
-  // if the item still has a step left there and nothing of its own to fetch (kt + 2 >= nk); otherwise the loader wave issues it
-  const int last2 = ((nk - 1) / 3) * 3;
-  const int pre_kt = last2 + 1 >= nk - 2 ? last2 + 1 : nk - 2;
-  const bool dma_in_loop = pre_kt < nk - 1;   // (it must land before the loop's final vmcnt(0) ... barrier, one step later)
-  int par = 1;
-  bool have_cur = false;
-#ifdef CLIPMI_TUNING
-  int round_ = 0;
-#define QA_STAMP(slot) do { if (a.stamps && lane == 0 && (wave == 0 || wave == 7) && round_ < 16) \
-    a.stamps[((size_t)blockIdx.x * 16 + round_) * 16 + (wave ? 8 : 0) + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define QA_STAMP(slot) do { } while (0)
-#endif
-  while (true) {
-    QA_STAMP(0);   // round start: attention phase (waves 0-6) / loader (wave 7)
-    if (have_cur && wave < 7) {
-      f32x16 oacc[2];
-      f32x16 lacc;
-      attend_dense_pf<NKT, GROUP>(ka, va, qa, L, hh, oacc, lacc);
-      const int nrows = L - q0 < 32 ? L - q0 : 32;
-      store_out_lines<NT>(a.out + ((int64_t)n * L + q0) * D + h * 64, D, lds_base + (uint32_t)(2 * VARR + q0 * 128), oacc, lacc[0], lane, nrows);
-    } else if (wave == 7 && has_next) {
-      load_item(n2, h2, par ^ 1, !have_cur || !dma_in_loop);
-    }
-    QA_STAMP(1);   // this wave's attention / loader work issued
-    if (!has_next) break;
-    // the loader's DMA and tables have landed; the query waves' staging reads are done (their output stores need no wait: a raw barrier)
-    if (wave == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    QA_STAMP(2);   // ... and complete
-    __builtin_amdgcn_s_barrier();
-    QA_STAMP(3);   // GEMM phase starts
-    n = n2; h = h2; par ^= 1; have_cur = true;
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x16 + (int64_t)n * L * D, (int64_t)L * D * 2);
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)h * 64 * D, ((int64_t)(3 * D - h * 64) * D) * 2);
-    // the item after this one (uniform): its first stage is DMA'd by this K loop's tail when buffer 2 is free by then
-    s_idx += slots;
-    has_next = item_of(s_idx, n2, h2);
-    const __amdgpu_buffer_rsrc_t xrs2 = make_rsrc(a.x16 + (int64_t)n2 * L * D, (int64_t)L * D * 2);
-    const __amdgpu_buffer_rsrc_t wrs2 = make_rsrc(a.W + (int64_t)h2 * 64 * D, ((int64_t)(3 * D - h2 * 64) * D) * 2);
-    auto stage = [&](const __amdgpu_buffer_rsrc_t& xr, const __amdgpu_buffer_rsrc_t& wr, int buf, int kt) {
-      if constexpr (CLIPMI_ATTN_ABLATE & 4096) return;
-      char* st = smem + buf * QA_STAGE;   // (wave-uniform LDS base: the hardware adds lane * 16)
-      const int k0 = kt * 128;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) CLIPMI_BUFFER_LOAD_LDS16(wr, st + QA_XB + (wave + 8 * i) * 1024, wvoff[i], k0);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) CLIPMI_BUFFER_LOAD_LDS16(xr, st + (wave + 8 * i) * 1024, xvoff[i], k0);
-      if (wave < 2) CLIPMI_BUFFER_LOAD_LDS16(xr, st + (wave + 24) * 1024, xvoff[3], k0);   // pieces 24, 25
-    };
-    static_assert(QA_XP == 26 && QA_WP == 24, "piece plan: 3 + 3 per wave and two more");
-    f32x4 acc[3][7];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 7; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // ---- GEMM phase.  Three stage buffers: K-step kt reads buffer (kt + 2) % 3 (the item's first stage was prefetched into buffer 2) and
-    // issues the DMA of K-step kt + 2 into buffer (kt + 1) % 3, whose last reads (K-step kt - 1) are a barrier behind: a stage has a whole
-    // K-step to land, so WHEN a wave issues its pieces inside the step is free -- waves 0-3 issue them before their MFMAs, waves 4-7
-    // (their partners on the SIMDs) after: one wave of a SIMD issues memory instructions while the other issues MFMAs, instead of both
-    // queueing ~700 cycles of DMA issue right behind the barrier with the matrix pipe idle (v1: 13.5 us per 12 K-steps, 7.9 us of MFMAs).
-    // The wait at the end of a step leaves exactly the pieces issued in that step in flight (7 for waves 0 and 1, 6 for the others).
-    auto wait_all_but_this_step = [&](bool issued) {
-      if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    };
-    if (nk > 1) stage(xrs, wrs, 0, 1);   // K-step 1's stage: one step to land (only here)
-    int cur = 2;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int tgt = cur == 0 ? 2 : cur - 1;          // (kt + 1) % 3 when cur = (kt + 2) % 3
-      const bool own = kt + 2 < nk;                    // a stage of this item is left to fetch
-      const bool pre = !own && kt == pre_kt && has_next;   // ... or, once in the tail, the NEXT item's first stage into buffer 2 (tgt == 2 there)
-      if (wave_m == 0) {
-        if (own) stage(xrs, wrs, tgt, kt + 2);
-        else if (pre) stage(xrs2, wrs2, 2, 0);
-      }
-      const char* st = smem + cur * QA_STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int fo = ks ? foff1 : foff0;
-        f16x8 xf[7], wf[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wfb + i * 2048 + fo);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xfb + j * 2048 + fo);
-        if (wave_m == 0) xf[6] = *reinterpret_cast<const f16x8*>(st + xfb + 6 * 2048 + fo);
-        __builtin_amdgcn_s_setprio(1);
-        if constexpr (CLIPMI_ATTN_ABLATE & 8192) {
-          asm volatile("" :: "v"(wf[0]), "v"(wf[1]), "v"(wf[2]), "v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(xf[3]), "v"(xf[4]), "v"(xf[5]));
-          if (wave_m == 0) asm volatile("" :: "v"(xf[6]));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-          if (wave_m == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) acc[i][6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[6], acc[i][6], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_s_setprio(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (wave_m == 1) {
-        if (own) stage(xrs, wrs, tgt, kt + 2);
-        else if (pre) stage(xrs2, wrs2, 2, 0);
-      }
-      // stage kt + 1 (issued a step ago) has landed for this wave; what this step issued may stay in flight -- except at the very end
-      wait_all_but_this_step((own || pre) && kt + 1 < nk);
-      __builtin_amdgcn_s_barrier();
-      cur = cur == 2 ? 0 : cur + 1;   // ring 2 -> 0 -> 1 -> 2
-    }
-    QA_STAMP(4);   // K loop done; its last barrier: every wave is done with the last stage, buffers 0 and 1 become the attention image
-    QA_STAMP(5);
-    // ---- epilogue: q | k | v = rstd * acc - rstd * mean * g + c (gemm.hip's fold epilogue, same fused multiply-adds), fp16, into the image
-    {
-      const float2* rowp = reinterpret_cast<const float2*>(smem + QA_ROWPAR) + par * QA_ROWS;
-      const float2* colp = reinterpret_cast<const float2*>(smem + QA_COLPAR) + par * QA_COLS;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int col = (wave_n * 3 + i) * 16 + g4 * 4;            // 0..191: q | k | v of the head
-        const int seg = col >> 6, within = col & 63;
-        const int arr = seg == 0 ? 2 * VARR : (seg == 1 ? 0 : VARR);   // image order: K | V | Q
-        float2 cp[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cp[e] = colp[col + e];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          if (j == 6 && wave_m) continue;
-          const int m = (mb0 + j) * 16 + r16;
-          const float2 rp = rowp[m];
-          f16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (half_t)__builtin_fmaf(acc[i][j][e], rp.x, __builtin_fmaf(-rp.y, cp[e].y, cp[e].x));
-          const int chunk = within >> 3;
-          const int sw = seg == 2 ? (chunk ^ (((m >> 1) & 1) << 2)) : (chunk ^ ((m >> 1) & 7));
-          if (m < VROWS) *reinterpret_cast<f16x4*>(smem + arr + m * 128 + (sw << 4) + ((within >> 2) & 1) * 8) = v;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    QA_STAMP(6);   // epilogue written
-    __builtin_amdgcn_s_barrier();   // the image is complete (every wave's LDS writes drained)
-#ifdef CLIPMI_TUNING
-    ++round_;
-#endif
-  }
-}
-#undef QA_STAMP
-
-template <bool NT>
-int launch_qkv_attention_t(const QAArgs& a, hipStream_t s) {
-  static DeviceOnce attr_once;
-  auto fn = qkv_attention_kernel<NT>;
-  ensure_dynamic_lds(fn, QA_SMEM, attr_once);
-  const int n_cu = device_cus() & ~7;
-  // one workgroup per CU; slots per XCD label = n_cu / 8; an XCD label works on ceil((N - x) / 8) images x H heads
-  const int per_xcd = ((a.N + 7) / 8) * a.H;
-  int slots = n_cu / 8;
-  if (slots > per_xcd) slots = per_xcd;
-  hipLaunchKernelGGL(fn, dim3(slots * 8), dim3(512), QA_SMEM, s, a);
-  return check_launch("qkv_attention_kernel");
-}
+// (Round 4 built the block's in-projection INTO this kernel -- a persistent workgroup per (image, head) computing q | k | v into this LDS image
+// itself; bit-identical to the two launches, 14-24 % slower than them: the 208 x 192 item GEMM is too small to amortise its barriers and pulls
+// 1.28 x the L2 -> LDS bytes per flop of the 256 x 256 tile.  Record with stamps and ablations: profiles/r04_qkv_attention_fusion.txt.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Streaming variant for sequences longer than one key block (ViT-L/14: 257 tokens, ViT-L/14@336: 577): the key
@@ -1193,28 +858,6 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   }
   // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks, 577 tokens (ViT-L/14@336) with 224-key blocks
   return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
-}
-
-// In-projection + attention of one residual block in ONE launch (vision towers at 193..200 tokens; see qkv_attention_kernel).
-bool qkv_attention_fits(int L, int D, int parts) {   // parts: row partials per row of the LayerNorm fold (0 = no fold)
-  return L > 192 && L <= VROWS && D % 64 == 0 && D >= 128 && D <= 2048 && parts <= QA_MAX_PARTS && (device_cus() & ~7) >= 8;
-}
-
-int launch_qkv_attention(const half_t* x16, const half_t* W, const float* g, const float* c, const float* stats, int parts, half_t* out, int N, int L,
-                         int H, float eps, int nt_stores, hipStream_t s) {
-  if (N == 0) return CLIPMI_OK;
-  CLIPMI_REQUIRE(x16 && W && c && out && (!stats || g), CLIPMI_ERR_ARG, "qkv_attention: null pointer");
-  CLIPMI_REQUIRE(N > 0 && H > 0 && qkv_attention_fits(L, 64 * H, 0), CLIPMI_ERR_SHAPE, "qkv_attention: needs 193..200 tokens and width 128..2048 (N=%d L=%d H=%d)", N, L, H);
-  CLIPMI_REQUIRE(!stats || (parts >= 1 && parts <= QA_MAX_PARTS), CLIPMI_ERR_ARG, "qkv_attention: parts=%d (1..%d)", parts, QA_MAX_PARTS);
-  CLIPMI_REQUIRE((uintptr_t)x16 % 16 == 0 && (uintptr_t)W % 16 == 0 && (uintptr_t)out % 16 == 0, CLIPMI_ERR_ARG, "qkv_attention: unaligned pointer");
-  CLIPMI_REQUIRE((int64_t)N * L < (1ll << 31) / 8, CLIPMI_ERR_SHAPE, "qkv_attention: too many rows");
-  QAArgs a;
-  a.x16 = x16; a.W = W; a.g = g; a.c = c; a.stats = stats; a.out = out; a.parts = parts; a.N = N; a.L = L; a.H = H; a.D = 64 * H; a.M = N * L;
-  a.inv_d = 1.0f / (float)(64 * H); a.eps = eps;
-#ifdef CLIPMI_TUNING
-  a.stamps = g_tuning_stamps.load(std::memory_order_relaxed);
-#endif
-  return nt_stores ? launch_qkv_attention_t<true>(a, s) : launch_qkv_attention_t<false>(a, s);
 }
 
 }  // namespace clipmi

@@ -197,18 +197,8 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
   const int64_t Mfull = (int64_t)n_seq * L;
   int rc;
   GemmArgs a{};
-  // option attn_loader = 3: steps 0 and 1 are ONE launch (in-projection fused into the vision attention kernel); step 1 is then empty
-  const bool fused_qkv = !causal && !cls_only && options().attn_loader.load(std::memory_order_relaxed) == 3 &&
-                         qkv_attention_fits(L, D, folded ? *parts : 0);   // (*parts is what step 4 of the previous block left: the same for steps 0 and 1)
   switch (step) {
     case 0:
-      if (fused_qkv) {
-        if (!folded) {
-          if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
-          return launch_qkv_attention(w.xn, (const half_t*)b.w_qkv, nullptr, b.b_qkv, nullptr, 0, w.att, n_seq, L, H, 1e-5f, 1, s);
-        }
-        return launch_qkv_attention(w.xn, (const half_t*)b.w_qkv_f, b.g_qkv, b.c_qkv, w.stats, *parts, w.att, n_seq, L, H, 1e-5f, 1, s);
-      }
       if (!folded) {
         if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
         a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
@@ -221,7 +211,6 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
       return launch_gemm(a, s);
     case 1:
-      if (fused_qkv) return CLIPMI_OK;
       return launch_attention(w.qkv, w.att, n_seq, L, H, causal, s);
     case 2:
       a.A = w.att; a.lda = rowD; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;
@@ -448,11 +437,6 @@ int clipmi_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
 
 int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal, clipmi_stream_t stream) {
   return launch_attention((const half_t*)qkv, (half_t*)out, N, L, H, causal, (hipStream_t)stream);
-}
-
-int clipmi_qkv_attention(const void* x16, const void* w_qkv, const float* g, const float* c, const float* stats, int parts, void* out, int N, int L,
-                         int H, float eps, int nt_stores, clipmi_stream_t stream) {
-  return launch_qkv_attention((const half_t*)x16, (const half_t*)w_qkv, g, c, stats, parts, (half_t*)out, N, L, H, eps, nt_stores, (hipStream_t)stream);
 }
 
 int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R, int P, int Kpad, clipmi_stream_t stream) {

@@ -133,8 +133,7 @@ struct Options {
                                              // (identical features; not the default: the headline benchmark computes every row)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
-  std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 3 = the block's in-projection FUSED into the attention kernel
-                                       // (qkv_attention_kernel: q | k | v never reach memory; tower blocks only); 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
+  std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
                                        // from a loader wave, fragment reads pinned by inline asm, output rows stored non-temporal); 1 = the same with plain
                                        // stores; 0 = persistent kernel (all three: same bits)
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)
@@ -213,10 +212,6 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
 // n*L + first + j, j < n_ctx.  M = N*L is the partial stride.
 int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
-// in-projection (optionally with the LayerNorm fold: stats != nullptr) + attention of one block in one launch, q | k | v never leave the CU
-bool qkv_attention_fits(int L, int D, int parts);
-int launch_qkv_attention(const half_t* x16, const half_t* W, const float* g, const float* c, const float* stats, int parts, half_t* out, int N, int L,
-                         int H, float eps, int nt_stores, hipStream_t s);
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
 // patch_embed.hip: conv1 as a GEMM whose loader reads the (fp16) NCHW image directly (+ pos, token-row scatter) and ln_pre over every token row with the
 // class / shallow-prompt rows formed on the fly   (clip/model.py:394-402,413)

@@ -118,27 +118,6 @@ def attention(qkv: torch.Tensor, n_seq: int, seq_len: int, n_head: int, causal: 
     return out
 
 
-def qkv_attention(x16: torch.Tensor, w_qkv: torch.Tensor, c: torch.Tensor, n_seq: int, seq_len: int, n_head: int,
-                  g: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, parts: int = 0, eps: float = 1e-5,
-                  nt_stores: bool = True) -> torch.Tensor:
-    """In-projection (optionally with ln_1 folded in: ``stats`` = [parts, n_seq*seq_len, 2] row partials, ``g``) + attention of a vision
-    block in one launch (clipmi_qkv_attention; clip/model.py:181-186): x16 fp16 [n_seq*seq_len, D] -> fp16 [n_seq*seq_len, D]."""
-    x16 = _dev(x16, "x16", (torch.float16,))
-    w_qkv = _dev(w_qkv, "w_qkv", (torch.float16,))
-    c = _dev(c, "c", (torch.float32,))
-    D = 64 * n_head
-    if x16.shape != (n_seq * seq_len, D) or w_qkv.shape != (3 * D, D) or c.numel() != 3 * D:
-        raise ValueError("qkv_attention: shapes do not match [n_seq*seq_len, D], [3D, D], [3D]")
-    g, pg = _opt(g, "g", (torch.float32,))
-    stats, ps = _opt(stats, "stats", (torch.float32,))
-    if stats is not None and (g is None or stats.numel() != parts * n_seq * seq_len * 2):
-        raise ValueError("qkv_attention: the LayerNorm fold needs g and stats [parts, rows, 2]")
-    out = torch.empty(n_seq * seq_len, D, dtype=torch.float16, device=x16.device)
-    check(lib.clipmi_qkv_attention(x16.data_ptr(), w_qkv.data_ptr(), pg, c.data_ptr(), ps, int(parts), out.data_ptr(), n_seq, seq_len, n_head,
-                                   float(eps), int(bool(nt_stores)), _stream()), "clipmi_qkv_attention")
-    return out
-
-
 def patchify(image: torch.Tensor, patch: int, kpad: Optional[int] = None) -> torch.Tensor:
     image = _dev(image, "image", (torch.float16, torch.float32))
     B, ch, R, R2 = image.shape

@@ -72,8 +72,7 @@ const char* clipmi_last_error(void);
  *   gemm_rstream     (CLIPMI_GEMM_RSTREAM)    1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
  *                                             residual GEMMs with K <= 1536 (out-proj); 0 = one 320 x 256 tile per workgroup.  The row-range
  *                                             kernel adds the residual inside its K loop: both round the same fp32 sum once, in another order
- *   attn_loader      (CLIPMI_ATTN_LOADER)     3 = the tower blocks' in-projection runs INSIDE the 193..200-token attention kernel (clipmi_qkv_attention);
- *                                             2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
+ *   attn_loader      (CLIPMI_ATTN_LOADER)     2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
  *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
  *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
@@ -126,20 +125,6 @@ int clipmi_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
  * merge_heads(softmax(q k^T / 8 + mask) v).  head_dim is 64 (D == 64*H).  causal != 0 applies the text
  * tower's mask (clip/model.py:585-591). */
 int clipmi_attention(const void* qkv, void* out, int N, int L, int H, int causal, clipmi_stream_t stream);
-
-/* ln_1 (folded) + in_proj + attention core of a vision block in ONE launch (clip/model.py:181-186): out = merge_heads(softmax(q k^T / 8) v)
- * with q | k | v = LN(x) @ in_proj_weight^T + in_proj_bias computed per (sequence, head) inside the attention kernel and kept in LDS --
- * they are never written to memory.  Two operand forms:
- *   stats != NULL (LayerNorm fold, what the towers use): x16 fp16 [N*L, D] = the fp16 copy of the residual stream; w_qkv fp16 [3D, D] =
- *       gamma * in_proj_weight; g fp32 [3D] = its row sums; c fp32 [3D] = in_proj_weight @ beta + in_proj_bias; stats fp32
- *       [parts][N*L][2] = (sum, sum of squares) row partials of the stream (1 <= parts <= 4); q|k|v = rstd*(x16 @ w^T) - rstd*mean*g + c
- *   stats == NULL: x16 = ln_1's output, w_qkv = in_proj_weight, c = in_proj_bias, g ignored; q|k|v = x16 @ w^T + c -- bit-identical to
- *       clipmi_gemm_f16(EPI_BIAS, fp16 out) followed by clipmi_attention
- * out fp16 [N*L, D].  Non-causal, 193 <= L <= 200 (ViT-B/16, ViT-B/32 towers at 224 px, with up to 3 prompt tokens), D = 64 H in 128..2048;
- * CLIPMI_ERR_SHAPE otherwise.  nt_stores != 0: output rows stored non-temporal.  Selected inside clipmi_encode_image by option
- * attn_loader = 3 (round 4 A/B: profiles/r04_qkv_attention_fusion.txt). */
-int clipmi_qkv_attention(const void* x16, const void* w_qkv, const float* g, const float* c, const float* stats, int parts, void* out,
-                         int N, int L, int H, float eps, int nt_stores, clipmi_stream_t stream);
 
 /* image.type(dtype) + the im2col half of conv1 (clip/model.py:598,395-397): image [B,3,R,R] (fp32 or fp16,
  * NCHW) -> col fp16 [B*(R/P)^2, Kpad], column c*P*P + ky*P + kx, zero padded up to Kpad (a multiple of 64). */

@@ -817,27 +817,6 @@ def test_image_tower_passes_same_bits(clipmi_option, hooked):
         assert need < need_whole if B >= 6 else need == need_whole            # 5 images: less than one and a half passes -> one pass
 
 
-@pytest.mark.parametrize("mode", ["default", "ln_fold=0", "residual_f16=0"])
-def test_image_tower_with_fused_in_projection_attention(clipmi_option, mode):
-    """Option attn_loader = 3: every block's in-projection runs inside the attention kernel (clipmi_qkv_attention; q | k | v stay in LDS).
-    Same operands, same K order, same epilogue arithmetic as the two launches it replaces: the ViT-B/16 image features must agree with the
-    default path to fp16-rounding level (identical where the compiler contracts the fold epilogue alike) in all three precision / fold modes."""
-    if mode != "default":
-        name, val = mode.split("=")
-        clipmi_option(name, int(val))
-    sd, model = _build("ViT-B/16")
-    images = syn.synthetic_images(12, "ViT-B/16", seed=4).cuda()
-    with torch.no_grad():
-        clipmi_option("attn_loader", 2)
-        want = model.image_features_f32(images).clone()
-        clipmi_option("attn_loader", 3)
-        got = model.image_features_f32(images).clone()
-    w, g = torch.nn.functional.normalize(want, dim=1), torch.nn.functional.normalize(got, dim=1)
-    assert torch.isfinite(got).all()
-    assert float((1.0 - (w * g).sum(1)).abs().max()) < 2e-6, float((1.0 - (w * g).sum(1)).abs().max())
-    assert float((w - g).abs().max()) < 2e-4
-
-
 def test_timed_tower_pass_is_the_ordinary_pass():
     """clipmi_encode_image_timed (bench.py's `us_in_tower`): the same launches as clipmi_encode_image with a hipEvent behind each -- same
     bits out, one positive interval per launch (embedding launches + 5 per layer + ln_post + proj), and a batch beyond one pass is refused
