@@ -79,7 +79,7 @@ _SIGNATURES = {
     "clipmi_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipmi_patch_embed_scratch_bytes": (_sz, [_i, _i, _i]),
     "clipmi_patch_embed": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "clipmi_embed_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "clipmi_embed_ln": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipmi_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "clipmi_logits": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipmi_fused_tail_workspace_bytes": (_sz, [_i, _i]),

@@ -450,9 +450,9 @@ int clipmi_patch_embed(const void* image, int image_dtype, void* scratch, const 
   return launch_patch_embed(image, image_dtype, scratch, (const half_t*)conv_w, ldw, pos, x0, x0_dtype, B, R, P, D, tokens, (hipStream_t)stream);
 }
 
-int clipmi_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
-                    float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps, clipmi_stream_t stream) {
-  return launch_embed_ln(x0, x0_dtype, cls, pos, shallow, gamma, beta, y, (half_t*)y16, stats, B, L, tokens0, D, eps, (hipStream_t)stream);
+int clipmi_embed_ln(const void* x0, int x0_dtype, int add_pos, const float* cls, const float* pos, const float* shallow, const float* gamma,
+                    const float* beta, float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps, clipmi_stream_t stream) {
+  return launch_embed_ln(x0, x0_dtype, add_pos, cls, pos, shallow, gamma, beta, y, (half_t*)y16, stats, B, L, tokens0, D, eps, (hipStream_t)stream);
 }
 
 int clipmi_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, clipmi_stream_t stream) {
@@ -710,10 +710,10 @@ static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype
     const int x0_dtype = f16res ? CLIPMI_F16 : CLIPMI_F32;
     void* x0 = w.qkv;                              // [B*L, D] embeddings before ln_pre (fp16 or fp32: at most 4 of the region's 6 bytes per element)
     if ((rc = launch_patch_embed(image, image_dtype, w.hid /* >= col_bytes = the fp16 image's size */, (const half_t*)m->vw.conv_w, Kpad,
-                                 m->vw.positional_embedding, x0, x0_dtype, batch, g.image_resolution, g.patch_size, D, L, s)))
+                                 nullptr /* pos: added by ln_pre's row pass */, x0, x0_dtype, batch, g.image_resolution, g.patch_size, D, L, s)))
       return rc;
     tick();   // (one interval: the cast of an fp32 image + the GEMM)
-    if ((rc = launch_embed_ln(x0, x0_dtype, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, m->vw.ln_pre_g,
+    if ((rc = launch_embed_ln(x0, x0_dtype, 1, m->vw.class_embedding, m->vw.positional_embedding, hook ? hook->shallow : nullptr, m->vw.ln_pre_g,
                               m->vw.ln_pre_b, f16res ? nullptr : w.xres, folded ? w.xn : nullptr, folded ? w.stats : nullptr, batch, L, L0, D, 1e-5f, s)))
       return rc;
     tick();

@@ -191,6 +191,9 @@ struct GemmArgs {
   int M, N, K, epilogue;
   // EPI_PATCH_POS: out row = (m / patches) * tokens + (m % patches) + 1, plus pos[(m % patches) + 1][n]
   const float* pos; int patches; int tokens;
+  // EPI_PATCH_POS with im_P != 0: implicit im2col -- A is the fp16 NCHW image batch [M / patches, 3, im_R, im_R] itself (conv1 has stride =
+  // kernel = im_P in {8, 16, 32}: column k = c P^2 + ky P + kx of patch row m is a pixel address), K = 3 P^2, lda unused
+  int im_R = 0, im_P = 0;
   // LayerNorm folding (see gemm.hip "LayerNorm folded into the GEMMs").  Row statistics live in a partial buffer
   // stats[p * M + m] = (sum, sum of squares) of row m over the p-th column tile of the producer; consumers add the
   // ln_parts partials in a fixed order (deterministic, no atomics, nothing to zero).
@@ -219,8 +222,8 @@ bool patch_embed_fits(int B, int R, int P, int D);
 size_t patch_embed_scratch_bytes(int B, int R, int image_dtype);   // fp16 copy of an fp32 image batch (0 for an fp16 image)
 int launch_patch_embed(const void* image, int image_dtype, void* scratch, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
                        int B, int R, int P, int D, int tokens, hipStream_t s);
-int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
-                    float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s);
+int launch_embed_ln(const void* x0, int x0_dtype, int add_pos, const float* cls, const float* pos, const float* shallow, const float* gamma,
+                    const float* beta, float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s);
 // x0[b, 0, :] = cls + pos[0]; x0[b, tokens0 + j, :] = shallow[j] (MaPLe)     (clip/model.py:398-402,459-460)
 int launch_cls_and_ctx_rows(float* x0, const float* cls, const float* pos, const float* shallow, int B, int tokens0,
                             int n_ctx, int D, hipStream_t s);

@@ -394,6 +394,50 @@ template <typename T, int EPI, bool OUT_F32>
 __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m,
                                                 int wave_n, int lane);
 
+// EPI_PATCH_POS with fp16 token rows (the fp16 residual stream: clip/model.py:395-401 on a convert_weights model holds the conv output and the
+// positional sum in fp16): acc (+ pos[1 + patch] in fp32 when a.pos is given; the image tower passes none and lets embed_ln_kernel add it: 40
+// dependent L2 loads per lane in this epilogue cost 13 us per launch), one rounding, 32 rows x 64 columns at a time through a wave-private LDS patch so that a
+// store instruction writes 128 contiguous bytes of 8 token rows (16 B per lane).  Rows map patch m -> token row (m / patches) * tokens +
+// m % patches + 1.  The caller has passed a workgroup barrier after the last main-loop LDS read.
+template <typename T>
+__device__ __forceinline__ void epilogue_patch_pos_f16(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n, int lane,
+                                                       char* patch) {
+  constexpr int TM = T::TM, TN = T::TN, ROWB = 64 * 2 + 16;
+  static_assert(T::WTN == 64 && TM % 2 == 0 && TN == 4, "64-column wave tiles");
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int rrow = lane >> 3, rcol = lane & 7;
+  half_t* out = static_cast<half_t*>(a.out);
+  const int n_st = n0 + wave_n * 64 + rcol * 8;
+#pragma unroll
+  for (int jc = 0; jc < TM / 2; ++jc) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int m = m0 + wave_m * T::WTM + (jc * 2 + jj) * 16 + r16;
+      const int mm = m < a.M ? m : a.M - 1;
+      const int t = mm - (mm / a.patches) * a.patches + 1;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
+        f32x4 v = acc[i][jc * 2 + jj];
+        if (a.pos && n < a.N) v += *reinterpret_cast<const f32x4*>(a.pos + (int64_t)t * a.N + n);   // (a.pos: kernel argument, uniform)
+        *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      }
+    }
+    // same wave, LDS is in order: the reads below see the writes above (and the next slice's writes follow these reads)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 8 + rrow;
+      const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
+      const int m = m0 + wave_m * T::WTM + jc * 32 + row;
+      if (m < a.M && n_st < a.N) {
+        const int b = m / a.patches;
+        *reinterpret_cast<f16x8*>(out + ((int64_t)b * a.tokens + (m - b * a.patches + 1)) * a.ldo + n_st) = val;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // one 32-row slice at a time: the accumulators die as they are converted
+  }
+}
+
 template <typename T, int EPI, bool OUT_F32, bool DMA_RES = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs& a, int m0, int n0, int wave_m, int wave_n,
                                          int lane, int wave, char* smem, const float2* lnp = nullptr) {
@@ -403,6 +447,11 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[T::TN][T::TM], const KArgs
   }
   if constexpr (EPI == EPI_RESIDUAL_FOLD || EPI == EPI_RESIDUAL_FOLD16) {
     epilogue_residual_fold<T, EPI == EPI_RESIDUAL_FOLD16>(acc, a, m0, n0, n0 / T::BN, wave_m, wave_n, lane, wave, smem);
+    return;
+  }
+  if constexpr (!OUT_F32 && EPI == EPI_PATCH_POS) {   // (launch_gemm checks N % 8 == 0)
+    __syncthreads();
+    epilogue_patch_pos_f16<T>(acc, a, m0, n0, wave_m, wave_n, lane, smem + wave * (32 * 144));
     return;
   }
   if constexpr (!OUT_F32 && EPI != EPI_PATCH_POS) {
@@ -468,8 +517,7 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
         v += rr;
       }
       if constexpr (EPI == EPI_PATCH_POS) {
-        const f32x4 pp = *reinterpret_cast<const f32x4*>(posrow + n);
-        v += pp;
+        if (a.pos) v += *reinterpret_cast<const f32x4*>(posrow + n);
       }
       if constexpr (OUT_F32) {
         *reinterpret_cast<f32x4*>(static_cast<float*>(a.out) + orow * a.ldo + n) = v;
@@ -1212,7 +1260,12 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
 // are those of gemm_f16_kernel.  Why: that kernel's compiler-scheduled loop (vmcnt(0) + __syncthreads per K-step, all DMA
 // issued behind the barrier) keeps the matrix pipe 68-75 % busy on this tile; this one 77+ %.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32>
+// IM2COL (the patch embedding, clip/model.py:395-397): the activation operand is the fp16 NCHW image itself.  conv1 has stride = kernel = P,
+// so column k = c P^2 + ky P + kx of patch row m = (b, py, px) is pixel (b, c, py P + ky, px P + kx): with P in {8, 16, 32} a 16-byte LDS slot
+// (8 consecutive k) is 8 consecutive pixels of one image row and a 64-deep K-step is 64 / P whole row segments of one channel.  The per-lane
+// source offset of a DMA piece is then (patch origin) + (row segment, first pixel of the lane's slot) -- one register per piece, set up once
+// -- and the scalar offset of a K-step is its (channel, first row).  No im2col matrix exists; the loader moves the bytes a dense operand would.
+template <typename T, int EPI, bool OUT_F32, bool IM2COL = false>
 __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
   static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
@@ -1231,7 +1284,8 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 
   const int srow = tid >> 3;
   const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
+  const __amdgpu_buffer_rsrc_t xrs = IM2COL ? make_rsrc(a.A, (int64_t)(a.M / a.patches) * 3 * a.im_R * a.im_R * 2)
+                                            : make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
   const int xoff0 = (srow * (int)a.lda + schunk * 8) * 2, woff0 = (srow * (int)a.ldw + schunk * 8) * 2;
   const int xstep = (NT / 8) * (int)a.lda * 2, wstep = (NT / 8) * (int)a.ldw * 2;
@@ -1240,14 +1294,39 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
     asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
     return r;
   };
+  // IM2COL: byte offset of the lane's 8 pixels of K-step 0 for each of its activation pieces (piece P = tile rows P * 64 + srow); rows at or
+  // beyond M point past the descriptor and read as zero.  The lane's data chunk `schunk` is row segment schunk / (P / 8), pixels (schunk % (P / 8)) * 8 ..
+  int xim[IM2COL ? T::XI : 1];
+  int im_spc = 1, im_rps = 1;   // K-steps per channel, image rows per K-step
+  if constexpr (IM2COL) {
+    const int cps = a.im_P >> 3;
+    const int lane_k = ((schunk / cps) * a.im_R + (schunk % cps) * 8) * 2;
+#pragma unroll
+    for (int i = 0; i < T::XI; ++i) {
+      const int m = m0 + i * (NT / 8) + srow;
+      const int b = m / a.patches, p = m - b * a.patches;
+      const int py = p / a.im_G, px = p - py * a.im_G;
+      xim[i] = m < a.M ? (((b * 3) * a.im_R + py * a.im_P) * a.im_R + px * a.im_P) * 2 + lane_k : (int)0xFFFFFF00;
+    }
+    im_spc = (a.im_P * a.im_P) >> 6;
+    im_rps = 64 / a.im_P;
+  }
   const int lds_wave_off = wave * 1024;
   auto stage_piece = [&](auto p_tag, int buf, int kt) {
     constexpr int P = decltype(p_tag)::value;
     if constexpr (P < NP) {
       char* xs = smem + buf * T::STAGE + lds_wave_off;
       const int k0 = kt * BK * 2;
-      if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
-      else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+      if constexpr (P < T::XI) {
+        if constexpr (IM2COL) {
+          const int c = kt / im_spc, ky0 = (kt - c * im_spc) * im_rps;   // scalar
+          CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), xim[P], ((c * a.im_R + ky0) * a.im_R) * 2);
+        } else {
+          CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
+        }
+      } else {
+        CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+      }
     }
   };
 
@@ -1386,10 +1465,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
 #endif
 }
 
-template <typename T, int EPI, bool OUT_F32>
+template <typename T, int EPI, bool OUT_F32, bool IM2COL = false>
 int launch_pp(KArgs k, hipStream_t s) {
   static DeviceOnce attr_once;
-  auto fn = gemm_pp_kernel<T, EPI, OUT_F32>;
+  auto fn = gemm_pp_kernel<T, EPI, OUT_F32, IM2COL>;
   constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);   // + the LayerNorm-fold row parameters
   constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;
   constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
@@ -1635,6 +1714,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.residual16 = static_cast<const half_t*>(a.residual);
   k.out = a.out; k.ldo = a.ldo; k.M = a.M; k.N = a.N; k.K = a.K;
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
+  k.im_R = a.im_R; k.im_P = a.im_P; k.im_G = a.im_P > 0 ? a.im_R / a.im_P : 0;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
   k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
 #ifdef CLIPMI_TUNING
@@ -1676,7 +1756,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
       CLIPMI_REQUIRE(a.residual && (uintptr_t)a.residual % 8 == 0 && !f32, CLIPMI_ERR_ARG, "gemm: BIAS_RESIDUAL16_RELU needs an fp16 residual and fp16 output");
       return launch_basic<CLIPMI_EPI_BIAS_RESIDUAL16_RELU, false>(k, s);
     case EPI_PATCH_POS:
-      CLIPMI_REQUIRE(a.pos && a.patches > 0 && a.tokens > a.patches && f32, CLIPMI_ERR_ARG, "gemm: bad patch epilogue");
+      CLIPMI_REQUIRE((a.pos || a.im_P) && a.patches > 0 && a.tokens > a.patches, CLIPMI_ERR_ARG, "gemm: bad patch epilogue");
+      if (a.im_P) {   // implicit im2col: the ping-pong 320 x 256 kernel with the image as its activation operand
+        CLIPMI_REQUIRE((a.im_P == 8 || a.im_P == 16 || a.im_P == 32) && a.im_R % a.im_P == 0 && a.K == 3 * a.im_P * a.im_P &&
+                           a.patches == (a.im_R / a.im_P) * (a.im_R / a.im_P) && a.M % a.patches == 0 && a.N % 8 == 0 && a.ldo % 8 == 0 &&
+                           (int64_t)(a.M / a.patches) * 3 * a.im_R * a.im_R * 2 < 0x7FFFFF00ll,
+                       CLIPMI_ERR_SHAPE, "gemm: implicit im2col needs P in {8, 16, 32}, K = 3 P^2, whole images below 2 GB, N %% 8 == 0");
+        return f32 ? launch_pp<T320w8, EPI_PATCH_POS, true, true>(k, s) : launch_pp<T320w8, EPI_PATCH_POS, false, true>(k, s);
+      }
+      CLIPMI_REQUIRE(f32, CLIPMI_ERR_ARG, "gemm: the im2col-matrix patch epilogue writes fp32 rows");
       return launch_one<EPI_PATCH_POS, true>(k, s, a.parts_out);
     default:
       set_error("gemm: unknown epilogue %d", a.epilogue);

@@ -30,6 +30,7 @@ struct KArgs {
   void* out; int64_t ldo;
   int M, N, K;
   const float* pos; int patches; int tokens;
+  int im_R, im_P, im_G;   // implicit im2col (gemm_pp_kernel<..., IM2COL>): A is the fp16 NCHW image [M / patches, 3, R, R], patch size P, grid G = R / P
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;

@@ -2,7 +2,7 @@
 // conv1 -> reshape -> permute -> cat(class_embedding) -> + positional_embedding; :413 ln_pre; :597-598 the dtype cast of encode_image).
 //
 //   cast_image_kernel    fp32 NCHW pixels -> fp16 NCHW pixels (image.type(self.dtype), clip/model.py:598); skipped for an fp16 image
-//   patch_embed_kernel   x0[b, 1 + p, :] = patch(b, p) @ conv_w^T + pos[1 + p]          (MFMA GEMM, M = B * G * G patches, N = width, K = 3 P^2)
+//   gemm_pp_kernel<IM2COL>  x0[b, 1 + p, :] = patch(b, p) @ conv_w^T + pos[1 + p]       (gemm.hip; M = B * G * G patches, N = width, K = 3 P^2)
 //   embed_ln_kernel      x[b, l, :] = ln_pre(l == 0 ? cls + pos[0] : l < 1 + G^2 ? x0[b, l] : shallow[l - 1 - G^2])   -> the residual stream
 //
 // conv1 has stride = kernel = P, so its im2col matrix is a pure ADDRESS MAP of the NCHW image: column k = c P^2 + ky P + kx of patch
@@ -17,7 +17,7 @@
 // embed_ln_kernel forms them on the fly; it is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same butterfly) with those
 // three row sources and the outputs the blocks want (fp32 stream and / or fp16 operand copy + the LayerNorm-fold row sums of the output).
 //
-// Why the cast is its own pass (profiles/r04_patch_embed.txt): the first form of this kernel staged fp32 pixels THROUGH REGISTERS (two
+// Why the cast is its own pass (profiles/r04_patch_embed.txt): the first form of the GEMM staged fp32 pixels THROUGH REGISTERS (two
 // 16-byte loads, four v_cvt_pk_f16_f32, one ds_write_b128 per slot) -- correct, and 140 us at batch 256: with 128 accumulator registers
 // per lane a wave can hold one K-step of pixels in flight, 1 us of MFMAs to cover a load that takes ~3 us when every CU pulls 64 KB of
 // fp32 per K-step through its L1, three times over (one per n-tile).  A 231 MB streaming cast (38 us) in front of an all-DMA GEMM is faster.
@@ -32,22 +32,6 @@ namespace {
 
 using namespace gemm;
 
-struct PEArgs {
-  const half_t* image;         // [B, 3, R, R] fp16 (the caller's, or cast_image_kernel's output)
-  const half_t* W; int64_t ldw;   // conv1.weight packed [N, K], K index c P^2 + ky P + kx
-  const float* pos;            // [tokens0, N]
-  void* out; int64_t ldo;      // token rows [B * tokens, N], fp16 or fp32
-  int M, N, K;                 // patches, width, 3 P^2
-  int R, P, G, GG, tokens;     // resolution, patch size, grid, G^2, tokens per sequence (1 + G^2 + n_ctx)
-  int tiles_n, nwg, band;
-};
-
-constexpr int PE_BM = 256, PE_BN = 256, PE_NT = 512;
-constexpr int PE_XBYTES = PE_BM * BK * 2, PE_WBYTES = PE_BN * BK * 2, PE_STAGE = PE_XBYTES + PE_WBYTES;
-constexpr int PE_SMEM = 2 * PE_STAGE;
-constexpr int PE_XI = PE_BM * 8 / PE_NT;   // 16-byte activation chunks per thread and stage (4)
-constexpr int PE_WI = PE_BN * 8 / PE_NT;   // LDS-DMA pieces per wave and stage (4)
-
 // fp32 -> fp16 pixels, 8 per thread (two 16-byte loads, one 16-byte store)
 __global__ __launch_bounds__(256) void cast_image_kernel(const float* __restrict__ src, half_t* __restrict__ dst, int64_t n8) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -57,163 +41,10 @@ __global__ __launch_bounds__(256) void cast_image_kernel(const float* __restrict
       f16x8{(half_t)lo[0], (half_t)lo[1], (half_t)lo[2], (half_t)lo[3], (half_t)hi[0], (half_t)hi[1], (half_t)hi[2], (half_t)hi[3]};
 }
 
-// 256 x 256 tile, eight waves of 128(m) x 64(n) (two per SIMD), two LDS stages, both operands by LDS-DMA: per K-step the barrier that hands
-// over stage kt, the DMA of stage kt + 1 into the other buffer, the 64 MFMAs of stage kt (gemm.hip gemm_f16_kernel's loop).
-template <typename TO>
-__global__ __launch_bounds__(PE_NT, 2) void patch_embed_kernel(const PEArgs a) {
-  constexpr int TM = 8, TN = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave & 1, wave_n = wave >> 1;
-
-  // tile traversal: XCD label = blockIdx % 8 gets a contiguous range of tiles, bands of `band` n-tiles, m slow / n fast inside a band
-  // (gemm.hip tile_coords): the n-tiles of an m-tile run together on one XCD, whose L2 then serves the pixel rows to all but the first
-  int tile_m, tile_n;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = a.nwg >> 3, r = a.nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tiles_m = a.nwg / a.tiles_n;
-    const int per_band = tiles_m * a.band;
-    const int b = wg / per_band;
-    const int within = wg - b * per_band;
-    const int rem = a.tiles_n - b * a.band;
-    const int gw = rem < a.band ? rem : a.band;
-    tile_m = within / gw;
-    tile_n = b * a.band + (within - tile_m * gw);
-  }
-  const int m0 = tile_m * PE_BM, n0 = tile_n * PE_BN;
-
-  // ---- activation staging: thread t, piece i covers patch row i * 64 + (t >> 3) of the tile, LDS slot (t & 7) of that row, which holds
-  //      data chunk j = (t & 7) ^ ((row >> 1) & 7) -- the same for all four rows of a thread (rows differ by 64).  Chunk j of a K-step is
-  //      row segment ky_l = j / (P / 8) of the step, pixels kx0 = (j % (P / 8)) * 8 .. + 7.
-  const int srow = tid >> 3;
-  const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-  const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.image, (int64_t)(a.M / a.GG) * 3 * a.R * a.R * 2);
-  const int cps = a.P >> 3;                                   // 16-byte chunks per row segment
-  const int lane_k = ((schunk / cps) * a.R + (schunk % cps) * 8) * 2;
-  int xoff[PE_XI];   // byte offset of the lane's 8 pixels for K-step 0; rows past M point past the descriptor (read as zero)
-#pragma unroll
-  for (int i = 0; i < PE_XI; ++i) {
-    const int m = m0 + i * (PE_NT / 8) + srow;
-    const int b = m / a.GG, p = m - b * a.GG;
-    const int py = p / a.G, px = p - py * a.G;
-    xoff[i] = m < a.M ? (((b * 3) * a.R + py * a.P) * a.R + px * a.P) * 2 + lane_k : (int)0xFFFFFF00;
-  }
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  int woff[PE_WI];
-#pragma unroll
-  for (int i = 0; i < PE_WI; ++i) woff[i] = ((i * (PE_NT / 8) + srow) * (int)a.ldw + schunk * 8) * 2;
-  const int lds_wave_off = wave * 1024;
-  const int spc = (a.P * a.P) >> 6, rps = 64 / a.P;           // K-steps per channel, image rows per K-step
-  auto stage = [&](int buf, int kt) {
-    char* xs = smem + buf * PE_STAGE + lds_wave_off;
-    const int c = kt / spc, ky0 = (kt - c * spc) * rps;        // scalar
-    const int soff = ((c * a.R + ky0) * a.R) * 2;
-#pragma unroll
-    for (int i = 0; i < PE_XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(irs, xs + i * (PE_NT * 16), xoff[i], soff);
-    const int k0 = kt * BK * 2;
-#pragma unroll
-    for (int i = 0; i < PE_WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + PE_XBYTES + i * (PE_NT * 16), woff[i], k0);
-  };
-
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int swz = (r16 >> 1) & 7;
-  int foff[2];
-  foff[0] = r16 * 128 + (((0 + g4) ^ swz) << 4);
-  foff[1] = r16 * 128 + (((4 + g4) ^ swz) << 4);
-  const int xbase = wave_m * 128 * 128;
-  const int wbase = PE_XBYTES + wave_n * 64 * 128;
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = a.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // stage kt landed for every wave; everyone finished reading the other buffer
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* st = smem + (kt & 1) * PE_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 xf[TM], wf[TN];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const f16x8*>(st + xbase + j * 2048 + foff[ks]);
-#pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f16x8*>(st + wbase + i * 2048 + foff[ks]);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-
-  // ---- epilogue: acc[i][j][e] = C[m = m0 + wave_m 128 + 16 j + r16][n = n0 + wave_n 64 + 16 i + 4 g4 + e]; + pos, token-row scatter
-  TO* out = static_cast<TO*>(a.out);
-  if constexpr (sizeof(TO) == 4) {
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wave_m * 128 + j * 16 + r16;
-      if (m >= a.M) continue;
-      const int b = m / a.GG, t = m - b * a.GG + 1;
-      const int64_t orow = (int64_t)b * a.tokens + t;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
-        if (n >= a.N) continue;
-        *reinterpret_cast<f32x4*>(out + orow * a.ldo + n) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.pos + (int64_t)t * a.N + n);
-      }
-    }
-  } else {
-    // fp16 rows: 32 rows x 64 columns at a time through a wave-private LDS patch, so that a store instruction writes 128 contiguous
-    // bytes of 8 rows (16 B per lane) instead of 8-byte pieces (gemm.hip epilogue_f16_staged)
-    constexpr int ROWB = 64 * 2 + 16;
-    __syncthreads();   // every wave is done with the main-loop LDS image
-    char* patch = smem + wave * (32 * ROWB);
-    const int rrow = lane >> 3, rcol = lane & 7;
-    const int n_st = n0 + wave_n * 64 + rcol * 8;
-#pragma unroll
-    for (int jc = 0; jc < TM / 2; ++jc) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int m = m0 + wave_m * 128 + (jc * 2 + jj) * 16 + r16;
-        const int mm = m < a.M ? m : a.M - 1;
-        const int t = mm - (mm / a.GG) * a.GG + 1;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int n = n0 + wave_n * 64 + i * 16 + g4 * 4;
-          f32x4 v = acc[i][jc * 2 + jj];
-          if (n < a.N) v += *reinterpret_cast<const f32x4*>(a.pos + (int64_t)t * a.N + n);
-          *reinterpret_cast<f16x4*>(patch + (jj * 16 + r16) * ROWB + (i * 16 + g4 * 4) * 2) = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        }
-      }
-      // same wave, LDS is in order: the reads below see the writes above (and the next slice's writes follow these reads)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = q * 8 + rrow;
-        const f16x8 val = *reinterpret_cast<const f16x8*>(patch + row * ROWB + rcol * 16);
-        const int m = m0 + wave_m * 128 + jc * 32 + row;
-        if (m < a.M && n_st < a.N) {
-          const int b = m / a.GG;
-          *reinterpret_cast<f16x8*>(out + ((int64_t)b * a.tokens + (m - b * a.GG + 1)) * a.ldo + n_st) = val;
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // ln_pre over every token row, one wave per row (layernorm.hip's arithmetic and reduction order).  Row sources:
 //   l == 0            cls + pos[0]                     (clip/model.py:398-401; identical for every image)
-//   1 <= l < tokens0  x0[b, l, :] as the GEMM above left it (fp16 or fp32)
+//   1 <= l < tokens0  x0[b, l, :] as the GEMM left it (fp16 or fp32) (+ pos[l] when add_pos: clip/model.py:401)
 //   l >= tokens0      shallow[l - tokens0, :]          (MaPLe's shallow prompt tokens, clip/model.py:459-460: appended after pos is added)
 // Outputs: y (fp32 stream, optional) and / or y16 + stats (fp16 operand copy + LayerNorm-fold row sums of the output, partial 0).
 // ---------------------------------------------------------------------------------------------------------------
@@ -227,7 +58,7 @@ template <typename TI, int NV>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const TI* __restrict__ x0, const float* __restrict__ cls, const float* __restrict__ pos,
                                                        const float* __restrict__ shallow, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ y, half_t* __restrict__ y16,
-                                                       float* __restrict__ stats_out, int rows, int L, int tokens0, int D, float eps) {
+                                                       float* __restrict__ stats_out, int rows, int L, int tokens0, int D, float eps, int add_pos) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -243,11 +74,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TI* __restrict__ x0
         v[i] = *reinterpret_cast<const f32x4*>(cls + c * 4) + *reinterpret_cast<const f32x4*>(pos + c * 4);
       } else if (l >= tokens0) {
         v[i] = *reinterpret_cast<const f32x4*>(shallow + (int64_t)(l - tokens0) * D + c * 4);
-      } else if constexpr (sizeof(TI) == 4) {
-        v[i] = *reinterpret_cast<const f32x4*>(x0 + (int64_t)row * D + c * 4);
       } else {
-        const f16x4 h = *reinterpret_cast<const f16x4*>(x0 + (int64_t)row * D + c * 4);
-        v[i] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        if constexpr (sizeof(TI) == 4) {
+          v[i] = *reinterpret_cast<const f32x4*>(x0 + (int64_t)row * D + c * 4);
+        } else {
+          const f16x4 h = *reinterpret_cast<const f16x4*>(x0 + (int64_t)row * D + c * 4);
+          v[i] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        if (add_pos) v[i] += *reinterpret_cast<const f32x4*>(pos + (int64_t)l * D + c * 4);   // (the GEMM left the bare conv output)
       }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
@@ -293,15 +127,6 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const TI* __restrict__ x0
   }
 }
 
-template <typename TO>
-int launch_pe(const PEArgs& a, hipStream_t s) {
-  static DeviceOnce attr_once;
-  auto fn = patch_embed_kernel<TO>;
-  ensure_dynamic_lds(fn, PE_SMEM, attr_once);
-  hipLaunchKernelGGL(fn, dim3(a.nwg), dim3(PE_NT), PE_SMEM, s, a);
-  return check_launch("patch_embed_kernel");
-}
-
 }  // namespace
 
 bool patch_embed_fits(int B, int R, int P, int D) {
@@ -314,7 +139,7 @@ size_t patch_embed_scratch_bytes(int B, int R, int image_dtype) { return image_d
 int launch_patch_embed(const void* image, int image_dtype, void* scratch, const half_t* conv_w, int64_t ldw, const float* pos, void* x0, int x0_dtype,
                        int B, int R, int P, int D, int tokens, hipStream_t s) {
   if (B == 0) return CLIPMI_OK;
-  CLIPMI_REQUIRE(image && conv_w && pos && x0, CLIPMI_ERR_ARG, "patch_embed: null pointer");
+  CLIPMI_REQUIRE(image && conv_w && x0, CLIPMI_ERR_ARG, "patch_embed: null pointer");
   CLIPMI_REQUIRE(image_dtype != CLIPMI_F32 || (scratch && (uintptr_t)scratch % 16 == 0), CLIPMI_ERR_ARG,
                  "patch_embed: an fp32 image needs a 16-byte aligned scratch buffer of patch_embed_scratch_bytes for its fp16 copy");
   CLIPMI_REQUIRE(image_dtype == CLIPMI_F16 || image_dtype == CLIPMI_F32, CLIPMI_ERR_ARG, "patch_embed: image dtype %d", image_dtype);
@@ -334,20 +159,15 @@ int launch_patch_embed(const void* image, int image_dtype, void* scratch, const 
     if (rc) return rc;
     image16 = static_cast<const half_t*>(scratch);
   }
-  PEArgs a;
-  a.image = image16; a.W = conv_w; a.ldw = ldw; a.pos = pos; a.out = x0; a.ldo = D;
-  a.M = B * G * G; a.N = D; a.K = 3 * P * P; a.R = R; a.P = P; a.G = G; a.GG = G * G; a.tokens = tokens;
-  const int tiles_m = (a.M + PE_BM - 1) / PE_BM;
-  a.tiles_n = (a.N + PE_BN - 1) / PE_BN;
-  a.band = a.tiles_n <= 6 ? a.tiles_n : 4;
-  const int64_t nwg = (int64_t)tiles_m * a.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "patch_embed: grid too large");
-  a.nwg = (int)nwg;
-  return x0_dtype == CLIPMI_F32 ? launch_pe<float>(a, s) : launch_pe<half_t>(a, s);
+  GemmArgs a{};
+  a.A = image16; a.lda = 3 * P * P; a.W = conv_w; a.ldw = ldw; a.out = x0; a.ldo = D; a.out_dtype = x0_dtype;
+  a.M = B * G * G; a.N = D; a.K = 3 * P * P; a.epilogue = EPI_PATCH_POS;
+  a.pos = pos; a.patches = G * G; a.tokens = tokens; a.im_R = R; a.im_P = P;
+  return launch_gemm(a, s);
 }
 
-int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma, const float* beta,
-                    float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s) {
+int launch_embed_ln(const void* x0, int x0_dtype, int add_pos, const float* cls, const float* pos, const float* shallow, const float* gamma,
+                    const float* beta, float* y, half_t* y16, float* stats_out, int B, int L, int tokens0, int D, float eps, hipStream_t s) {
   if (B == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x0 && cls && pos && gamma && beta && (y || y16), CLIPMI_ERR_ARG, "embed_ln: null pointer");
   CLIPMI_REQUIRE((!y16 && !stats_out) || (y16 && stats_out), CLIPMI_ERR_ARG, "embed_ln: y16 and stats_out come together");
@@ -358,7 +178,7 @@ int launch_embed_ln(const void* x0, int x0_dtype, const float* cls, const float*
   const dim3 grid((rows + 3) / 4), block(256);
   const bool wide = D / 4 > 64 * 4;
 #define ELN_LAUNCH(TI, NV) \
-  hipLaunchKernelGGL((embed_ln_kernel<TI, NV>), grid, block, 0, s, (const TI*)x0, cls, pos, shallow, gamma, beta, y, y16, stats_out, rows, L, tokens0, D, eps)
+  hipLaunchKernelGGL((embed_ln_kernel<TI, NV>), grid, block, 0, s, (const TI*)x0, cls, pos, shallow, gamma, beta, y, y16, stats_out, rows, L, tokens0, D, eps, add_pos)
   if (x0_dtype == CLIPMI_F32) { if (wide) ELN_LAUNCH(float, 16); else ELN_LAUNCH(float, 4); }
   else { if (wide) ELN_LAUNCH(half_t, 16); else ELN_LAUNCH(half_t, 4); }
 #undef ELN_LAUNCH

@@ -135,7 +135,8 @@ int clipmi_patchify(const void* image, int image_dtype, void* col, int B, int R,
  * (clip/model.py:598,395-397,401; conv1 has stride = kernel = P, so its im2col matrix is an address map of the NCHW image):
  *   x0[b * tokens + 1 + p, :] = sum_k pixel(b, p, k) * conv_w[:, k] + pos[1 + p, :]        p = py * (R/P) + px,  k = c*P*P + ky*P + kx
  * image [B,3,R,R] fp32 or fp16; an fp32 image is first cast to fp16 into `scratch` (clipmi_patch_embed_scratch_bytes bytes, 16-byte aligned;
- * NULL for an fp16 image); conv_w fp16 [D, ldw] = conv1.weight.reshape(D, 3*P*P) (ldw >= 3*P*P); pos fp32 [1 + (R/P)^2, D]; x0 fp16 or fp32
+ * NULL for an fp16 image); conv_w fp16 [D, ldw] = conv1.weight.reshape(D, 3*P*P) (ldw >= 3*P*P); pos fp32 [1 + (R/P)^2, D] or NULL (the bare conv
+ * output: clipmi_embed_ln then adds pos -- what clipmi_encode_image does, the positional rows cost this GEMM's epilogue 13 us); x0 fp16 or fp32
  * (x0_dtype) [B * tokens, D]: only the patch rows are written -- row 0 (class token) and rows beyond 1 + (R/P)^2 (prompt tokens) of every
  * sequence are left to clipmi_embed_ln.  fp16 operands, fp32 accumulation, pos added in fp32, one rounding.  Requires P in {8, 16, 32},
  * R % P == 0, D % 8 == 0, an fp16 image batch below 2 GB; 16-byte aligned pointers.  CLIPMI_ERR_SHAPE otherwise (clipmi_encode_image then
@@ -145,12 +146,12 @@ int clipmi_patch_embed(const void* image, int image_dtype, void* scratch, const 
                        int x0_dtype, int B, int R, int P, int D, int tokens, clipmi_stream_t stream);
 
 /* cat(class_embedding) + positional embedding of the class row + ln_pre over every token row (clip/model.py:398-402,413; MaPLe's shallow
- * prompt rows, :459-460), one wave per row:  row (b, l) = l == 0 ? cls + pos[0] : l < tokens0 ? x0[b * L + l] : shallow[l - tokens0];
- * out = LayerNorm(row) with fp32 statistics.  x0 fp16 / fp32 [B * L, D] as clipmi_patch_embed left it; cls fp32 [D]; pos fp32 [>= 1, D];
+ * prompt rows, :459-460), one wave per row:  row (b, l) = l == 0 ? cls + pos[0] : l < tokens0 ? x0[b * L + l] (+ pos[l] if add_pos) : shallow[l - tokens0];
+ * out = LayerNorm(row) with fp32 statistics.  x0 fp16 / fp32 [B * L, D] as clipmi_patch_embed left it; cls fp32 [D]; pos fp32 [tokens0, D];
  * shallow fp32 [L - tokens0, D] or NULL when L == tokens0; y fp32 [B * L, D] or NULL; y16 fp16 [B * L, D] + stats fp32 [B * L * 2]
  * ((sum, sum of squares) of each output row: the LayerNorm-fold partial the first in-projection consumes) or both NULL. */
-int clipmi_embed_ln(const void* x0, int x0_dtype, const float* cls, const float* pos, const float* shallow, const float* gamma,
-                    const float* beta, float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps,
+int clipmi_embed_ln(const void* x0, int x0_dtype, int add_pos, const float* cls, const float* pos, const float* shallow,
+                    const float* gamma, const float* beta, float* y, void* y16, float* stats, int B, int L, int tokens0, int D, float eps,
                     clipmi_stream_t stream);
 
 /* Row L2 normalisation  f / ||f||  (zsclip.py:99; coop.py:212-213): in (fp16|fp32) [rows,E] -> out fp32. */

@@ -269,7 +269,7 @@ def test_modified_resnet_boundary_surface():
         m.encode_image(torch.zeros(1, 3, 64, 64))                       # no CPU path
 
 
-MFMA_SOURCES = ("attention.hip", "logits.hip", "gemm.hip", "gemm_rstream.hip", "patch_embed.hip", "probe.hip")
+MFMA_SOURCES = ("attention.hip", "logits.hip", "gemm.hip", "gemm_rstream.hip", "probe.hip")
 
 
 def _hazard_scan():

@@ -352,6 +352,13 @@ def test_patch_embed_vs_conv2d(B, R, P, D, n_ctx, dt_in, dt_out):
           "clipmi_patch_embed")
     ref = F.conv2d(image.half().float(), w.float(), stride=P).reshape(B, D, G * G).permute(0, 2, 1) + pos[1:]
     got = x0.float().cpu().reshape(B, L, D)
+    if B == 2:                                            # pos = NULL: the bare conv output (what the image tower asks for)
+        x1 = torch.full_like(x0, float("nan"))
+        check(lib.clipmi_patch_embed(img_d.data_ptr(), idt, scratch.data_ptr() if dt_in == torch.float32 else None, wd.data_ptr(), 3 * P * P, None,
+                                     x1.data_ptr(), F32 if dt_out == torch.float32 else F16, B, R, P, D, L, torch.cuda.current_stream().cuda_stream),
+              "clipmi_patch_embed")
+        bare = x1.float().cpu().reshape(B, L, D)[:, 1:1 + G * G]
+        assert (bare - (ref - pos[1:])).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
     assert torch.isnan(got[:, 0]).all() and (n_ctx == 0 or torch.isnan(got[:, 1 + G * G:]).all())       # class / prompt rows untouched
     err = (got[:, 1:1 + G * G] - ref).abs().max().item()
     assert err < (2e-3 if dt_out == torch.float16 else 2e-5) * max(1.0, ref.abs().max().item()), err
@@ -359,7 +366,7 @@ def test_patch_embed_vs_conv2d(B, R, P, D, n_ctx, dt_in, dt_out):
 
 @pytest.mark.parametrize("B,L0,n_ctx,D,dt", [(3, 197, 0, 768, torch.float16), (2, 17, 2, 128, torch.float32), (5, 50, 4, 1024, torch.float16),
                                             (1, 5, 0, 1280, torch.float32)])
-@pytest.mark.parametrize("outs", ["y", "y16", "both"])
+@pytest.mark.parametrize("outs", ["y", "y16", "both", "both+pos"])
 def test_embed_ln_vs_layer_norm(B, L0, n_ctx, D, dt, outs):
     """clipmi_embed_ln: cat(class_embedding) + pos[0], the patch rows as the GEMM left them, MaPLe's shallow prompt rows, then ln_pre
     (clip/model.py:398-402,413,459-460) against F.layer_norm in fp32; the fold row sums are those of the output."""
@@ -371,15 +378,19 @@ def test_embed_ln_vs_layer_norm(B, L0, n_ctx, D, dt, outs):
     cls, pos = torch.randn(D, generator=g), torch.randn(L0, D, generator=g) * 0.2
     shallow = torch.randn(max(n_ctx, 1), D, generator=g)
     gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    add_pos = outs.endswith("+pos")                       # the image tower's form: the GEMM left the bare conv output, pos[l] is added here
+    outs = outs.split("+")[0]
     y = torch.full((B * L, D), float("nan"), device="cuda") if outs != "y16" else None
     y16 = torch.full((B * L, D), float("nan"), dtype=torch.float16, device="cuda") if outs != "y" else None
     stats = torch.full((B * L, 2), float("nan"), device="cuda") if outs != "y" else None
     dev = [t.cuda() for t in (x0, cls, pos, shallow, gamma, beta)]
     ptr = lambda t: None if t is None else t.data_ptr()
-    check(lib.clipmi_embed_ln(dev[0].data_ptr(), F32 if dt == torch.float32 else F16, dev[1].data_ptr(), dev[2].data_ptr(),
+    check(lib.clipmi_embed_ln(dev[0].data_ptr(), F32 if dt == torch.float32 else F16, int(add_pos), dev[1].data_ptr(), dev[2].data_ptr(),
                               dev[3].data_ptr() if n_ctx else None, dev[4].data_ptr(), dev[5].data_ptr(), ptr(y), ptr(y16), ptr(stats), B, L, L0, D,
                               1e-5, torch.cuda.current_stream().cuda_stream), "clipmi_embed_ln")
     rows = x0.float().reshape(B, L, D).clone()
+    if add_pos:
+        rows[:, 1:L0] += pos[1:]
     rows[:, 0] = cls + pos[0]
     if n_ctx:
         rows[:, L0:] = shallow[:n_ctx]
