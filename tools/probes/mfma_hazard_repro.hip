@@ -12,7 +12,9 @@
 //            'r' all operands in registers; 'l' the A operand re-read from LDS every step (ds_read_b64_tr_b16 pairs, as the V tiles are).
 // For each WS the table gives the victim launches (of N) whose output differs, and the hammer's own checksum against WS = 8 (the wave's
 // own result is expected to be right at every WS >= the 2 that hipcc guarantees; below that the sequence is illegal even for the wave
-// itself and is listed only to show where the hardware interlock ends).
+// itself and is listed only to show where the hardware interlock ends).  Hand-written sequences carry every hazard themselves: the first
+// version of this probe fed v_exp_f32 results straight into v_cvt_pk_f16_f32 -- the transcendental-result -> VALU-use hazard, which hipcc
+// pads and inline asm does not -- and a quarter of its own checksums changed from run to run at every WS.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void victim_kernel(const float* __restrict__ x
 // address the sub-registers of a 128-bit tuple).  NOPS = the s_nop text between the last write and the MFMA.
 #define HAMMER_STEP(NOPS)                                                                                                    \
   asm volatile("v_fma_f32 %[t0], %[s0], %[c], %[m]\n\tv_fma_f32 %[t1], %[s1], %[c], %[m]\n\t"                                 \
-               "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\t"                                                        \
+               "v_exp_f32 %[t0], %[t0]\n\tv_exp_f32 %[t1], %[t1]\n\ts_nop 1\n\t" /* trans result -> VALU use: its own wait states */   \
                "v_cvt_pk_f16_f32 v124, %[t0], %[t1]\n\tv_cvt_pk_f16_f32 v125, %[t1], %[t0]\n\t"                               \
                "v_cvt_pk_f16_f32 v126, %[t0], %[t0]\n\tv_cvt_pk_f16_f32 v127, %[t1], %[t1]\n\t" NOPS                          \
                "v_mfma_f32_32x32x16_f16 %[acc], %[a], v[124:127], %[acc]\n\t"                                                 \
@@ -156,6 +158,12 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(sh));
       CK(hipMemcpy((ws == 8 ? hsink8 : hsink).data(), sink, hsink.size() * 4, hipMemcpyDeviceToHost));
       const bool own_ok = ws == 8 || memcmp(hsink.data(), hsink8.data(), hsink.size() * 4) == 0;
+      if (getenv("REPRO_DEBUG")) {
+        const float* h = (ws == 8 ? hsink8 : hsink).data();
+        size_t nd = 0;
+        for (size_t i = 0; i < hsink.size(); ++i) nd += memcmp(&hsink8[i], &h[i], 4) != 0;
+        printf("   ws %d: sink[0..3] = %.9g %.9g %.9g %.9g | sink[64] = %.9g | %zu of %zu words differ from ws 8\n", ws, h[0], h[1], h[2], h[3], h[64], nd, hsink.size());
+      }
       int bad = 0;
       long long bad_words = 0;
       for (int l = 0; l < launches; ++l) {
