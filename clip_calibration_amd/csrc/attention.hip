@@ -827,6 +827,8 @@ int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int caus
   const int n_cu = device_cus();
   const int nqt = (L + 31) / 32;
   const int nw = nqt < 4 ? 4 : nqt;                  // <= 7 here
+  // (three workgroups per CU fit the three-key-tile instantiations -- 48 KiB, 146-153 VGPRs -- and were measured: no faster,
+  // profiles/r04_text_attention.txt)
   const int per_cu = SMEM <= 80 * 1024 ? 2 : 1;
   const int n_items = N * H;
   const int grid = n_items < n_cu * per_cu ? n_items : n_cu * per_cu;
