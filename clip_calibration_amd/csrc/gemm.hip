@@ -1227,7 +1227,9 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
   static DeviceOnce attr_once;
   auto fn = gemm_stream_kernel<EPI>;
   ensure_dynamic_lds(fn, SMEM, attr_once);
-  const int n_cu = device_cus() & ~7;   // the XCD label of a virtual block id must not change across rounds
+  // the XCD label of a virtual block id must not change across rounds: a grid that is a multiple of 8.  A device (partition) with fewer than 8
+  // CUs never gets here: stream_offsets_ok() -- part of launch_one's `fits` and required again below -- sends it to the tile kernels.
+  const int n_cu = device_cus() & ~7;
   const int tiles_m = (k.M + T::BM - 1) / T::BM;
   k.tiles_n = (k.N + T::BN - 1) / T::BN;
   k.band = pick_band(k.tiles_n, T::BN, k.K);
