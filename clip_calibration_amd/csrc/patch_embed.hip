@@ -10,11 +10,11 @@
 // k) is 8 consecutive fp16 pixels of one image row, and a 64-deep K-step is 64 / P whole row segments of one channel: the operand is staged by
 // LDS-DMA (buffer_load ... lds) exactly like a dense GEMM's, with the per-lane source offset = patch origin + (ky, kx) of the slot and the
 // scalar offset = (channel, first ky) of the K-step.  No im2col matrix is written or read (77 MB each way at batch 256) and the GEMM's
-// loader moves the same bytes the im2col GEMM's did.  The epilogue adds the positional embedding in fp32 and stores the token rows -- in
-// fp16 through a wave-private LDS transpose (16 B per lane, 128 contiguous bytes per row) when the residual stream is fp16 (the reference's
-// own GPU path holds the conv output, the class token and the positional sum in fp16: clip/model.py:395-401 on a convert_weights model), in
-// fp32 when the stream is fp32.  The class row and MaPLe's shallow prompt rows are the same for every image and never pass through memory:
-// embed_ln_kernel forms them on the fly; it is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same butterfly) with those
+// loader moves the same bytes the im2col GEMM's did.  The epilogue stores the token rows -- in fp16 through a wave-private LDS transpose (16 B
+// per lane, 128 contiguous bytes per row) when the residual stream is fp16 (the reference's own GPU path holds the conv output in fp16:
+// clip/model.py:395-397 on a convert_weights model), in fp32 when the stream is fp32 -- and can add the positional rows; the image tower lets
+// embed_ln_kernel add them instead (fp32, before the statistics).  The class row and MaPLe's shallow prompt rows are the same for every image
+// and never pass through memory: embed_ln_kernel forms them on the fly; it is layernorm_kernel's arithmetic (two-pass statistics in fp32, the same butterfly) with those
 // three row sources and the outputs the blocks want (fp32 stream and / or fp16 operand copy + the LayerNorm-fold row sums of the output).
 //
 // Why the cast is its own pass (profiles/r04_patch_embed.txt): the first form of the GEMM staged fp32 pixels THROUGH REGISTERS (two
@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void cast_image_kernel(const float* __restrict
 //   1 <= l < tokens0  x0[b, l, :] as the GEMM left it (fp16 or fp32) (+ pos[l] when add_pos: clip/model.py:401)
 //   l >= tokens0      shallow[l - tokens0, :]          (MaPLe's shallow prompt tokens, clip/model.py:459-460: appended after pos is added)
 // Outputs: y (fp32 stream, optional) and / or y16 + stats (fp16 operand copy + LayerNorm-fold row sums of the output, partial 0).
+// One row per wave, gamma / beta / pos re-read from L2 per row: measured against several rows per wave with gamma / beta held in registers
+// (6 KB less L2 traffic per row): 43.7 us against 58.8 (one row, 32 more registers) and 62.7 us (four rows) -- latency hiding by many small
+// waves beats the saved bytes (profiles/r04_patch_embed.txt).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float eln_wave_sum(float v) {
 #pragma unroll
