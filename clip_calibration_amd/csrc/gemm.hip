@@ -1486,224 +1486,9 @@ int launch_pp(KArgs k, hipStream_t s) {
   return check_launch("gemm_pp_kernel");
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// gemm_pp_kernel with a FOUR-SLOT RING OF HALF STAGES (variant 17; VERDICT r03 task 5).  The ping-pong loop above keeps ONE 64-deep stage in
-// flight: its last DMA pieces go out in phase 2 of K-step k and every wave waits for them at the end of K-step k, two slots later -- phase
-// stamps and the no-DMA ablation put ~400-600 cycles of every 3,200-cycle K-step of c_proj into that wait.  Here the LDS image is cut along K:
-// a half stage = the 32-deep k-half one phase pair reads = (BM + BN) rows x 64 B (36,864 B for the 320 x 256 tile), FOUR slots (the same
-// 147,456 B as two whole stages).  While half stage g is being read, g + 1 and g + 2 have been issued earlier and g + 3 is being issued (into
-// the slot of g - 1, whose last reads are a barrier behind): a piece has one and a half K-steps to land instead of at most one, and each wave
-// waits with a COUNTED vmcnt that leaves the two youngest half stages in flight.  Same phases, same barriers, same K order and MFMA as
-// gemm_pp_kernel: bit-identical results.  64-byte LDS rows: a DMA piece is 16 rows x 64 B, data chunk c of row r sits at slot c ^ ((r >> 1) & 3)
-// (conflict-free for ds_read_b128: brute-forced over the instruction's four 16-lane groups).
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(T::NT, T::OCC) void gemm_pph_kernel(const KArgs a) {
-  constexpr int BM = T::BM, NT = T::NT, TM = T::TM, TN = T::TN, H = TM / 2;
-  static_assert(T::NW == 8 && TN == 4 && TM % 2 == 0 && T::WTN == 64, "ping-pong loop: eight waves of (16 TM) x 64");
-  constexpr int XH = BM * 64, WH = T::BN * 64, HS = XH + WH;   // one half stage
-  constexpr int XP = BM / 16, WP = T::BN / 16;                 // 1 KiB DMA pieces per half stage and operand
-  static_assert(XP == 20 && WP == 16 && 4 * HS == T::SMEM, "piece plan: waves 0-3 issue 3 + 2, waves 4-7 issue 2 + 2 pieces per half stage");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
-  const int grp = wave >> 2;   // uniform: waves w and w + 4 share a SIMD
-
-  int tile_m, tile_n;
-  tile_coords(a, a.nwg / a.tiles_n, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * T::BN;
-
-  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)m0 * a.lda, ((int64_t)(a.M - m0) * a.lda) * 2);
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-  // DMA: lane -> row (lane >> 2) of the piece's 16 rows, LDS slot (lane & 3) of that row = data chunk (lane & 3) ^ ((row >> 1) & 3)
-  const int prow = lane >> 2, pchunk = (lane & 3) ^ ((lane >> 3) & 3);
-  const int xoff0 = (prow * (int)a.lda + pchunk * 8) * 2, woff0 = (prow * (int)a.ldw + pchunk * 8) * 2;
-  const int xstep = 16 * (int)a.lda * 2, wstep = 16 * (int)a.ldw * 2;   // one piece further
-  auto row_off = [](int base, int add) {
-    int r;
-    asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
-    return r;
-  };
-  // piece I (0 .. 4) of this wave in half stage g: 0, 1 = weight pieces wave, wave + 8; 2, 3, 4 = activation pieces wave, wave + 8, wave + 16
-  // (the last only on waves 0-3: 20 pieces)
-  auto piece = [&](auto i_tag, int g) {
-    constexpr int I = decltype(i_tag)::value;
-    char* slot = smem + (g & 3) * HS;
-    const int k0 = g * 64;   // bytes: 32 k per half stage
-    if constexpr (I < 2) CLIPMI_BUFFER_LOAD_LDS16(wrs, slot + XH + (wave + 8 * I) * 1024, row_off(woff0, (wave + 8 * I) * wstep), k0);
-    else CLIPMI_BUFFER_LOAD_LDS16(xrs, slot + (wave + 8 * (I - 2)) * 1024, row_off(xoff0, (wave + 8 * (I - 2)) * xstep), k0);
-  };
-  auto issue_half = [&](int g) {   // the whole half stage at once (prologue only)
-    piece(std::integral_constant<int, 0>{}, g); piece(std::integral_constant<int, 1>{}, g);
-    piece(std::integral_constant<int, 2>{}, g); piece(std::integral_constant<int, 3>{}, g);
-    if (grp == 0) piece(std::integral_constant<int, 4>{}, g);
-  };
-
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t fl = (uint32_t)(r16 * 64 + ((g4 ^ ((r16 >> 1) & 3)) << 4));
-  const uint32_t xb = (uint32_t)(wave_m * T::WTM * 64) + fl, wb = (uint32_t)(XH + wave_n * T::WTN * 64) + fl;
-  const int nk = a.K / BK;
-  const int nh = 2 * nk;   // half stages
-
-#ifdef CLIPMI_TUNING
-  const bool stamp = a.stamps != nullptr && tid == 0;
-  if (stamp) {
-    a.stamps[blockIdx.x * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
-    a.stamps[blockIdx.x * 8 + 5] = (long long)__smid();
-  }
-#endif
-  // ---- prologue: half stages 0, 1, 2 (nk >= 2: at least four exist), and (LayerNorm-fold consumers) the tile's row parameters
-  issue_half(0);
-  issue_half(1);
-  issue_half(2);
-  float2* lnp = nullptr;
-  if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-    if (a.ln_stats) {   // block-uniform
-      lnp = reinterpret_cast<float2*>(smem + T::SMEM);
-      for (int t = tid; t < BM; t += NT) {
-        float rs, mrs;
-        ln_row_params(a, m0 + t, rs, mrs);
-        lnp[t] = make_float2(rs, mrs);
-      }
-    }
-  }
-  if (grp == 0) wait_vmcnt<10>(); else wait_vmcnt<8>();   // half stage 0 has landed; 1 and 2 stay in flight
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#ifdef CLIPMI_TUNING
-  if (stamp) {
-    a.stamps[blockIdx.x * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-    a.stamps[blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
-  }
-#endif
-
-  f32x4 acc[TN][TM];
-  // R = K-steps that follow this one, capped at 2: which of the half stages g + 1, g + 2, g + 3 exist is then known at compile time
-  auto kstep = [&](auto first_tag, auto r_tag, int kt) {
-    constexpr bool FIRSTK = decltype(first_tag)::value;
-    constexpr int R = decltype(r_tag)::value;
-    f16x8 wf[4], xf[H];
-    auto phase = [&](auto p_tag) {
-      constexpr int P = decltype(p_tag)::value;
-      constexpr int KS = P >> 1, JH = P & 1;
-      constexpr bool HAS3 = KS + 3 <= 2 * R + 1, HAS2 = KS + 2 <= 2 * R + 1, HAS1 = KS + 1 <= 2 * R + 1;
-      constexpr int INFLIGHT = (HAS2 ? 1 : 0) + (HAS3 ? 1 : 0);   // half stages younger than g + 1 whose pieces this wave has issued
-      const int g = 2 * kt + KS;
-      const uint32_t sb = lds_base + (uint32_t)((g & 3) * HS);
-      // ---- load part
-      {
-        const uint32_t xa = sb + xb;
-        ds_read128<(JH * H + 0) * 1024>(xf[0], xa);
-        ds_read128<(JH * H + 1) * 1024>(xf[1], xa);
-        ds_read128<(JH * H + 2) * 1024>(xf[2], xa);
-        ds_read128<(JH * H + 3) * 1024>(xf[3], xa);
-        if constexpr (H == 5) ds_read128<(JH * H + 4) * 1024>(xf[H - 1], xa);
-        if constexpr (JH == 0) {
-          const uint32_t wa = sb + wb;
-          ds_read128<0>(wf[0], wa);
-          ds_read128<1024>(wf[1], wa);
-          ds_read128<2048>(wf[2], wa);
-          ds_read128<3072>(wf[3], wa);
-        }
-      }
-      if constexpr (HAS3 && !(CLIPMI_ABLATE & 2)) {   // this wave's pieces of half stage g + 3 -> the slot of g - 1 (last read a barrier ago)
-        if constexpr (JH == 0) {
-          piece(std::integral_constant<int, 0>{}, g + 3);
-          piece(std::integral_constant<int, 1>{}, g + 3);
-          piece(std::integral_constant<int, 2>{}, g + 3);
-        } else {
-          piece(std::integral_constant<int, 3>{}, g + 3);
-          if (grp == 0) piece(std::integral_constant<int, 4>{}, g + 3);
-        }
-      }
-      if constexpr (JH == 0) lgkm_wait4<0>(wf[0], wf[1], wf[2], wf[3]);
-      lgkm_wait_x<0, H>(xf);
-      if constexpr (JH == 1 && HAS1) {   // group 1: its pieces of half stage g + 1 have landed (one barrier before the first read)
-        if (grp == 1) wait_vmcnt<4 * INFLIGHT>();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- compute part: registers only, accumulators tied to the destination
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          if constexpr (FIRSTK && KS == 0)
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
-          else
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * H + j]) : "v"(wf[i]), "v"(xf[j]));
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if constexpr (JH == 1 && HAS1) {
-        if (grp == 0) wait_vmcnt<5 * INFLIGHT>();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    phase(std::integral_constant<int, 0>{});
-    phase(std::integral_constant<int, 1>{});
-    phase(std::integral_constant<int, 2>{});
-    phase(std::integral_constant<int, 3>{});
-  };
-  (void)nh;
-
-  constexpr std::false_type no{};
-  constexpr std::true_type yes{};
-  using R0 = std::integral_constant<int, 0>;
-  using R1 = std::integral_constant<int, 1>;
-  using R2 = std::integral_constant<int, 2>;
-  if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 start one part later
-  if (nk >= 3) {
-    kstep(yes, R2{}, 0);
-    for (int kt = 1; kt < nk - 2; ++kt) kstep(no, R2{}, kt);
-    kstep(no, R1{}, nk - 2);
-  } else {
-    kstep(yes, R1{}, 0);                          // nk == 2 (checked by the launcher)
-  }
-  kstep(no, R0{}, nk - 1);
-  if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and waves 0-3 wait out the last compute part of waves 4-7
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
-#ifdef CLIPMI_TUNING
-  if (stamp) {
-    a.stamps[blockIdx.x * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-    a.stamps[blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
-  }
-#endif
-  epilogue<T, EPI, OUT_F32, true>(acc, a, m0, n0, wave_m, wave_n, lane, wave, smem, lnp);
-#ifdef CLIPMI_TUNING
-  if (a.stamps != nullptr) {
-    if (stamp) a.stamps[blockIdx.x * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (stamp) a.stamps[blockIdx.x * 8 + 4] = (long long)__builtin_amdgcn_s_memrealtime();
-  }
-#endif
-}
-
-template <typename T, int EPI, bool OUT_F32>
-int launch_pph(KArgs k, hipStream_t s) {
-  static DeviceOnce attr_once;
-  auto fn = gemm_pph_kernel<T, EPI, OUT_F32>;
-  constexpr int SMEM_MAIN = T::SMEM + T::BM * (int)sizeof(float2);
-  constexpr int SMEM_EPI = (EPI == EPI_RESIDUAL_FOLD16 && T::WTN == 64) ? FoldDma<T>::LDS : 0;
-  constexpr int SMEM = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
-  static_assert(SMEM <= 160 * 1024, "tile does not fit the CU's LDS");
-  ensure_dynamic_lds(fn, SMEM, attr_once);
-  const int tiles_m = (k.M + T::BM - 1) / T::BM;
-  k.tiles_n = (k.N + T::BN - 1) / T::BN;
-  k.band = pick_band(k.tiles_n, T::BN, k.K);
-  const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
-  CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  k.nwg = (int)nwg;
-  hipLaunchKernelGGL(fn, dim3(k.nwg), dim3(T::NT), SMEM, s, k);
-  return check_launch("gemm_pph_kernel");
-}
+// (Round 4 built this loop on a four-slot ring of HALF stages -- (BM + BN) rows x 64 B, 16-row DMA pieces, three half stages in flight behind a
+// counted vmcnt -- to let a piece fly one and a half K-steps instead of one: bit-identical, 5-7 % slower on every GEMM of the block.  Record:
+// profiles/r04_cproj_half_stage_ring.txt.)
 
 using T128 = Tile<128, 128, 2, 2, 2>;      // 4 waves of 64x64, 64 KiB LDS, 2 workgroups / CU
 using T256w16 = Tile<256, 256, 4, 4, 4>;   // 16 waves of 64x64, 128 KiB LDS, 1 workgroup / CU, 4 waves / SIMD
@@ -1725,7 +1510,7 @@ using T320w8 = Tile<320, 256, 2, 4, 2>;    // 8 waves of 160x64: 474 tiles at M=
 int pick_variant(const KArgs& k) {
   const int forced = options().gemm_variant.load(std::memory_order_relaxed);   // -1 unless a test / tuning run forces one
   if (forced == 0 || forced == 1 || forced == 13 || forced == 16) return forced;
-  if (forced == 10 || forced == 17) return k.K >= 2 * BK ? forced : 1;
+  if (forced == 10) return k.K >= 2 * BK ? 10 : 1;
   struct Cand { int id, bm, bn, per_cu; double penalty; };
   static const Cand cands[] = {{1, 256, 256, 1, 1.00}, {10, 320, 256, 1, 1.03}, {0, 128, 128, 2, 1.12}};
   const int cus = device_cus();
@@ -1868,7 +1653,6 @@ template <typename Tl, int EPI, bool OUT_F32>
 int launch_by_variant(int variant, const KArgs& k, hipStream_t s) {
   switch (variant) {
     case 10: return launch_pp<T320w8, EPI, OUT_F32>(k, s);
-    case 17: return launch_pph<T320w8, EPI, OUT_F32>(k, s);
     case 0: return launch_tile<T128, EPI, OUT_F32>(k, s);
     default: return launch_tile<T256w16, EPI, OUT_F32>(k, s);
   }
