@@ -559,6 +559,7 @@ def main():
         # the reference's schedule: prompt learner + text tower on every batch (coop.py:208-210).  The mirror's cache_text_features=False
         # runs that per-batch tower call on the fp16 residual stream (per-call flag; the cached features above keep the fp32 stream)
         per_batch = CoOpCLIP(model, ids_new, n_ctx=n_ctx, logit_scale=1.0, seed=3, cache_text_features=False)
+        per_batch.overlap_towers = os.environ.get("BENCH_OVERLAP_TOWERS", "1") == "1"   # text tower on a side stream beside the image tower
         text_again = per_batch.text_features
         with torch.no_grad():
             text_s = timed_ms(text_fp32_stream, 5) * 1e-3
@@ -600,6 +601,9 @@ def main():
         return ops.fused_tail(feats, txt, scale, dac_conf, True, True, labels, bins, n_bins)
 
     def step(labels, recompute_text=False):
+        if recompute_text and world == 1 and shards is None:   # the reference's per-batch schedule: both towers of the batch (CoOpCLIP.towers)
+            feats, txt = per_batch.towers(images)
+            return tail(feats, labels, txt)
         txt = text_again() if recompute_text else text_features
         if shards is not None:
             emb = torch.cat([ops.l2_normalize(model.image_features_f32(x), torch.float16) for x in shards])

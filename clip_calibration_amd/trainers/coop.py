@@ -141,10 +141,34 @@ class CustomCLIP(nn.Module):
     def _image_features(self, image: torch.Tensor) -> torch.Tensor:
         return self.clip_model.image_features_f32(image)
 
+    overlap_towers: bool = True   # per-batch text tower (cache_text_features=False): run it on a side stream beside the image tower
+
+    @torch.no_grad()
+    def towers(self, image: torch.Tensor):
+        """(image features fp32 un-normalised, text features fp32 normalised) of one batch.  With the reference's per-batch schedule
+        (coop.py:208-210: prompt learner + text tower on every batch) the two towers are independent until the logits, so the text tower
+        is issued on a side stream and the image tower on the caller's; the caller's stream then waits for the side stream.  They use
+        separate workspaces (the model's "text" and "vision" buffers)."""
+        if self.cache_text_features or not self.overlap_towers or not image.is_cuda:
+            text_features = self.text_features()
+            return self._image_features(image), text_features
+        cur = torch.cuda.current_stream(image.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != image.device:
+            side = torch.cuda.Stream(device=image.device)
+            object.__setattr__(self, "_side_stream", side)
+        side.wait_stream(cur)                       # the prompt learner's parameters may have been written on the caller's stream
+        with torch.cuda.stream(side):
+            text_features = self.text_features()
+        image_features = self._image_features(image)
+        cur.wait_stream(side)
+        text_features.record_stream(cur)
+        return image_features, text_features
+
     @torch.no_grad()
     def forward(self, image: torch.Tensor, label=None, dac_conf: Optional[torch.Tensor] = None, want_conf_pred: bool = False):
-        text_features = self.text_features()
-        logits, image_features, conf, pred = ops.fused_tail(self._image_features(image), text_features, self.scale, dac_conf,
+        image_features_raw, text_features = self.towers(image)
+        logits, image_features, conf, pred = ops.fused_tail(image_features_raw, text_features, self.scale, dac_conf,
                                                             want_conf_pred)
         if want_conf_pred:
             return logits, image_features, text_features, conf, pred

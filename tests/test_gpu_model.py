@@ -217,6 +217,29 @@ def test_zeroshot_pipeline_vs_oracle(B):
         assert top2[1] - top2[0] < 2 * 100 * COS_TOL
 
 
+def test_coop_per_batch_towers_on_two_streams_same_bits():
+    """CoOpCLIP(cache_text_features=False) -- the reference's schedule, prompt learner + text tower on every batch (coop.py:208-210) --
+    issues the text tower on a side stream beside the image tower (CustomCLIP.towers): independent work on separate workspaces, joined
+    before the logits.  Outputs are bit-identical to the one-stream order, batch after batch (8 batches: a stale or half-written text
+    feature row would show), and to a second model-level call after a ctx update."""
+    from clip_calibration_amd.trainers import CoOpCLIP
+    sd, model = _build("tiny")
+    ids = syn.synthetic_token_ids(24, "tiny", seed=5, n_ctx_placeholders=4)
+    a = CoOpCLIP(model, ids, n_ctx=4, seed=1, cache_text_features=False)
+    b = CoOpCLIP(model, ids, n_ctx=4, seed=1, cache_text_features=False)
+    b.overlap_towers = False
+    for k in range(8):
+        images = syn.synthetic_images(9, "tiny", seed=20 + k).cuda()
+        if k == 4:
+            with torch.no_grad():
+                a.prompt_learner.ctx.mul_(1.5)
+                b.prompt_learner.ctx.mul_(1.5)
+        la, ia, ta, ca, pa = a(images, want_conf_pred=True)
+        lb, ib, tb, cb, pb = b(images, want_conf_pred=True)
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb) and torch.equal(ta, tb) and torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(pa, pb), f"batch {k}"
+
+
 @pytest.mark.parametrize("cached", [True, False])
 def test_coop_dac_tempscaling_pipeline_vs_oracle(cached):
     """BASELINE config 3 (scaled down in C): CoOp prompts -> cached text features; DAC fit on the four text-feature
