@@ -325,10 +325,13 @@ class CLIP(nn.Module):
         return v.value
 
     def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
-        ws = self._ws.get(kind)
+        """Tower workspace of the CURRENT stream: launches on one stream run in order and may share a buffer; two tower calls in flight on
+        different streams (batches pipelined over two streams, the text tower beside the image tower) must not."""
+        key = (kind, torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0)
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes or ws.device != self.device:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws[kind] = ws
+            self._ws[key] = ws
         return ws
 
     def _hook(self, n_ctx: int, shallow: Optional[torch.Tensor], deep: Optional[Sequence[torch.Tensor]], max_deep: int):
