@@ -166,7 +166,7 @@ class CLIP(nn.Module):
         self._init_ivlp_prompts()
         self._handle: Optional[int] = None
         self._bound = None          # keeps the packed tensors + ctypes arrays alive
-        self._ws: Dict[str, torch.Tensor] = {}
+        self._ws: Dict[tuple, torch.Tensor] = {}   # (kind, stream) -> workspace, LRU-bounded (_workspace)
 
     # ---- IVLP / VPT design (clip/model.py:191-256, 334-346, 361-381) -------------------------------------------
     def _init_ivlp_prompts(self) -> None:
@@ -328,10 +328,12 @@ class CLIP(nn.Module):
         """Tower workspace of the CURRENT stream: launches on one stream run in order and may share a buffer; two tower calls in flight on
         different streams (batches pipelined over two streams, the text tower beside the image tower) must not."""
         key = (kind, torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes or ws.device != self.device:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws[key] = ws
+        self._ws[key] = ws                       # (re-inserted last: the dict is the LRU order)
+        while len(self._ws) > 8:                 # short-lived streams must not pin workspaces for ever
+            self._ws.pop(next(iter(self._ws)))
         return ws
 
     def _hook(self, n_ctx: int, shallow: Optional[torch.Tensor], deep: Optional[Sequence[torch.Tensor]], max_deep: int):
