@@ -67,6 +67,33 @@ def test_golden_tiny(gname, fname):
     assert np.array_equal(pred.cpu().numpy(), g["logits"].argmax(1))
 
 
+@pytest.mark.parametrize("what", ["ViT-B/32", "patch 8", "patch 32, fp32 stream", "patch 16, 3 images of 96 px"])
+def test_image_tower_patch_sizes_vs_oracle(what, clipmi_option):
+    """The patch embedding reads the NCHW image in the GEMM's loader (gemm_pp_kernel<IM2COL>: 64 / P row segments of one channel per K-step) for
+    patch sizes 8, 16 and 32 -- 8, 4 and 2 segments per step, 1 / 4 / 16 K-steps per channel -- with ragged patch counts and both stream
+    precisions; ViT-B/32 at full depth.  Image features against the fp32 oracle (clip/model.py:394-424)."""
+    if what == "ViT-B/32":
+        geom, n = syn.GEOMETRIES["ViT-B/32"], 6
+    elif what == "patch 8":
+        geom, n = syn.ClipGeometry(64, 40, 2, 128, 8, 77, 256, 128, 2, 2), 7          # 5 x 5 grid: 26 tokens
+    elif what.startswith("patch 32"):
+        geom, n = syn.ClipGeometry(64, 96, 2, 192, 32, 77, 256, 128, 2, 2), 5         # 3 x 3 grid: 10 tokens
+        clipmi_option("residual_f16", 0)
+    else:
+        geom, n = syn.ClipGeometry(64, 96, 3, 128, 16, 77, 256, 128, 2, 2), 3         # 6 x 6 grid: 37 tokens
+    from clip_calibration_amd.model import build_model
+    sd = syn.synthetic_state_dict(geom, seed=2)
+    model = build_model(dict(sd), dict(PLAIN)).cuda()
+    images = syn.synthetic_images(n, geom, seed=4)
+    with torch.no_grad():
+        got = model.image_features_f32(images.cuda()).cpu().numpy()
+        got16 = model.image_features_f32(images.half().cuda()).cpu().numpy()           # an fp16 image: no cast pass
+        ref = orc.encode_image(sd, images).numpy()
+        ref16 = orc.encode_image(sd, images.half().float()).numpy()
+    _feat_close(got, ref, what)
+    _feat_close(got16, ref16, what + " (fp16 image)")
+
+
 @pytest.mark.parametrize("gname,fname", [("tiny", "tiny_clip.npz"), ("tiny3", "tiny3_clip.npz")])
 def test_golden_coop_text_encoder_both_call_styles(gname, fname):
     g = load_golden(fname)
