@@ -440,14 +440,15 @@ def launch_ranks(n, argv):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+    # The launcher asks for SIGTERM if this process dies, however it dies (PR_SET_PDEATHSIG = 1; torch.distributed.run answers SIGTERM by
+    # stopping its workers).  It sets that itself, first thing in its own single-threaded start-up: a preexec_fn would run between fork and
+    # exec of THIS process, which has imported torch and numpy and may own threads (subprocess documents that as unsafe).
+    boot = ("import ctypes, runpy, signal, sys; ctypes.CDLL(None).prctl(1, signal.SIGTERM); sys.argv[0] = 'torch.distributed.run'; "
+            "runpy.run_module('torch.distributed.run', run_name='__main__', alter_sys=True)")
+    cmd = [sys.executable, "-c", boot, "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-
-    def die_with_parent():                                       # the launcher gets SIGTERM if this process dies, however it dies;
-        import ctypes                                            # torch.distributed.run answers SIGTERM by stopping its workers
-        ctypes.CDLL(None).prctl(1, signal.SIGTERM)               # PR_SET_PDEATHSIG
     # same process group as this process (no new session): a `kill -- -pgid` or a `timeout` aimed at bench.py reaches the ranks too
-    child = subprocess.Popen(cmd, env=env, preexec_fn=die_with_parent)
+    child = subprocess.Popen(cmd, env=env)
 
     def forward(signum, _frame):
         child.send_signal(signal.SIGTERM)
@@ -472,6 +473,8 @@ def main():
     if args.gpus > 1 and world == 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher of its N ranks (nothing below this line runs here)
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if world > 1:
+        print(f"[bench rank {rank} of {world}] started (local rank {local_rank})", file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), f"bench.py needs a GPU (no CPU fallback) [rank {rank} of {world}]"
     # BENCH_SAME_GPU=1 is a functional self-test of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the
     # exchange goes through torch.distributed/gloo (RCCL refuses two ranks on one device).  Never a measurement.

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLIPMI_LIBRARY") or os.path.join(_HERE, "csrc", "libclipmi.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "clipmi.h")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_WORKSPACE, ERR_STATE = 0, -1, -2, -3, -4, -5
 F16, F32 = 0, 1
@@ -111,13 +111,13 @@ _SIGNATURES = {
     "clipmi_set_vision_weights": (_i, [_vp, C.POINTER(VisionWeights)]),
     "clipmi_set_text_weights": (_i, [_vp, C.POINTER(TextWeights)]),
     "clipmi_vision_workspace_bytes": (_sz, [_vp, _i, _i]),
-    "clipmi_text_workspace_bytes": (_sz, [_vp, _i]),
+    "clipmi_text_workspace_bytes": (_sz, [_vp, _i, _i]),
     "clipmi_model_set_option": (_i, [_vp, C.c_char_p, _i]),
     "clipmi_model_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "clipmi_encode_image": (_i, [_vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
     "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _u, _vp]),
-    "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
-    "clipmi_encode_text": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _u, _vp]),
+    "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
+    "clipmi_encode_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _u, _vp]),
     "clipmi_profile_block": (_i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),
     "clipmi_encode_image_timed": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _u, C.POINTER(_f), _i, C.POINTER(_i), _vp]),
     "clipmi_probe_mfma_f16": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_i), _vp]),

@@ -312,8 +312,9 @@ int check_hook(const clipmi_prompt_hook* hook, int layers, bool vision) {
 }
 
 // text blocks on w.xres (already holds embeddings + pos)
-int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, const clipmi_prompt_hook* hook, bool folded, bool f16res, hipStream_t s) {
-  const int L = m->g.context_length, D = m->g.text_width;
+// L = token rows per prompt that are computed (the whole context, or the caller's seq_rows: see include/clipmi.h clipmi_text_encoder)
+int run_text_blocks(clipmi_model* m, const TowerWs& w, int C, int L, const clipmi_prompt_hook* hook, bool folded, bool f16res, hipStream_t s) {
+  const int D = m->g.text_width;
   int rc, parts = 1;
   if (folded && (rc = launch_row_stats(w.xres, w.xn, w.stats, 1, C, L, D, 0, L, s))) return rc;   // input rows of block 0
   for (int i = 0; i < m->g.text_layers; ++i) {
@@ -340,7 +341,10 @@ int run_text_tail(clipmi_model* m, const TowerWs& w, int C, float* out, bool f16
   return launch_gemm(a, s);
 }
 
-int text_prologue(clipmi_model* m, int n_prompts, const clipmi_prompt_hook* hook, void* ws, size_t ws_bytes, unsigned flags, TowerWs* w,
+// rows of a prompt the tower works on: the caller's bound on the last live token (dead-row elimination), else the whole context
+int live_rows(const clipmi_model* m, int seq_rows) { return seq_rows > 0 && seq_rows < m->g.context_length ? seq_rows : m->g.context_length; }
+
+int text_prologue(clipmi_model* m, int n_prompts, int seq_rows, const clipmi_prompt_hook* hook, void* ws, size_t ws_bytes, unsigned flags, TowerWs* w,
                   bool* folded, bool* f16res) {
   CLIPMI_REQUIRE(m, CLIPMI_ERR_ARG, "null model");
   CLIPMI_REQUIRE(m->has_text, CLIPMI_ERR_STATE, "text weights not bound (clipmi_set_text_weights)");
@@ -354,8 +358,9 @@ int text_prologue(clipmi_model* m, int n_prompts, const clipmi_prompt_hook* hook
   CLIPMI_REQUIRE((int64_t)n_prompts * m->g.context_length < (1ll << 31), CLIPMI_ERR_SHAPE, "too many prompt tokens");
   int rc = check_hook(hook, m->g.text_layers, false);
   if (rc) return rc;
-  if (hook) CLIPMI_REQUIRE(1 + hook->n_ctx <= m->g.context_length, CLIPMI_ERR_SHAPE, "prompt hook: n_ctx too large");
-  *w = carve(ws, (int64_t)n_prompts * m->g.context_length, m->g.text_width, n_prompts);
+  const int L = live_rows(m, seq_rows);
+  if (hook) CLIPMI_REQUIRE(1 + hook->n_ctx <= L, CLIPMI_ERR_SHAPE, "prompt hook: n_ctx=%d does not fit the %d token rows that are computed", hook->n_ctx, L);
+  *w = carve(ws, (int64_t)n_prompts * L, m->g.text_width, n_prompts);
   CLIPMI_REQUIRE(ws || n_prompts == 0, CLIPMI_ERR_ARG, "null workspace");
   CLIPMI_REQUIRE(ws_bytes >= w->bytes, CLIPMI_ERR_WORKSPACE, "text workspace too small: %zu < %zu", ws_bytes, w->bytes);
   CLIPMI_REQUIRE((uintptr_t)ws % 256 == 0, CLIPMI_ERR_ARG, "workspace must be 256-byte aligned");
@@ -651,9 +656,9 @@ size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx
   return carve(nullptr, (int64_t)b * L, m->g.vision_width, b, m->col_bytes(b)).bytes;
 }
 
-size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts) {
+size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts, int seq_rows) {
   if (!m || n_prompts < 0) return 0;
-  return carve(nullptr, (int64_t)n_prompts * m->g.context_length, m->g.text_width, n_prompts).bytes;
+  return carve(nullptr, (int64_t)n_prompts * live_rows(m, seq_rows), m->g.text_width, n_prompts).bytes;
 }
 
 static int encode_image_pass(clipmi_model* m, const void* image, int image_dtype, int batch, const clipmi_prompt_hook* hook, float* out,
@@ -800,50 +805,50 @@ int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n
                        void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
   TowerWs w;
   bool folded, f16res;
-  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
+  int rc = text_prologue(m, n_prompts, 0, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x && y, CLIPMI_ERR_ARG, "text_blocks: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int L = m->g.context_length, D = m->g.text_width;
-  if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, D, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, hook, folded, f16res, s))) return rc;
+  if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, L, D, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, L, hook, folded, f16res, s))) return rc;
   if (f16res) return launch_cast_f16(w.xn, y, dtype, (int64_t)n_prompts * L * D, s);
   return launch_cast_f32(w.xres, y, dtype, (int64_t)n_prompts * L * D, s);
 }
 
-int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
+int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts, int seq_rows,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes, unsigned flags,
                         clipmi_stream_t stream) {
   TowerWs w;
   bool folded, f16res;
-  int rc = text_prologue(m, n_prompts, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
+  int rc = text_prologue(m, n_prompts, seq_rows, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(prompts && eot && out, CLIPMI_ERR_ARG, "text_encoder: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int L = m->g.context_length, D = m->g.text_width;
-  if ((rc = launch_add_pos(prompts, dtype, m->tw.positional_embedding, w.xres, n_prompts, L, D, s))) return rc;
+  const int L = live_rows(m, seq_rows), D = m->g.text_width;   // rows [L, context_length) of every prompt are never read
+  if ((rc = launch_add_pos(prompts, dtype, m->tw.positional_embedding, w.xres, n_prompts, L, m->g.context_length, D, s))) return rc;
   if ((rc = launch_eot_rows(eot, w.idx + n_prompts, n_prompts, L, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, hook, folded, f16res, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, L, hook, folded, f16res, s))) return rc;
   return run_text_tail(m, w, n_prompts, out, f16res, s);
 }
 
-int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace, size_t workspace_bytes,
+int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, int seq_rows, float* out, void* workspace, size_t workspace_bytes,
                        unsigned flags, clipmi_stream_t stream) {
   TowerWs w;
   bool folded, f16res;
-  int rc = text_prologue(m, n_prompts, nullptr, workspace, workspace_bytes, flags, &w, &folded, &f16res);
+  int rc = text_prologue(m, n_prompts, seq_rows, nullptr, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(ids && out, CLIPMI_ERR_ARG, "encode_text: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int L = m->g.context_length, D = m->g.text_width;
-  if ((rc = launch_embed_tokens(ids, m->tw.token_embedding, m->tw.positional_embedding, w.xres, w.idx, n_prompts, L, D,
+  const int L = live_rows(m, seq_rows), D = m->g.text_width;
+  if ((rc = launch_embed_tokens(ids, m->tw.token_embedding, m->tw.positional_embedding, w.xres, w.idx, n_prompts, L, m->g.context_length, D,
                                 m->g.vocab_size, s)))
     return rc;
   if ((rc = launch_eot_rows(w.idx, w.idx + n_prompts, n_prompts, L, s))) return rc;
-  if ((rc = run_text_blocks(m, w, n_prompts, nullptr, folded, f16res, s))) return rc;
+  if ((rc = run_text_blocks(m, w, n_prompts, L, nullptr, folded, f16res, s))) return rc;
   return run_text_tail(m, w, n_prompts, out, f16res, s);
 }
 

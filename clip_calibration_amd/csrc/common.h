@@ -230,10 +230,10 @@ int launch_cls_and_ctx_rows(float* x0, const float* cls, const float* pos, const
 // x[n, first + j, :] = prompt[j, :]  for j < n_ctx       (clip/model.py:301-328)
 int launch_overwrite_tokens(float* x, const float* prompt, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 // xres[c,l,:] = float(src[c,l,:]) + (pos ? pos[l,:] : 0)
-int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int D, hipStream_t s);
+int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int src_L, int D, hipStream_t s);  // first L of src_L rows
 // xres[c,l,:] = table[ids[c,l],:] + pos[l,:] ; eot[c] = argmax_l ids[c,l]     (clip/model.py:601-603,611)
 int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* xres, int32_t* eot, int C,
-                        int L, int D, int vocab, hipStream_t s);
+                        int L, int src_L, int D, int vocab, hipStream_t s);   // ids [C, src_L]; the first L positions are embedded
 int launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);  // rows[c] = c*L + eot[c]
 int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStream_t s);

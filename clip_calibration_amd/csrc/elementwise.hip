@@ -100,18 +100,21 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
   if (lane < parts) *reinterpret_cast<float2*>(stats + 2 * ((int64_t)lane * M + row)) = lane == 0 ? make_float2(s, q) : make_float2(0.f, 0.f);
 }
 
+// src rows are [C, src_L, D]; the first L <= src_L token rows of every sequence are taken (text tower: dead-row elimination)
 template <typename TI>
 __global__ __launch_bounds__(256) void add_pos_kernel(const TI* __restrict__ src, const float* __restrict__ pos,
-                                                      float* __restrict__ xres, int L, int D4, int64_t total4) {
+                                                      float* __restrict__ xres, int L, int src_L, int D4, int64_t total4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int d4 = (int)(i % D4);
-  const int l = (int)((i / D4) % L);
+  const int64_t tok = i / D4;
+  const int l = (int)(tok % L);
+  const int64_t si = ((tok / L) * src_L + l) * D4 + d4;
   f32x4 v;
   if constexpr (sizeof(TI) == 4) {
-    v = *reinterpret_cast<const f32x4*>(src + i * 4);
+    v = *reinterpret_cast<const f32x4*>(src + si * 4);
   } else {
-    const f16x4 h = *reinterpret_cast<const f16x4*>(src + i * 4);
+    const f16x4 h = *reinterpret_cast<const f16x4*>(src + si * 4);
     v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
   }
   if (pos) v += *reinterpret_cast<const f32x4*>(pos + ((int64_t)l * D4 + d4) * 4);
@@ -119,14 +122,14 @@ __global__ __launch_bounds__(256) void add_pos_kernel(const TI* __restrict__ src
 }
 
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
-                                                    const float* __restrict__ pos, float* __restrict__ xres, int L, int D4,
+                                                    const float* __restrict__ pos, float* __restrict__ xres, int L, int src_L, int D4,
                                                     int vocab, int64_t total4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int d4 = (int)(i % D4);
   const int64_t tok = i / D4;
   const int l = (int)(tok % L);
-  int64_t id = ids[tok];
+  int64_t id = ids[(tok / L) * src_L + l];   // ids are [C, src_L]; the first L token positions of every prompt are embedded
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // never read outside the table
   const f32x4 e = *reinterpret_cast<const f32x4*>(table + (id * D4 + d4) * 4);
   const f32x4 p = *reinterpret_cast<const f32x4*>(pos + ((int64_t)l * D4 + d4) * 4);
@@ -303,16 +306,17 @@ int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N
   return check_launch("row_stats_kernel");
 }
 
-int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int D, hipStream_t s) {
+int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, int C, int L, int src_L, int D, hipStream_t s) {
   CLIPMI_REQUIRE(src && xres, CLIPMI_ERR_ARG, "add_pos: null pointer");
   CLIPMI_REQUIRE(D % 4 == 0, CLIPMI_ERR_SHAPE, "add_pos: D=%d must be a multiple of 4", D);
+  CLIPMI_REQUIRE(L > 0 && L <= src_L, CLIPMI_ERR_SHAPE, "add_pos: %d rows of a %d-row sequence", L, src_L);
   const int64_t total4 = (int64_t)C * L * (D / 4);
   if (total4 == 0) return CLIPMI_OK;
   const unsigned grid = (unsigned)((total4 + 255) / 256);
   if (dtype == CLIPMI_F32)
-    hipLaunchKernelGGL(add_pos_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, pos, xres, L, D / 4, total4);
+    hipLaunchKernelGGL(add_pos_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, pos, xres, L, src_L, D / 4, total4);
   else if (dtype == CLIPMI_F16)
-    hipLaunchKernelGGL(add_pos_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)src, pos, xres, L, D / 4, total4);
+    hipLaunchKernelGGL(add_pos_kernel<half_t>, dim3(grid), dim3(256), 0, s, (const half_t*)src, pos, xres, L, src_L, D / 4, total4);
   else {
     set_error("add_pos: bad dtype %d", dtype);
     return CLIPMI_ERR_ARG;
@@ -320,18 +324,19 @@ int launch_add_pos(const void* src, int dtype, const float* pos, float* xres, in
   return check_launch("add_pos_kernel");
 }
 
-int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* xres, int32_t* eot, int C, int L,
+int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos, float* xres, int32_t* eot, int C, int L, int src_L,
                         int D, int vocab, hipStream_t s) {
   CLIPMI_REQUIRE(ids && table && pos && xres, CLIPMI_ERR_ARG, "embed: null pointer");
   CLIPMI_REQUIRE(D % 4 == 0, CLIPMI_ERR_SHAPE, "embed: D=%d must be a multiple of 4", D);
+  CLIPMI_REQUIRE(L > 0 && L <= src_L, CLIPMI_ERR_SHAPE, "embed: %d rows of a %d-token prompt", L, src_L);
   if (C == 0) return CLIPMI_OK;
   const int64_t total4 = (int64_t)C * L * (D / 4);
-  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ids, table, pos, xres, L, D / 4,
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ids, table, pos, xres, L, src_L, D / 4,
                      vocab, total4);
   int rc = check_launch("embed_kernel");
   if (rc != CLIPMI_OK) return rc;
-  if (eot) {
-    hipLaunchKernelGGL(eot_kernel, dim3(C), dim3(64), 0, s, ids, eot, (int32_t*)nullptr, C, L);
+  if (eot) {   // the argmax scans the whole prompt
+    hipLaunchKernelGGL(eot_kernel, dim3(C), dim3(64), 0, s, ids, eot, (int32_t*)nullptr, C, src_L);
     rc = check_launch("eot_kernel");
   }
   return rc;

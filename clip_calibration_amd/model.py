@@ -10,6 +10,7 @@ Running any forward on a CPU tensor raises; there is no fallback.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -164,9 +165,14 @@ class CLIP(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(geom.transformer_width, geom.embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * float(np.log(1 / 0.07)))
         self._init_ivlp_prompts()
+        self._resnet_cfg = dict(resnet) if resnet is not None else None
         self._handle: Optional[int] = None
         self._bound = None          # keeps the packed tensors + ctypes arrays alive
         self._ws: Dict[tuple, torch.Tensor] = {}   # (kind, stream) -> workspace, LRU-bounded (_workspace)
+        self._options: Dict[str, int] = {}         # per-handle settings, replayed on the per-device copies
+        self._device_copies: Dict[int, "CLIP"] = {}   # device index -> resident copy (see _resident)
+        self._live_rows: Dict[tuple, tuple] = {}      # tokenised prompt set -> (the tensor, rows the text tower must compute)
+        self._copies_lock = threading.Lock()
 
     # ---- IVLP / VPT design (clip/model.py:191-256, 334-346, 361-381) -------------------------------------------
     def _init_ivlp_prompts(self) -> None:
@@ -207,16 +213,88 @@ class CLIP(nn.Module):
         out = super()._apply(fn, *a, **k)
         self._bound = None          # tensors moved / re-typed: re-pack lazily
         self._ws = {}
+        self._device_copies = {}
         return out
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._bound = None
+        self.rebind()
         return res
 
     def rebind(self) -> None:
         """Call after modifying tower parameters in place (the packed fp16/fp32 copies are otherwise reused)."""
         self._bound = None
+        self._device_copies = {}
+        if self.is_resnet:          # the ModifiedResNet tower keeps its own folded operands (resnet.py)
+            self.visual._packed, self.visual._packed_elsewhere = None, {}
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: the C handle, the packed operands, the workspaces and the per-device copies belong to THIS object
+        (``__del__`` destroys the handle); a copy binds its own lazily."""
+        state = dict(self.__dict__)
+        state.update(_handle=None, _bound=None, _ws={}, _device_copies={}, _copies_lock=None, _live_rows={})
+        state.pop("_origin", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._copies_lock = threading.Lock()
+        for tower in (self.visual, self.transformer):      # the towers of a copy call into the copy
+            if "_owner" in tower.__dict__:
+                object.__setattr__(tower, "_owner", self)
+
+    # ---- several GPUs in one process: nn.DataParallel around the unchanged trainers -------------------------------
+    # The reference wraps its models in nn.DataParallel whenever torch.cuda.device_count() > 1 (trainers/classification/coop.py:268-272:
+    # the TextEncoder; trainers/calibration/tempscaling.py:117-120: the whole calibration model).  DataParallel clones the module tree per
+    # device on EVERY forward (``_replicate_for_data_parallel``: a shallow ``__dict__`` copy, parameters re-broadcast) and runs the clones
+    # in threads under ``torch.cuda.device(k)``.  A clone of a tower proxy therefore still points at the model that owns the C handle,
+    # whose operands live on ITS device.  The owner answers a call whose activations live on another GPU from a copy of itself that is
+    # resident there: built once per device (weights, packed operands, handle, workspaces), kept until the owner's weights are re-bound --
+    # not re-sent per call as DataParallel's own broadcast is.  One process per GPU (torchrun, INTEGRATION.md "Multi-GPU") stays the
+    # recommended deployment; this makes the unchanged single-process callers correct instead of silently reading cuda:0's weights.
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__.update(_handle=None, _bound=None, _ws={}, _device_copies={}, _live_rows={})   # never shares (or frees) the owner's handle
+        object.__setattr__(replica, "_origin", self._home())
+        return replica
+
+    def _home(self) -> "CLIP":
+        return self.__dict__.get("_origin") or self
+
+    def _copy_to(self, device: torch.device) -> "CLIP":
+        """A model of the same geometry, design and per-handle options with this model's weights copied to ``device``."""
+        with torch.no_grad():
+            twin = CLIP(self.geometry, self.design_details, self._resnet_cfg)
+            src = dict(self.named_parameters())
+            src.update(dict(self.named_buffers()))
+            for name, t in list(twin.named_parameters()) + list(twin.named_buffers()):
+                t.data = src[name].detach().to(device, copy=True)
+            for p in twin.parameters():
+                p.requires_grad_(False)
+        twin.eval()
+        for name, value in self._options.items():
+            twin.set_option(name, value)
+        return twin
+
+    def _resident(self, device: torch.device) -> "CLIP":
+        """The model that owns the weights on ``device``: the owner itself, or its resident copy there."""
+        home = self._home()
+        if device == home.device or device.type != "cuda" or home.device.type != "cuda":   # (a CPU tensor / model is refused further down)
+            return home
+        with home._copies_lock:
+            twin = home._device_copies.get(device.index)
+            if twin is None:
+                with torch.cuda.device(device):
+                    twin = home._copy_to(device)
+                home._device_copies[device.index] = twin
+        return twin
+
+    def _elsewhere(self, t) -> Optional["CLIP"]:
+        """The resident copy a call on tensor ``t`` must run on, None when this model is the right one."""
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            return None
+        m = self._resident(t.device)
+        return None if m is self else m
 
     def __del__(self):
         try:
@@ -317,6 +395,9 @@ class CLIP(nn.Module):
             raise KeyError(f"unknown model option {name!r}; one of {self._MODEL_OPTIONS}")
         self._ensure_handle()
         check(lib.clipmi_model_set_option(self._handle, name.encode(), int(value)), "clipmi_model_set_option")
+        self._options[name] = int(value)
+        for twin in list(self._device_copies.values()):
+            twin.set_option(name, value)
 
     def get_option(self, name: str) -> int:
         self._ensure_handle()
@@ -356,6 +437,10 @@ class CLIP(nn.Module):
                            deep_prompts: Optional[Sequence[torch.Tensor]] = None, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
         """VisionTransformer.forward / ModifiedResNet.forward with fp32 output (un-normalised).  ``flags``: per-call
         stream precision (``_lib.CALL_STREAM_F32`` / ``_F16``); default = the model's setting."""
+        twin = self._elsewhere(image)
+        if twin is not None:
+            with torch.cuda.device(image.device):
+                return twin.image_features_f32(image, shared_ctx, deep_prompts, flags)
         if self.is_resnet:
             if shared_ctx is not None:
                 raise ValueError("prompt tokens apply to the ViT towers only")
@@ -385,6 +470,10 @@ class CLIP(nn.Module):
         return self.visual(image.type(self.dtype))
 
     def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+        twin = self._elsewhere(x_lnd)
+        if twin is not None:
+            with torch.cuda.device(x_lnd.device):
+                return twin._text_blocks(x_lnd, deep, n_ctx, flags)
         self._ensure_bound()
         g = self.geometry
         x_lnd = ops._dev(x_lnd, "x", (torch.float16, torch.float32))
@@ -397,16 +486,44 @@ class CLIP(nn.Module):
         if deep:
             hook, keep = self._hook(n_ctx, None, deep, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, 0))
         check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
                                      ws.numel(), int(flags), ops._stream()), "clipmi_text_blocks")
         return y.permute(1, 0, 2)
 
+    # ---- dead-row elimination in the causal text tower (include/clipmi.h, clipmi_text_encoder `seq_rows`) ---------------------
+    text_dead_row_elimination: bool = True   # False: always run all context_length rows of every prompt
+
+    def live_rows(self, tokenized_prompts: torch.Tensor, n_ctx: int = 0) -> int:
+        """Token rows per prompt the text tower has to compute for this set of tokenised prompts: the blocks mask causally
+        (clip/model.py:585-591) and only the EOT row = ``argmax(ids)`` leaves the tower (clip/model.py:611, coop.py:65), so nothing behind the
+        last prompt's EOT can reach an output.  ``max(EOT) + 1`` rounded up to a multiple of 8 (few distinct shapes), at least the prompt
+        tokens 1..n_ctx a hook overwrites, at most the context.  Costs one read-back of a scalar per NEW prompt set: the answer is kept with
+        the tensor it was computed for (which keeps that storage -- and so the key -- alive) and re-used while its version counter stands."""
+        L = self.context_length
+        if not self.text_dead_row_elimination:
+            return L
+        t = tokenized_prompts
+        key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device))
+        hit = self._live_rows.pop(key, None)
+        if hit is None:
+            last = int(t.reshape(-1, t.shape[-1]).argmax(dim=-1).max()) if t.numel() else 0
+            hit = (t, min(L, max((last + 1 + 7) // 8 * 8, 1 + int(n_ctx))))
+        self._live_rows[key] = hit                   # (re-inserted last: the dict is the LRU order)
+        while len(self._live_rows) > 16:
+            self._live_rows.pop(next(iter(self._live_rows)))
+        return max(hit[1], min(L, 1 + int(n_ctx)))
+
     def text_encoder_f32(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor,
                          deep_prompts: Optional[Sequence[torch.Tensor]] = None, n_ctx: int = 0,
-                         flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+                         flags: int = _lib.CALL_DEFAULT, seq_rows: Optional[int] = None) -> torch.Tensor:
         """TextEncoder.forward fused (coop.py:56-67; maple.py:60-74): prompts [C,77,D] (no pos-emb) -> fp32 [C,E].
-        ``flags``: per-call stream precision (CoCoOp's per-image passes ask for ``_lib.CALL_STREAM_F16``)."""
+        ``flags``: per-call stream precision (CoCoOp's per-image passes ask for ``_lib.CALL_STREAM_F16``).  ``seq_rows``: the caller's own
+        bound on the live token rows (``live_rows`` of the prompt set it tiles or repeats per call); None = derived from ``tokenized_prompts``."""
+        twin = self._elsewhere(prompts)
+        if twin is not None:
+            with torch.cuda.device(prompts.device):
+                return twin.text_encoder_f32(prompts, tokenized_prompts, deep_prompts, n_ctx, flags, seq_rows)
         self._ensure_bound()
         g = self.geometry
         prompts = ops._dev(prompts, "prompts", (torch.float16, torch.float32))
@@ -422,12 +539,17 @@ class CLIP(nn.Module):
         if deep_prompts:
             hook, keep = self._hook(n_ctx, None, deep_prompts, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
-        check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, hook_ref,
+        rows = self.live_rows(tokenized_prompts, n_ctx if deep_prompts else 0) if seq_rows is None else int(seq_rows)
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
+        check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, rows, hook_ref,
                                       out.data_ptr(), ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_text_encoder")
         return out
 
     def text_features_f32(self, text: torch.Tensor, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+        twin = self._elsewhere(text)
+        if twin is not None:
+            with torch.cuda.device(text.device):
+                return twin.text_features_f32(text, flags)
         self._ensure_bound()
         g = self.geometry
         text = ops._dev(text, "text", (torch.int64,))
@@ -437,8 +559,9 @@ class CLIP(nn.Module):
             return self.text_encoder_f32(self.token_embedding(text), text, flags=flags)
         Cn = text.shape[0]
         out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=text.device)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn))
-        check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, out.data_ptr(), ws.data_ptr(), ws.numel(),
+        rows = self.live_rows(text)
+        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
+        check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                      int(flags), ops._stream()), "clipmi_encode_text")
         return out
 

@@ -12,6 +12,7 @@ called.  ``forward`` is a sequence of C-ABI launches on NHWC fp16 activations:
 """
 from __future__ import annotations
 
+import threading
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -80,17 +81,57 @@ class ModifiedResNet(nn.Module):
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self.attnpool = AttentionPool2d(input_resolution // 32, width * 32, heads, output_dim)
         self._packed = None
+        self._packed_elsewhere: Dict[int, dict] = {}    # device index -> the packed operands copied there (nn.DataParallel replicas)
+        self._pack_lock = threading.Lock()
 
     # ---- binding: fold BatchNorm, pack weights ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._packed = None
+        self._packed, self._packed_elsewhere = None, {}
         return out
 
     def load_state_dict(self, *a, **k):
         res = super().load_state_dict(*a, **k)
-        self._packed = None
+        self._packed, self._packed_elsewhere = None, {}
         return res
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.update(_packed=None, _packed_elsewhere={}, _pack_lock=None)
+        state.pop("_origin", None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._pack_lock = threading.Lock()
+
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel clones this module per device on every forward (model.py "several GPUs in one process"): a clone takes the
+        owner's packed operands from a per-device copy kept by the owner instead of re-folding its re-broadcast parameters per call."""
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__.update(_packed=None, _packed_elsewhere={})
+        object.__setattr__(replica, "_origin", self.__dict__.get("_origin") or self)
+        return replica
+
+    def _packed_on(self, device: torch.device) -> dict:
+        """The owner's packed operands on ``device`` (copied once per device, dropped when the owner re-packs)."""
+        own = self._ensure_packed()
+        if device == self.conv1.weight.device:
+            return own
+
+        def move(v):
+            if isinstance(v, torch.Tensor):
+                return v.to(device)
+            if isinstance(v, (list, tuple)):
+                return type(v)(move(e) for e in v)
+            if isinstance(v, dict):
+                return {k: move(e) for k, e in v.items()}
+            return v
+        with self._pack_lock:
+            p = self._packed_elsewhere.get(device.index)
+            if p is None:
+                p = self._packed_elsewhere[device.index] = move(own)
+        return p
 
     @staticmethod
     def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d, order: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None):
@@ -165,7 +206,11 @@ class ModifiedResNet(nn.Module):
     @torch.no_grad()
     def features_f32(self, image: torch.Tensor) -> torch.Tensor:
         """ModifiedResNet.forward (clip/model.py:136-150) with fp32 output."""
-        p = self._ensure_packed()
+        origin = self.__dict__.get("_origin")
+        if isinstance(image, torch.Tensor) and image.is_cuda and (origin is not None or image.device != self.conv1.weight.device):
+            p = (origin or self)._packed_on(image.device)
+        else:
+            p = self._ensure_packed()
         image = ops._dev(image, "image", (torch.float16, torch.float32))
         R, w = self.input_resolution, self.width
         if image.dim() != 4 or tuple(image.shape[1:]) != (3, R, R):

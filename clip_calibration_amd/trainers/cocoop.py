@@ -97,11 +97,12 @@ class CustomCLIP(nn.Module):
         m = self.clip_model
         f16 = self.text_stream_f16 and m.get_option("residual_f16") == 2 and m.get_option("ln_fold") == 1   # 2 = image tower only (the default)
         flags = _lib.CALL_STREAM_F16 if f16 else _lib.CALL_DEFAULT
+        rows = m.live_rows(self.tokenized_prompts)      # of the class list (kept with it: no per-batch read-back); every image repeats it
         for lo in range(0, B, step):
             nb = min(step, B - lo)
             prompts = ops.cocoop_prompts(pl.base_embedding(), ctx_shifted[lo:lo + nb])
             ids = self.tokenized_prompts.repeat(nb, 1)                       # EOT index plumbing
-            out[lo:lo + nb] = self.text_encoder(prompts, ids, flags=flags).view(nb, Cn, -1)
+            out[lo:lo + nb] = self.text_encoder(prompts, ids, flags=flags, seq_rows=rows).view(nb, Cn, -1)
         return out
 
     @torch.no_grad()

@@ -21,8 +21,8 @@ class TextEncoder(nn.Module):
         self.dtype = clip_model.dtype
 
     def forward(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor, compound_prompts_deeper_text=None,
-                n_ctx: int = 0, flags: int = 0) -> torch.Tensor:
-        return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx, flags=flags)
+                n_ctx: int = 0, flags: int = 0, seq_rows: Optional[int] = None) -> torch.Tensor:
+        return self.clip_model.text_encoder_f32(prompts, tokenized_prompts, compound_prompts_deeper_text, n_ctx, flags=flags, seq_rows=seq_rows)
 
 
 def n_ctx_from_init_ids(ctx_init_ids: torch.Tensor, context_length: int) -> int:
@@ -152,6 +152,9 @@ class CustomCLIP(nn.Module):
         if self.cache_text_features or not self.overlap_towers or not image.is_cuda:
             text_features = self.text_features()
             return self._image_features(image), text_features
+        # Weight binding is lazy and packs BOTH towers with torch ops on whatever stream is current: do it here, on the caller's stream,
+        # so that the side stream (which waits for this point) and the caller's stream both see finished operands.
+        self.clip_model._resident(image.device)._ensure_bound()
         cur = torch.cuda.current_stream(image.device)
         side = getattr(self, "_side_stream", None)
         if side is None or side.device != image.device:

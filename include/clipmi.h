@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CLIPMI_ABI_VERSION 12
+#define CLIPMI_ABI_VERSION 13
 
 typedef void* clipmi_stream_t; /* hipStream_t */
 
@@ -376,9 +376,10 @@ int clipmi_set_text_weights(clipmi_model* m, const clipmi_text_weights* w);
 
 /* Bytes of scratch the caller must pass to the tower calls for `batch` images / `n_prompts` prompts.  clipmi_encode_image works a large
  * batch in passes (option vision_pass): the vision figure is that of the largest pass, under the option's value at the time of the call to
- * clipmi_encode_image -- size the workspace after any clipmi_set_option("vision_pass", ...). */
+ * clipmi_encode_image -- size the workspace after any clipmi_set_option("vision_pass", ...).  The text figure is for a call with the
+ * same `seq_rows` (below; 0 = the whole context). */
 size_t clipmi_vision_workspace_bytes(const clipmi_model* m, int batch, int n_ctx);
-size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts);
+size_t clipmi_text_workspace_bytes(const clipmi_model* m, int n_prompts, int seq_rows);
 
 /* CLIP.encode_image / VisionTransformer.forward (clip/model.py:597-598,394-424; MaPLe :447-478 when hook != NULL):
  * image [B,3,R,R] (fp32|fp16) -> out fp32 [B,E] (un-normalised, as the reference returns).  Batches of one and a half passes or more
@@ -395,13 +396,23 @@ int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n
                        unsigned flags, clipmi_stream_t stream);
 
 /* TextEncoder.forward (coop.py:56-67, maple.py:60-74): prompts (fp16|fp32) [C,L,Dt] WITHOUT positional embedding,
- * eot int32[C] = tokenized_prompts.argmax(-1)  ->  out fp32 [C,E] = ln_final(blocks(prompts + pos))[eot] @ text_projection. */
-int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts,
+ * eot int32[C] = tokenized_prompts.argmax(-1)  ->  out fp32 [C,E] = ln_final(blocks(prompts + pos))[eot] @ text_projection.
+ *
+ * seq_rows -- dead-row elimination.  The text blocks mask causally (clip/model.py:585-591: token l attends to tokens <= l only) and the
+ * one row that leaves the tower is the EOT row (clip/model.py:611, coop.py:65), so no token behind the LAST prompt's EOT can influence any
+ * output.  With 0 < seq_rows < L the tower embeds, runs and reads only the first `seq_rows` token positions of every prompt (the inputs keep
+ * their [C,L,..] layout; rows >= seq_rows are never read): identical features, L / seq_rows times fewer rows through every GEMM
+ * ("X X X X a photo of a <name>." ends at token ~22 of 77).  The CALLER guarantees max(eot) < seq_rows -- it holds the tokenised prompts on the
+ * host side and computes the bound once, without a per-call device sync -- and 1 + hook->n_ctx <= seq_rows; an EOT index outside is clamped
+ * to seq_rows - 1 as it is to L - 1 today.  seq_rows <= 0 or >= L: the whole context.  `clip_model.transformer(x)` (clipmi_text_blocks)
+ * returns every row and therefore always runs every row. */
+int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts, int seq_rows,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
                         unsigned flags, clipmi_stream_t stream);
 
-/* CLIP.encode_text (clip/model.py:600-613): ids int64 [C,L] -> out fp32 [C,E]; EOT row = argmax(ids), computed on device. */
-int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, float* out, void* workspace,
+/* CLIP.encode_text (clip/model.py:600-613): ids int64 [C,L] -> out fp32 [C,E]; EOT row = argmax(ids), computed on device.
+ * seq_rows as above (the argmax always scans all L ids). */
+int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, int seq_rows, float* out, void* workspace,
                        size_t workspace_bytes, unsigned flags, clipmi_stream_t stream);
 
 /* Timing aid for bench.py (the per-kernel roofline of its JSON line): the five launches of the vision tower's residual

@@ -43,16 +43,22 @@ def pytest_sessionstart(session):
     def run_to_completion(cmd, env, log):
         """One child in a session of its own, so that on a timeout the WHOLE tree (bench.py -> torch.distributed.run -> rank workers) is
         killed and reaped before the first test runs: an orphaned rank would share the GPU with the parity suite."""
+        import atexit
         import signal
         p = subprocess.Popen(cmd, env=env, stdout=open(log, "w"), stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True)
+
+        def reap():                                   # also at interpreter exit: a pytest that is interrupted while it waits here
+            if p.poll() is None:                      # must not leave the rank tree (a session of its own) on the GPU
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+        atexit.register(reap)
         try:
             p.wait(timeout=600)
-        except subprocess.TimeoutExpired:
-            try:
-                os.killpg(p.pid, signal.SIGKILL)
-            except ProcessLookupError:
-                pass
-            p.wait()
+        except (subprocess.TimeoutExpired, KeyboardInterrupt):
+            reap()
         return p
     # exactly the driver's command for N > 1: plain `python bench.py --gpus 2` (bench.py starts its own rank processes)
     two = run_to_completion([sys.executable, bench, "--gpus", "2", "--dump", os.path.join(tmp, "two.npz")] + common, env, os.path.join(tmp, "two.out"))

@@ -338,3 +338,24 @@ def test_hazard_scan_follows_branches_and_fails_loudly():
             hs.scan("layernorm.hip")
 
 
+
+
+def test_live_rows_is_host_logic():
+    """CLIP.live_rows (dead-row elimination of the causal text tower, include/clipmi.h `seq_rows`): max(EOT) + 1 rounded up to 8, per NEW
+    prompt set, never below a hook's prompt tokens, never above the context."""
+    model = build_model(dict(syn.synthetic_state_dict("tiny")), {"trainer": "CoOp"})
+    ids = syn.synthetic_token_ids(8, "tiny", seed=11, n_ctx_placeholders=4)
+    last = int(ids.argmax(-1).max())
+    r = model.live_rows(ids)
+    assert r == (last + 8) // 8 * 8 and r == model.live_rows(ids[:]) and len(model._live_rows) == 1
+    ids[0, :40] = 5
+    ids[0, 40] = model.vocab_size - 1                      # in-place edit: the version counter moves, the bound is recomputed
+    assert model.live_rows(ids) == 48 and model.live_rows(ids, n_ctx=60) == 61
+    ids[1, 76] = model.vocab_size - 1
+    ids[1, :76] = 5
+    assert model.live_rows(ids) == 77
+    for k in range(40):
+        model.live_rows(syn.synthetic_token_ids(4, "tiny", seed=100 + k))
+    assert len(model._live_rows) <= 16
+    model.text_dead_row_elimination = False
+    assert model.live_rows(ids) == model.context_length
