@@ -36,6 +36,9 @@ if ROOT not in sys.path:
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 HBM_PEAK_BYTES_PER_S = 8.0e12        # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+MFMA_PEAK_CLOCK_MHZ = 2400.0         # the clock the 2.5 PF figure is quoted at (same guide, peaks table)
+CPU_BASELINE_THREADS = 32            # fastest of 8 / 16 / 32 / 64 on the GPU box's host (profiles/r05_cpu_baseline_threads.txt)
+CPU_BASELINE_WARMUPS = 2
 
 
 def parse():
@@ -60,6 +63,7 @@ def parse():
     ap.add_argument("--dump", default=None, help="rank 0: save logits / conf / pred / ECE bins of the last step to this .npz")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel profile (functional multi-rank self-tests)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the per-GPU shapes of BASELINE configs[2] / [3] / [4] (other_configs)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-classes", type=int, default=100, help="BASELINE configs[0]: Caltech101-sized prompt set")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -72,13 +76,14 @@ def cpu_baseline(sd, geom_name, n_cls, batch, budget_s):
     from clip_calibration_amd import synthetic as syn
     from oracle import clip_oracle as orc  # timed baseline + checker only
 
-    # torch CPU kernels collapse when oversubscribed (256 logical CPUs on the GPU box -> 0.5 img/s): take the CPUs
-    # this process may actually run on, capped at 32, and report both counts.
+    # torch CPU kernels collapse when oversubscribed (256 logical CPUs on the GPU box -> 0.5 img/s): take the CPUs this process may
+    # actually run on, capped at the thread count that was FASTEST in a sweep on the GPU box's host (tools/cpu_baseline_threads.py ->
+    # profiles/r05_cpu_baseline_threads.txt; BENCH_CPU_THREADS overrides), and report both counts.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))
+    cores = max(1, min(avail, int(os.environ.get("BENCH_CPU_THREADS", CPU_BASELINE_THREADS))))
     torch.set_num_threads(cores)
     ids = syn.synthetic_token_ids(n_cls, geom_name, seed=0)
     images = syn.synthetic_images(batch, geom_name, seed=0)
@@ -96,12 +101,12 @@ def cpu_baseline(sd, geom_name, n_cls, batch, budget_s):
             orc.calibrated_ece(logits.numpy(), labels.numpy())
             dt = time.perf_counter() - t0
             it += 1
-            if it > 1:  # first iteration is the warm-up
+            if it > CPU_BASELINE_WARMUPS:  # two warm-ups, then the median of up to 5 timed iterations
                 times.append(dt)
             if (time.perf_counter() - t_start > budget_s and len(times) >= 1) or len(times) >= 5:
                 break
     med = float(np.median(times))
-    sample = (f"{len(times)} timed iterations (1 warm-up) of batch {batch} x {n_cls} prompts, fp32 oracle on {cores} host "
+    sample = (f"{len(times)} timed iterations ({CPU_BASELINE_WARMUPS} warm-ups) of batch {batch} x {n_cls} prompts, fp32 oracle on {cores} host "
               f"threads, median {med:.3f} s/batch; text tower once {t_text:.2f} s (excluded)")
     return batch / med, cores, avail, sample, logits, images, labels
 
@@ -231,6 +236,89 @@ def ceilings(dev, local_rank, geom, B, seconds=1.0):
         del x, w
     out["vendor_gemm"] = dict(vend, what="torch.matmul (hipBLASLt) fp16, randn activations, N(0, 0.03^2) weights, NO epilogue (no bias / QuickGELU / "
                                          "residual / LayerNorm fold): comparison only, never on the product path")
+    return out
+
+
+def environment():
+    """Where this line was measured: kernel driver / VBIOS / ROCm versions from sysfs and the files of the image, the library's ABI and the
+    VALU -> MFMA fence it was built with (common.h CLIPMI_FENCE_SNOP), so that a recurrence of the round-3 corruption can be tied to a box
+    (profiles/r04_hazard_repro.txt).  Files only: nothing is exec'ed from this GPU-initialised process."""
+    import glob
+    import platform
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    env = {"kernel": platform.release(), "amdgpu_driver": read("/sys/module/amdgpu/version"), "rocm": read("/opt/rocm/.info/version"),
+           "torch": torch.__version__, "hip_runtime": getattr(torch.version, "hip", None)}
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/vbios_version"))
+    env["vbios"] = sorted({v for v in (read(c) for c in cards) if v})
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        env["device"] = {"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
+                         "hbm_gib": round(pr.total_memory / 2 ** 30, 1)}
+    except Exception:
+        pass
+    try:
+        from clip_calibration_amd import _lib
+        env["libclipmi"] = {"abi": _lib.lib.clipmi_abi_version(), "sha256_16": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]}
+        src = open(os.path.join(ROOT, "clip_calibration_amd", "csrc", "common.h")).read()
+        import re
+        m = re.search(r"#\s*define\s+CLIPMI_FENCE_SNOP\s+(-?\d+)", src)
+        env["libclipmi"]["valu_to_mfma_fence"] = f"s_nop {m.group(1)}" if m else "see common.h"
+    except Exception as e:   # never let bookkeeping fail a measurement
+        env["libclipmi"] = {"error": repr(e)}
+    return env
+
+
+def other_configs(dev, syn, model, build_model, images, Cn):
+    """The other BASELINE configs at their per-GPU shapes, OUTSIDE `value` (a few seconds): the driver's record then carries a number for each.
+      configs[3]  11-dataset sweep, batch 1024 over 8 GPUs   -> ViT-B/16 image tower at 128 images per GPU
+      configs[4]  ViT-L/14@336px, batch 512 over 8 GPUs     -> ViT-L/14@336 image tower at 64 images per GPU
+      configs[2]  CoOp 16-shot + DAC, reference schedule    -> both towers + tail per batch (text tower re-run every batch, coop.py:208-210)
+    Image towers: torch events around 6 calls after 2 warm-ups; fraction = algorithmic flop / time / 2.5 PF."""
+    from clip_calibration_amd.trainers import CoOpCLIP
+    from clip_calibration_amd import ops
+    out = {}
+
+    def tower(m, name, x, iters=6):
+        m.image_features_f32(x)
+        ms = timed_ms(lambda: m.image_features_f32(x), iters)
+        tf = syn.flops_per_image(name) * x.shape[0] / (ms * 1e-3) / 1e12
+        return {"model": name, "batch_per_gpu": x.shape[0], "tower_ms": ms, "images_per_s_tower": x.shape[0] / (ms * 1e-3), "tower_tflops": tf,
+                "tower_frac": tf / MFMA_F16_DENSE_PEAK_TFLOPS}
+    with torch.no_grad():
+        out["configs[3] per-rank"] = tower(model, "ViT-B/16", images[:128].contiguous())
+        # configs[2]: 500 classes, n_ctx 16, DAC factors (any positive vector times the row: the fit is host work outside the loop)
+        ids = syn.synthetic_token_ids(500, "ViT-B/16", seed=11, n_ctx_placeholders=16)
+        coop = CoOpCLIP(model, ids, n_ctx=16, logit_scale=1.0, seed=3, cache_text_features=False)
+        dac = (1.0 + 0.1 * torch.rand(500, generator=torch.Generator().manual_seed(5))).to(dev)
+        scale = float(np.exp(4.6052))
+
+        def coop_step():
+            feats, txt = coop.towers(images)
+            return ops.fused_tail(feats, txt, scale, dac, True, True)
+        coop_step()
+        ms = timed_ms(coop_step, 6)
+        rows = model.live_rows(coop.tokenized_prompts)
+        t_ms = timed_ms(lambda: coop.text_features(), 6)
+        out["configs[2] per-batch schedule"] = {
+            "model": "ViT-B/16", "batch_per_gpu": images.shape[0], "classes": 500, "n_ctx": 16, "ms_per_batch": ms,
+            "images_per_s_text_recomputed_every_batch": images.shape[0] / (ms * 1e-3),
+            "text_rows_computed": rows, "text_rows_of_context": model.context_length, "text_tower_ms": t_ms,
+            "text_tower_tflops_on_computed_rows": syn.flops_per_prompt("ViT-B/16") * 500 * rows / model.context_length / (t_ms * 1e-3) / 1e12,
+            "what": "prompt learner + text tower (fp16 stream, side stream) + image tower + fused tail with DAC row scale, every batch; flop credited "
+                    "for the computed token rows only (linear terms; the attention term is < 3 % of a prompt)"}
+        del coop
+        big = "ViT-L/14@336px"
+        m2 = build_model(dict(syn.synthetic_state_dict(big, seed=0)), {"trainer": "ZeroshotCLIP"}).to(dev)
+        x2 = syn.synthetic_images(64, big, seed=0, device=dev)
+        out["configs[4] per-rank"] = tower(m2, big, x2, iters=4)
+        del m2, x2
+    torch.cuda.empty_cache()
     return out
 
 
@@ -675,8 +763,12 @@ def main():
                                     "difference; between the features themselves the distance bounds any cosine-logit difference",
                             "pred_flips": int(flipped.numel()), "rows": int(p32.numel()),
                             "max_top2_margin_of_flipped_rows": float((top2[flipped, 0] - top2[flipped, 1]).max()) if flipped.numel() else 0.0}
-            tf = (lambda t: 5.960e9 * Cn / t / 1e12) if args.model == "ViT-B/16" else (lambda t: None)
+            # flop credited for the token rows the tower COMPUTES (dead-row elimination: rows behind the last EOT are never run); the
+            # per-prompt figure is SURVEY 8(d)'s 5.960 GFLOP at 77 rows, linear terms scaled by rows / 77 (attention is < 3 % of it)
+            text_rows = model.live_rows(per_batch.tokenized_prompts)
+            tf = (lambda t: 5.960e9 * Cn * text_rows / model.context_length / t / 1e12) if args.model == "ViT-B/16" else (lambda t: None)
             extra["coop_dac"] = {
+                "text_rows_computed": text_rows, "text_rows_of_context": model.context_length,
                 "images_per_s_text_cached": world * B * args.steps / elapsed,
                 "images_per_s_text_recomputed_every_batch": world * B * n_rt / elapsed_rt,
                 "text_tower_prompts_per_s": Cn / text_s, "text_tower_ms": 1e3 * text_s, "text_tower_tflops": tf(text_s),
@@ -730,6 +822,14 @@ def main():
             out["roofline"] = kernel_roofline(model, syn, geom, args.model, B, images)
             if rank == 0 and world == 1:
                 out["ceiling"] = ceilings(dev, local_rank, geom, B)
+                clk = out["ceiling"]["mfma_only"].get("in_kernel_clock_mhz")
+                if clk:
+                    # the datasheet's 2.5 PF is quoted at 2.4 GHz; under an MFMA-dense load this box holds `clk`: the same achieved rate
+                    # against the peak AT THAT CLOCK (clock-normalised fraction, next to the datasheet one)
+                    out["roofline"]["tower_frac_at_clock"] = out["roofline"]["tower"]["achieved"] / (MFMA_F16_DENSE_PEAK_TFLOPS * clk / MFMA_PEAK_CLOCK_MHZ)
+                    out["roofline"]["frac_at_clock"] = out["roofline"]["achieved"] / (MFMA_F16_DENSE_PEAK_TFLOPS * clk / MFMA_PEAK_CLOCK_MHZ)
+                if not coop and args.model == "ViT-B/16" and B >= 128 and not args.no_other_configs:
+                    out["other_configs"] = other_configs(dev, syn, model, build_model, images, Cn)
             feats = model.image_features_f32(images)
             # device time of the tail: its launches are queued BEHIND a tower pass (10 ms of GPU work), so that the host's
             # ~40 us of Python per call never starves the stream and the events bracket back-to-back executions only
@@ -777,6 +877,7 @@ def main():
                          "ece_delta": abs(ECE(conf.cpu().numpy(), pred.cpu().numpy(), cpu_labels.numpy()) - ece_ref),
                          "sample": f"{args.cpu_batch} images x {args.cpu_classes} prompts"}
     if rank == 0:
+        out["env"] = environment()
         print(json.dumps(out))
     if exchange is not None:
         exchange.close()

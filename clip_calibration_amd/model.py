@@ -173,6 +173,9 @@ class CLIP(nn.Module):
         self._device_copies: Dict[int, "CLIP"] = {}   # device index -> resident copy (see _resident)
         self._live_rows: Dict[tuple, tuple] = {}      # tokenised prompt set -> (the tensor, rows the text tower must compute)
         self._copies_lock = threading.Lock()
+        # Held while ONE tower call enqueues its launches: two host threads that drive this model on the SAME stream (they then share the
+        # stream's workspace) must not interleave their launch sequences; on different streams the workspaces differ and the lock costs a few us.
+        self._launch_lock = threading.Lock()
 
     # ---- IVLP / VPT design (clip/model.py:191-256, 334-346, 361-381) -------------------------------------------
     def _init_ivlp_prompts(self) -> None:
@@ -232,13 +235,13 @@ class CLIP(nn.Module):
         """copy.deepcopy / pickle: the C handle, the packed operands, the workspaces and the per-device copies belong to THIS object
         (``__del__`` destroys the handle); a copy binds its own lazily."""
         state = dict(self.__dict__)
-        state.update(_handle=None, _bound=None, _ws={}, _device_copies={}, _copies_lock=None, _live_rows={})
+        state.update(_handle=None, _bound=None, _ws={}, _device_copies={}, _copies_lock=None, _launch_lock=None, _live_rows={})
         state.pop("_origin", None)
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        self._copies_lock = threading.Lock()
+        self._copies_lock, self._launch_lock = threading.Lock(), threading.Lock()
         for tower in (self.visual, self.transformer):      # the towers of a copy call into the copy
             if "_owner" in tower.__dict__:
                 object.__setattr__(tower, "_owner", self)
@@ -325,6 +328,11 @@ class CLIP(nn.Module):
     def _ensure_bound(self):
         if self._bound is not None:
             return
+        with self._launch_lock:             # two threads' first calls: one packs, the other finds it done
+            if self._bound is None:
+                self._bind()
+
+    def _bind(self):
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("clipmi: the model must be on a ROCm GPU before it is run (model.to('cuda')); "
@@ -460,9 +468,10 @@ class CLIP(nn.Module):
             hook, keep = self._hook(n_ctx, shared_ctx, deep_prompts, g.vision_layers - 1)
             hook_ref = C.byref(hook)
         nbytes = lib.clipmi_vision_workspace_bytes(self._handle, B, n_ctx)
-        ws = self._workspace("vision", nbytes)
-        check(lib.clipmi_encode_image(self._handle, image.data_ptr(), _DT[image.dtype], B, hook_ref, out.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_encode_image")
+        with self._launch_lock:
+            ws = self._workspace("vision", nbytes)
+            check(lib.clipmi_encode_image(self._handle, image.data_ptr(), _DT[image.dtype], B, hook_ref, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_encode_image")
         return out
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:
@@ -486,9 +495,10 @@ class CLIP(nn.Module):
         if deep:
             hook, keep = self._hook(n_ctx, None, deep, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, 0))
-        check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
-                                     ws.numel(), int(flags), ops._stream()), "clipmi_text_blocks")
+        with self._launch_lock:
+            ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, 0))
+            check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
+                                         ws.numel(), int(flags), ops._stream()), "clipmi_text_blocks")
         return y.permute(1, 0, 2)
 
     # ---- dead-row elimination in the causal text tower (include/clipmi.h, clipmi_text_encoder `seq_rows`) ---------------------
@@ -540,9 +550,10 @@ class CLIP(nn.Module):
             hook, keep = self._hook(n_ctx, None, deep_prompts, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
         rows = self.live_rows(tokenized_prompts, n_ctx if deep_prompts else 0) if seq_rows is None else int(seq_rows)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
-        check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, rows, hook_ref,
-                                      out.data_ptr(), ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_text_encoder")
+        with self._launch_lock:
+            ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
+            check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, rows, hook_ref,
+                                          out.data_ptr(), ws.data_ptr(), ws.numel(), int(flags), ops._stream()), "clipmi_text_encoder")
         return out
 
     def text_features_f32(self, text: torch.Tensor, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
@@ -560,9 +571,10 @@ class CLIP(nn.Module):
         Cn = text.shape[0]
         out = torch.empty(Cn, g.embed_dim, dtype=torch.float32, device=text.device)
         rows = self.live_rows(text)
-        ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
-        check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     int(flags), ops._stream()), "clipmi_encode_text")
+        with self._launch_lock:
+            ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
+            check(lib.clipmi_encode_text(self._handle, text.data_ptr(), Cn, rows, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         int(flags), ops._stream()), "clipmi_encode_text")
         return out
 
     def encode_text(self, text: torch.Tensor) -> torch.Tensor:

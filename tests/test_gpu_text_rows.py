@@ -2,10 +2,13 @@
 
 Reference: the text blocks mask causally (clip/model.py:585-591) and only the EOT row leaves the tower (clip/model.py:611; coop.py:65),
 so token rows behind the last prompt's EOT cannot reach any output.  The library computes ``seq_rows`` token positions per prompt
-instead of all 77.  Tested here: the truncated tower against the full-length one (same library, same weights: <= 1e-6 in cosine, and
-to fp32 rounding on the un-normalised features -- the kernels pick tiles by row count, the arithmetic per element is the same),
-against the fp32 oracle, with ragged EOTs, a prompt whose EOT is the very last token, the prompt hook of MaPLe, the fp16 stream,
-and the bookkeeping of ``CLIP.live_rows`` (one read-back per NEW prompt set)."""
+instead of all 77.  Tested here: the truncated tower against the full-length one (same library, same weights).  With the SAME GEMM
+kernels on both sides (option gemm_variant pinned) the features agree to <= 1e-6 in cosine -- the arithmetic per element is the same.
+With the cost model free to choose, 24 000 and 77 000 rows get different kernels (row-range residual GEMMs add the residual inside the
+K loop, tile kernels in the epilogue: another fp32 summation order, then one fp16 rounding of the stream's shadow) and the two runs
+differ as ANY two batch sizes do (<= 2e-4 on normalised features) -- both within the tolerance against the fp32
+oracle.  Also: ragged EOTs, a prompt whose EOT is the very last token, the prompt hook of MaPLe, the fp16 stream, rows that must
+never be read, and the bookkeeping of ``CLIP.live_rows`` (one read-back per NEW prompt set)."""
 import ctypes as C
 
 import numpy as np
@@ -58,10 +61,15 @@ def _raw_text_encoder(model, prompts, eot, seq_rows, flags=0):
     return out
 
 
-@pytest.mark.parametrize("gname,n", [("tiny", 37), ("ViT-B/16", 1000)])
-def test_truncated_tower_equals_full_length_tower(gname, n):
-    """encode_text at C = 1000 (BASELINE configs[1]'s class list) and a small ragged case: dead rows off vs on."""
+@pytest.mark.parametrize("gname,n,variant", [("tiny", 37, -1), ("ViT-B/16", 1000, 0), ("ViT-B/16", 1000, -1)])
+def test_truncated_tower_equals_full_length_tower(gname, n, variant, clipmi_option):
+    """encode_text at C = 1000 (BASELINE configs[1]'s class list) and a small ragged case: dead rows off vs on.  variant 0 pins every GEMM to
+    the 128 x 128 tile kernel on both sides (same summation order: 1e-6); -1 leaves the cost model free (batch-size-class difference)."""
     sd, model = _build(gname)
+    if variant >= 0:
+        clipmi_option("gemm_variant", variant)
+        clipmi_option("gemm_stream", 0)
+        clipmi_option("gemm_rstream", 0)
     ids = _ragged_ids(n, gname, seed=3).cuda()
     rows = model.live_rows(ids)
     eot_max = int(ids.argmax(-1).max())
@@ -73,8 +81,16 @@ def test_truncated_tower_equals_full_length_tower(gname, n):
         full = model.text_features_f32(ids)
     torch.cuda.synchronize()
     assert torch.isfinite(short).all()
-    assert _cosine_gap(short, full) <= 1e-6
-    assert float((short - full).abs().max()) <= 2e-5 * float(full.abs().max())
+    gap = _cosine_gap(short, full)
+    print(f"[{gname} x {n}, gemm_variant {variant}] rows {rows} of {model.context_length}: cosine gap {gap:.2e}, "
+          f"max |d feature| / max |feature| {float((short - full).abs().max()) / float(full.abs().max()):.2e}")
+    same_kernels = variant >= 0 or gname == "tiny"
+    assert gap <= (1e-6 if same_kernels else 2e-4)
+    if gname == "ViT-B/16":      # both against the fp32 oracle on a slice (the 12-layer tower on the CPU: 24 prompts)
+        with torch.no_grad():
+            ref = orc.encode_text(sd, ids[:24].cpu()).numpy()
+        for got in (short[:24].cpu().numpy(), full[:24].cpu().numpy()):
+            assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max()
 
 
 def test_prompt_ending_on_the_last_token_keeps_every_row():
