@@ -15,6 +15,7 @@
 //   O^T tile += V^T(32 d x 16 keys) * P^T             the S^T accumulators, packed to fp16, ARE the B operand
 //                                                     (cdna_hip_programming.md §3 "accumulator tile as the next
 //                                                     MFMA's operand"); A = V^T via transposed LDS reads
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -818,6 +819,481 @@ int launch_stream(const half_t* qkv, half_t* out, int N, int L, int H, int causa
   return check_launch("attention_stream_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ring kernel (round 5) for non-causal sequences longer than one key block: ViT-L/14 (257 tokens) and ViT-L/14@336 (577 tokens; BASELINE
+// configs[4], clip/model.py:181-183 at the geometry of clip/clip.py:38).  The streaming kernel above spends ~900 cycles per (32 queries x
+// 32 keys) tile where the matrix pipe needs 256-320: compiler-placed fragment reads (an LDS round trip in front of every MFMA), one
+// workgroup per CU, K | V re-staged per query split behind a load -> wait -> barrier -> compute chain.  Here:
+//
+//   * persistent workgroups (one per CU, 8 waves = two per SIMD, 256 registers each) walk the (sequence, head) items; all 8 waves
+//     compute, each on the 32-query tile it holds in registers (the round-3 vision form: S^T = K Q^T, a lane owns a query column,
+//     softmax in registers, P is directly the B operand of O^T += V^T P^T), with every LDS fragment read pinned ahead of its MFMA;
+//   * the keys of an item pass by in BLOCKS of 128 (K | V: 32 KiB) through a THREE-slot LDS ring filled by LDS-DMA: at step g the 8
+//     waves issue the 32 pieces of block g + 2 (4 each: no loader wave -- a ninth wave would put three on one SIMD and cap every wave
+//     at 168 registers), so a block has two whole steps to land; one workgroup barrier per block;
+//   * an item's query tiles are worked in PASSES of 8 (577 tokens: 19 tiles = 8 + 8 + 3); the 32 rows x 128 B of a wave's Q tile come by
+//     DMA into its own 4 KiB of LDS a whole pass ahead.  The last pass of an item has fewer tiles than waves: its tiles are SPLIT over
+//     the idle waves by key tile within every block (577: two tiles on two waves each, the one-row class... last tile on four), and the
+//     partial (max, sum, O) of a tile are merged through the ring slot that falls free at the pass end -- 19 tile-passes cost
+//     2 + 3/8 passes instead of 3 (the plan is built on the host: RingPlan);
+//   * output tiles leave as full 128-byte lines, non-temporal (store_out_lines), staged in the same free slot.
+//
+// LDS: 3 x 32 KiB ring + 32 KiB of Q tiles = 128 KiB.  vmcnt discipline: every wave issues exactly 4 pieces per block, so
+// `s_waitcnt vmcnt(4)` at step g leaves at most the 4 youngest operations in flight -- block g + 1's pieces or something younger
+// still -- and block g's pieces (two steps old) have landed; Q pieces are at least one block older than the block they are waited
+// with (needs >= 2 blocks per item: L > 128).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RTPB = 4;                     // key tiles per block
+constexpr int RKEYS = RTPB * 32;            // keys per block
+constexpr int RIMG = RKEYS * 128;           // one operand image of a block
+constexpr int RSLOT = 2 * RIMG;             // K | V
+constexpr int RNSLOT = 3;
+constexpr int RQ = 8 * 32 * 128;            // the eight Q tiles of a pass
+constexpr int RSMEM = RNSLOT * RSLOT + RQ;  // 131072
+constexpr int RSPOT = 8192 + 512;           // a partial: O (32 registers x 64 lanes x 4 B) + m + l per lane
+constexpr int RMAXPASS = 8;                 // 8 passes x 8 tiles x 32 rows = 2048 tokens
+
+// 32-bit words only: a wave reads its entry by a wave-uniform index, which must stay a scalar load (a byte array in the kernel arguments is
+// read with global_load_sbyte + s_waitcnt vmcnt(0), and that wait would drain the DMA ring at every step).
+struct RingPlan {
+  int n_pass, n_blocks, n_rounds;   // passes per item; key blocks per item; merge rounds of the split (last) pass (0: not split)
+  // LAST pass, wave w: bits 0-7 query tile + 1 (0: idle) | 8-9 first key tile of every block | 10-12 key tiles per block | 13-15 the wave that
+  // owns the tile's result (== w: this wave stores it) | 16-17 merge round (partner waves) | 18-19 scratch spot.  Earlier passes: tile 8 p + w, whole blocks.
+  unsigned info[8];
+};
+__host__ __device__ inline int ring_qt(unsigned i) { return (int)(i & 255u) - 1; }
+__host__ __device__ inline int ring_first(unsigned i) { return (int)((i >> 8) & 3u); }
+__host__ __device__ inline int ring_count(unsigned i) { return (int)((i >> 10) & 7u); }
+__host__ __device__ inline int ring_leader(unsigned i) { return (int)((i >> 13) & 7u); }
+__host__ __device__ inline int ring_round(unsigned i) { return (int)((i >> 16) & 3u); }
+__host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 18) & 3u); }
+
+// One block's share of a wave: CNT key tiles (LDS images at ka / va, first key = k_lo) against the wave's 32 queries.  One softmax
+// group per call; fragment reads pinned as in attend_dense_pf; only the item's very last key tile can hold keys >= L (wave-uniform test).
+#ifdef CLIPMI_TUNING
+#define CLIPMI_RING_STAMP(slot, dep) do { asm volatile("" :: "v"(dep)); if (sp) sp[slot] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CLIPMI_RING_STAMP(slot, dep) do { } while (0)
+#endif
+// One softmax group of CNT (1 or 2) key tiles (LDS images at ka / va, first key = k_lo) against the wave's 32 queries; a block of four tiles is
+// two groups, so that a wave alternates a matrix-bound S phase with a vector-bound P.V phase twice per block and the two waves of a SIMD, half a
+// phase apart (see the kernel), overlap one's MFMAs with the other's exponentials.  Fragment reads pinned as in attend_dense_pf; only the item's
+// very last key tile can hold keys >= L (wave-uniform test).  `ones`: the all-ones A operand of the row-sum MFMA, defined ONCE per wave by inline
+// asm (the compiler cannot re-materialise it in front of its use, so it needs no fence); one fence per 16-key step covers P and both V tiles.
+template <int CNT>
+__device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint32_t (&va)[2], const f16x8 (&qf)[4], const f16x8& ones, int k_lo, int L,
+                                            int hh, float& m_run, f32x16 (&oacc)[2], float& l_run, long long* sp = nullptr) {
+  constexpr float C = 0.125f * LOG2E;
+  const f32x16 zero16 = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f16x8 kf[2][4];
+  f16x4 vf[2][4];
+  f32x16 s[CNT];
+  static_assert(CNT == 1 || CNT == 2, "one or two key tiles per softmax group");
+  read_k<0>(kf[0], ka);
+  auto s_tile = [&](auto t_tag) {
+    constexpr int T = decltype(t_tag)::value;
+    constexpr int CUR = T & 1;
+    if constexpr (T + 1 < CNT) {
+      read_k<T + 1>(kf[CUR ^ 1], ka);
+      lds_wait4<4>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
+    } else {
+      lds_wait4<0>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
+    }
+    s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+    if (k_lo + T * 32 + 32 > L) {   // wave-uniform: the item's last key tile
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = k_lo + T * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        s[T][e] = key >= L ? NEG_BIG : s[T][e];
+      }
+    }
+  };
+  s_tile(std::integral_constant<int, 0>{});
+  if constexpr (CNT > 1) s_tile(std::integral_constant<int, 1>{});
+  CLIPMI_RING_STAMP(3, s[CNT - 1][0]);
+  read_v<0>(vf[0], va);   // the P.V phase opens with these: behind the maximum and the rescale by the time they are needed
+  float mloc = NEG_BIG;
+#pragma unroll
+  for (int t = 0; t < CNT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+  mloc = fmaxf(mloc, swap32_f(mloc));
+  const float m_new = fmaxf(m_run, mloc);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull, 0)) {   // wave-uniform; exact either way (alpha == 1 where the maximum stands)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    l_run *= alpha;
+    CLIPMI_VALU_TO_MFMA_FENCE2(oacc[0], oacc[1]);   // VALU-written accumulators are MFMA sources (SrcC) below
+  }
+  f32x16 lacc;
+  const float mc = m_new * C;
+  m_run = m_new;
+  CLIPMI_RING_STAMP(4, mc);
+  auto pv_step = [&](auto t_tag, auto ss_tag) {
+    constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
+    constexpr int STEP = T * 2 + SS, CUR = STEP & 1;
+    constexpr bool LAST = STEP == 2 * CNT - 1;
+    if constexpr (!LAST) read_v<((STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
+    f16x8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
+    if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+    else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+    f16x8 v8[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const f16x4 lo = vf[CUR][dt * 2], hi = vf[CUR][dt * 2 + 1];
+      v8[dt] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    CLIPMI_VALU_TO_MFMA_FENCE3(pf, v8[0], v8[1]);   // ONE fence: P comes from conversions, the V halves may have been moved together by VALU copies
+    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[0], pf, oacc[0], 0, 0, 0);
+    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[1], pf, oacc[1], 0, 0, 0);
+    if constexpr (STEP == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, zero16, 0, 0, 0);
+    else lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+  };
+  pv_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  pv_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  if constexpr (CNT > 1) {
+    pv_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    pv_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  }
+  l_run += lacc[0];   // every row of the ones-tile holds the same sum
+}
+
+// diagnostic build: stamps[((workgroup * 64 + step) * 9 + wave) * 8 + k], s_memtime (shader cycles) of lane 0, workgroups 0..7, steps 0..63.
+// compute waves 0-7: 0 loop top | 2 past the block's barrier | 3 S tiles of the LAST group issued | 4 its maximum + rescale done | 5 block computed | 6 step end
+// (pass end: merged + stored);  loader (wave 8): 0 loop top | 1 block g landed | 2 past the barrier | 7 DMA of block g + 2 (and the next Q tiles) issued
+__global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items,
+                                                             const RingPlan plan CLIPMI_VISION_STAMPS_PARAM) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7 compute, 8 loader
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int D = H * 64;
+  const int ld = 3 * D;                                   // halves per qkv row (< 2^31 / L: checked by the launcher)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int P = plan.n_pass, NB = plan.n_blocks;
+  const int gstride = gridDim.x;
+  const int my_items = (int)blockIdx.x < n_items ? (n_items - 1 - (int)blockIdx.x) / gstride + 1 : 0;
+  const int n_steps = my_items * P * NB;
+  if (n_steps == 0) return;
+
+  // ---- cursors over the stream of (item, pass, block) steps, each with its (sequence, head) kept incrementally (no division per step)
+  struct Cur { int item, n, h, p, b; };
+  const int dn = gstride / H, dh = gstride - dn * H;
+  auto next_item = [&](Cur& u) {
+    u.item += gstride;
+    u.n += dn;
+    u.h += dh;
+    if (u.h >= H) { u.h -= H; ++u.n; }
+  };
+  auto advance = [&](Cur& u) {
+    if (++u.b == NB) { u.b = 0; if (++u.p == P) { u.p = 0; next_item(u); } }
+  };
+  Cur c{(int)blockIdx.x, (int)blockIdx.x / H, (int)blockIdx.x % H, 0, 0};
+
+  if (wave == 8) {
+    // ================= loader wave: every LDS-DMA piece of the workgroup (a dedicated wave issues a piece in tens of cycles; a wave in the middle of
+    // MFMA / exponent work was measured at ~200 per piece, a fifth of the step: profiles/r05_vitl_attention.txt) =================
+    // A piece = 8 rows x 128 B; lane -> row lr of the piece, 16-byte chunk cs.  Lane-constant byte offsets by piece parity (the swizzle of a row
+    // depends on (row >> 1) & 7 = ((lr >> 1) + 4 (piece & 1)) & 7); a piece adds one scalar (its rows' offset) per operand.
+    const int lr = lane >> 3, cs = lane & 7;
+    const int lane_row = lr * ld * 2;
+    const int swv = (cs ^ (((lr >> 1) & 1) << 2)) << 4;                                      // V: chunk ^ (((row >> 1) & 1) << 2)
+    const int swk[2] = {(cs ^ (lr >> 1)) << 4, (cs ^ (4 + (lr >> 1))) << 4};                  // K, Q: chunk ^ ((row >> 1) & 7), by piece parity
+    const int piece_bytes = 8 * ld * 2;
+    auto radd = [](int base, int add) {
+      int r;
+      asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(base), "s"(add));
+      return r;
+    };
+    auto item_rsrc = [&](const Cur& u) {
+      return make_rsrc(qkv + (int64_t)u.n * L * ld + u.h * 64, ((int64_t)L * ld - u.h * 64) * 2);   // rows >= L: outside the descriptor, read as zero
+    };
+    auto dma_block = [&](const Cur& u, int slot) {   // 32 pieces: K | V of 128 keys
+      const __amdgpu_buffer_rsrc_t rs = item_rsrc(u);
+      char* B = smem + slot * RSLOT;
+      const int boff = u.b * RKEYS * ld * 2;
+#pragma unroll
+      for (int pc = 0; pc < RKEYS / 8; ++pc) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + pc * 1024), 16, radd(lane_row + swk[pc & 1] + D * 2, boff + pc * piece_bytes), 0, 0, 0);          // K
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + RIMG + pc * 1024), 16, radd(lane_row + swv + 2 * D * 2, boff + pc * piece_bytes), 0, 0, 0);     // V
+      }
+    };
+    auto dma_q = [&](const Cur& u) {   // the Q tiles of pass u.p, tile of wave w into region w: 32 pieces
+      const __amdgpu_buffer_rsrc_t rs = item_rsrc(u);
+      char* Q = smem + RNSLOT * RSLOT;
+      for (int w = 0; w < 8; ++w) {
+        int qt = u.p == P - 1 ? ring_qt(plan.info[w]) : u.p * 8 + w;
+        qt = qt < 0 ? 0 : qt;
+        const int toff = qt * 32 * ld * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(Q + w * 4096 + j * 1024), 16, radd(lane_row + swk[j & 1], toff + j * piece_bytes), 0, 0, 0);
+      }
+    };
+    Cur f = c, q = c;
+    auto next_pass = [&](Cur& u) {
+      if (++u.p == P) { u.p = 0; next_item(u); }
+    };
+    dma_q(q);
+    next_pass(q);
+    dma_block(f, 0);
+    advance(f);
+    if (n_steps > 1) {
+      dma_block(f, 1);
+      advance(f);
+    }
+    for (int g = 0; g < n_steps; ++g) {
+#ifdef CLIPMI_TUNING
+      long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * 9 + wave) * 8 : nullptr;
+      if (sp) sp[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      // Block g (and every Q tile a pass start needs) has landed once at most the 32 youngest pieces are in flight: those are block g + 1's, issued
+      // a step after block g's; the Q pieces of a step are issued BEFORE its block pieces, so they are never among the 32 youngest when needed.
+      if (g + 1 < n_steps) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CLIPMI_TUNING
+      if (sp) sp[1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      __builtin_amdgcn_s_barrier();   // block g is in LDS for every wave; every wave is done with block g - 1, whose slot block g + 2 takes
+#ifdef CLIPMI_TUNING
+      if (sp) sp[2] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      // the NEXT pass's Q tiles go out one step AFTER the pass start: by this barrier every compute wave has taken its fragments of the current ones
+      if (c.b == 1 && q.item < n_items) {
+        dma_q(q);
+        next_pass(q);
+      }
+      if (g + 2 < n_steps) {
+        dma_block(f, (g + 2) % RNSLOT);
+        advance(f);
+      }
+#ifdef CLIPMI_TUNING
+      if (sp) sp[7] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+      if (c.b == NB - 1 && c.p == P - 1 && plan.n_rounds > 0) {   // the compute waves' merge barriers of a split pass end (below): 1 + 2 per round - 1
+        const int nbar = 2 * plan.n_rounds;
+        for (int i = 0; i < nbar; ++i) __builtin_amdgcn_s_barrier();
+      }
+      advance(c);
+    }
+    return;
+  }
+
+  // ================= compute waves: no vector-memory LOAD in their instruction stream =================
+#ifndef CLIPMI_RING_VARIANT
+#define CLIPMI_RING_VARIANT 0
+#endif
+  const bool late = wave >= 4;   // the second (younger) wave of every SIMD: it loses the arbitration for the vector issue port to its partner
+  if (CLIPMI_RING_VARIANT == 1 && late) __builtin_amdgcn_s_setprio(1);
+  const unsigned my_info = plan.info[wave];             // (scalar load, once: see RingPlan)
+  const int last_qt = ring_qt(my_info);
+  const int kswz = (r32 >> 1) & 7;
+  int kro[4], vro[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  {
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int fq = (qq >> 1) & 1;
+    const int lane_base = RIMG + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+    vro[0] = lane_base + fq * 64;
+    vro[1] = lane_base + (1 - fq) * 64;
+  }
+  f16x8 qf[4], ones;
+  {   // 1.0 in every half: defined by inline asm, never written again
+    unsigned o0, o1, o2, o3;
+    asm volatile("v_mov_b32 %0, 0x3c003c00\n\tv_mov_b32 %1, 0x3c003c00\n\tv_mov_b32 %2, 0x3c003c00\n\tv_mov_b32 %3, 0x3c003c00\n\ts_nop 3"
+                 : "=v"(o0), "=v"(o1), "=v"(o2), "=v"(o3));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    ones = __builtin_bit_cast(f16x8, u32x4{o0, o1, o2, o3});
+  }
+  f32x16 oacc[2];
+  float m_run = NEG_BIG, l_run = 0.f;
+  const uint32_t q_lds = lds_base + (uint32_t)(RNSLOT * RSLOT + wave * 4096);
+  const uint32_t qa[4] = {q_lds + (uint32_t)kro[0], q_lds + (uint32_t)kro[1], q_lds + (uint32_t)kro[2], q_lds + (uint32_t)kro[3]};
+
+  for (int g = 0; g < n_steps; ++g) {
+    const int slot = g % RNSLOT;
+#ifdef CLIPMI_TUNING
+    long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * 9 + wave) * 8 : nullptr;
+    if (sp) sp[0] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();   // the loader's vmcnt wait came first: block g (and at a pass start this wave's Q tile) is in LDS
+#ifdef CLIPMI_TUNING
+    if (sp) sp[2] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    const bool split = c.p == P - 1 && plan.n_rounds > 0;
+    if (CLIPMI_RING_VARIANT == 4 && late) __builtin_amdgcn_s_sleep(4);
+    if (CLIPMI_RING_VARIANT == 5 && late) __builtin_amdgcn_s_sleep(8);
+    if (c.b == 0) {
+      read_k<0>(qf, qa);
+      lds_wait4<0>(qf[0], qf[1], qf[2], qf[3]);
+      m_run = NEG_BIG;
+      l_run = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; }
+      CLIPMI_VALU_TO_MFMA_FENCE2(oacc[0], oacc[1]);
+    }
+    // ---- this wave's share of block g
+    const int qt = c.p == P - 1 ? last_qt : c.p * 8 + wave;
+    {
+      int first = split ? ring_first(my_info) : 0, count = split ? ring_count(my_info) : RTPB;
+      const int live = (L - c.b * RKEYS + 31) >> 5;          // live key tiles of this block (>= 1)
+      if (first + count > live) count = live - first;
+      if (qt >= 0 && !(CLIPMI_RING_VARIANT == 6 && late) && !(CLIPMI_RING_VARIANT == 7 && !late)) {   // 6 / 7: timing only (half the waves idle)
+#ifdef CLIPMI_TUNING
+        long long* spa = sp;
+#else
+        long long* spa = nullptr;
+#endif
+        // two loops with ONE body each: the accumulators then stay in their registers (a loop whose body chooses between two instantiations, or
+        // a conditional rescale written on one element of an MFMA tuple, made hipcc copy all 48 accumulator registers at every join)
+        for (int grp = 0; count >= 2; count -= 2, first += 2, ++grp) {           // softmax groups of two key tiles ...
+          if (CLIPMI_RING_VARIANT == 2) { if (late && grp == 1) __builtin_amdgcn_s_setprio(1); }
+          if (CLIPMI_RING_VARIANT == 3) { if (late == (grp == 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+          const uint32_t sb = lds_base + (uint32_t)(slot * RSLOT + first * 4096);
+          const uint32_t ka[4] = {sb + (uint32_t)kro[0], sb + (uint32_t)kro[1], sb + (uint32_t)kro[2], sb + (uint32_t)kro[3]};
+          const uint32_t va[2] = {sb + (uint32_t)vro[0], sb + (uint32_t)vro[1]};
+          ring_attend<2>(ka, va, qf, ones, c.b * RKEYS + first * 32, L, hh, m_run, oacc, l_run, spa);
+        }
+        if (CLIPMI_RING_VARIANT == 2 || CLIPMI_RING_VARIANT == 3) __builtin_amdgcn_s_setprio(0);
+        for (; count >= 1; --count, ++first) {                   // ... and a last one of a single tile
+          const uint32_t sb = lds_base + (uint32_t)(slot * RSLOT + first * 4096);
+          const uint32_t ka[4] = {sb + (uint32_t)kro[0], sb + (uint32_t)kro[1], sb + (uint32_t)kro[2], sb + (uint32_t)kro[3]};
+          const uint32_t va[2] = {sb + (uint32_t)vro[0], sb + (uint32_t)vro[1]};
+          ring_attend<1>(ka, va, qf, ones, c.b * RKEYS + first * 32, L, hh, m_run, oacc, l_run, spa);
+        }
+      }
+    }
+#ifdef CLIPMI_TUNING
+    asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[1][15]), "v"(l_run));
+    if (sp) sp[5] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // ---- pass end: merge the partials of a split tile, store the tile
+    if (c.b == NB - 1) {
+      int owner = wave;
+      if (split) {
+        __builtin_amdgcn_s_barrier();   // every wave is done reading this block: its slot is scratch until the next step's barrier
+        const uint32_t scratch = lds_base + (uint32_t)(slot * RSLOT);
+        owner = ring_leader(my_info);
+        for (int round = 0; round < plan.n_rounds; ++round) {
+          if (owner != wave && ring_round(my_info) == round && qt >= 0) {   // partner: park (O, m, l)
+            const uint32_t spot = scratch + (uint32_t)(ring_spot(my_info) * RSPOT);
+#pragma unroll
+            for (int r4 = 0; r4 < 8; ++r4) {
+              const f32x4 v = f32x4{oacc[r4 >> 2][(r4 & 3) * 4 + 0], oacc[r4 >> 2][(r4 & 3) * 4 + 1], oacc[r4 >> 2][(r4 & 3) * 4 + 2], oacc[r4 >> 2][(r4 & 3) * 4 + 3]};
+              asm volatile("ds_write_b128 %0, %1" :: "v"(spot + (uint32_t)(r4 * 1024 + lane * 16)), "v"(v) : "memory");
+            }
+            asm volatile("ds_write_b32 %0, %1" :: "v"(spot + (uint32_t)(8192 + lane * 4)), "v"(m_run) : "memory");
+            asm volatile("ds_write_b32 %0, %1" :: "v"(spot + (uint32_t)(8192 + 256 + lane * 4)), "v"(l_run) : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (owner == wave && qt >= 0) {
+            constexpr float C = 0.125f * LOG2E;
+            for (int w2 = 0; w2 < 8; ++w2) {
+              const unsigned i2 = plan.info[w2];
+              if (w2 == wave || ring_leader(i2) != wave || ring_round(i2) != round || ring_qt(i2) < 0) continue;   // wave-uniform
+              const uint32_t spot = scratch + (uint32_t)(ring_spot(i2) * RSPOT);
+              float m2, l2;
+              f32x4 o2[8];
+              asm volatile("ds_read_b32 %0, %1" : "=v"(m2) : "v"(spot + (uint32_t)(8192 + lane * 4)) : "memory");
+              asm volatile("ds_read_b32 %0, %1" : "=v"(l2) : "v"(spot + (uint32_t)(8192 + 256 + lane * 4)) : "memory");
+#pragma unroll
+              for (int r4 = 0; r4 < 8; ++r4) asm volatile("ds_read_b128 %0, %1" : "=v"(o2[r4]) : "v"(spot + (uint32_t)(r4 * 1024 + lane * 16)) : "memory");
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m2), "+v"(l2), "+v"(o2[0]), "+v"(o2[1]), "+v"(o2[2]), "+v"(o2[3]), "+v"(o2[4]), "+v"(o2[5]), "+v"(o2[6]), "+v"(o2[7]) :: "memory");
+              const float m_new = fmaxf(m_run, m2);
+              const float a1 = __builtin_amdgcn_exp2f((m_run - m_new) * C), a2 = __builtin_amdgcn_exp2f((m2 - m_new) * C);
+#pragma unroll
+              for (int r4 = 0; r4 < 8; ++r4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[r4 >> 2][(r4 & 3) * 4 + e] = oacc[r4 >> 2][(r4 & 3) * 4 + e] * a1 + o2[r4][e] * a2;
+              l_run = l_run * a1 + l2 * a2;
+              m_run = m_new;
+            }
+          }
+          if (round + 1 < plan.n_rounds) __builtin_amdgcn_s_barrier();   // the spots are free again for the next round
+        }
+      }
+      // Straight from the registers: four 16-byte stores per lane (store_out).  The tile is 1 / 19 of the item's traffic here, not a quarter as in
+      // the 197-token kernel: full-line staging through LDS would need a free region -- i.e. one more workgroup barrier per pass.
+      const bool stores = owner == wave && qt >= 0;          // wave-uniform; every lane of a storing wave takes part in store_out's lane swaps
+      if (stores) {
+        const int q0 = qt * 32;
+        store_out(out + ((int64_t)c.n * L + (q0 + r32 < L ? q0 + r32 : L - 1)) * D + c.h * 64, oacc, l_run, hh, q0 + r32 < L);
+      }
+    }
+#ifdef CLIPMI_TUNING
+    if (sp) sp[6] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    advance(c);
+  }
+}
+
+// Host side of the plan: passes of 8 query tiles; the tiles of a short last pass are split over the waves by key tile.
+static RingPlan make_ring_plan(int L) {
+  RingPlan pl;
+  memset(&pl, 0, sizeof(pl));
+  const int nqt = (L + 31) / 32;
+  pl.n_pass = (nqt + 7) / 8;
+  pl.n_blocks = (L + RKEYS - 1) / RKEYS;
+  auto pack = [](int qt, int first, int count, int leader, int round, int spot) {
+    return (unsigned)(qt + 1) | (unsigned)first << 8 | (unsigned)count << 10 | (unsigned)leader << 13 | (unsigned)round << 16 | (unsigned)spot << 18;
+  };
+  const int base = (pl.n_pass - 1) * 8;
+  const int R = nqt - base;                                // tiles of the last pass (1..8)
+  for (int w = 0; w < 8; ++w) pl.info[w] = pack(w < R ? base + w : -1, 0, RTPB, w, 0, 0);
+  if (R < 8) {
+    // ways[i] in {1, 2, 4}: double the tile with the fewest ways while the waves last (ties: the LAST tile first -- the ragged one)
+    int ways[8];
+    for (int i = 0; i < R; ++i) ways[i] = 1;
+    for (;;) {
+      int used = 0, best = -1;
+      for (int i = 0; i < R; ++i) used += ways[i];
+      for (int i = R - 1; i >= 0; --i)
+        if (ways[i] < RTPB && used + ways[i] <= 8 && (best < 0 || ways[i] < ways[best])) best = i;
+      if (best < 0) break;
+      ways[best] *= 2;
+    }
+    // waves in order of DESCENDING share (count = RTPB / ways), so that wave w and wave w + 4 -- the two waves of a SIMD -- pair a heavy and a light share
+    int w = 0, partners = 0;
+    for (int w2 = 0; w2 < 8; ++w2) pl.info[w2] = pack(-1, 0, RTPB, w2, 0, 0);
+    for (int cnt = RTPB; cnt >= 1; cnt /= 2)
+      for (int i = 0; i < R; ++i) {
+        if (RTPB / ways[i] != cnt) continue;
+        const int lead = w;
+        for (int j = 0; j < ways[i]; ++j, ++w) {
+          pl.info[w] = pack(base + i, j * cnt, cnt, lead, j > 0 ? partners / 3 : 0, j > 0 ? partners % 3 : 0);
+          if (j > 0) ++partners;
+        }
+      }
+    pl.n_rounds = (partners + 2) / 3;
+  }
+  return pl;
+}
+
+int launch_ring(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s) {
+  static DeviceOnce attr_once;
+  ensure_dynamic_lds(attention_ring_kernel, RSMEM, attr_once);
+  const RingPlan plan = make_ring_plan(L);
+  const int n_cu = device_cus();
+  const int n_items = N * H;
+  const int grid = n_items < n_cu ? n_items : n_cu;
+#ifdef CLIPMI_TUNING
+  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(576), RSMEM, s, qkv, out, L, H, n_items, plan, g_tuning_stamps.load(std::memory_order_relaxed));
+#else
+  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(576), RSMEM, s, qkv, out, L, H, n_items, plan);   // 8 compute waves + the loader
+#endif
+  return check_launch("attention_ring_kernel");
+}
+
 template <int NKT, int GROUP, int DENSE>
 int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
@@ -858,7 +1334,12 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
     }
     return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
   }
-  // two-slot ring of key blocks: 257 tokens (ViT-L/14) with 128-key blocks, 577 tokens (ViT-L/14@336) with 224-key blocks
+  // Longer than one key block (ViT-L/14: 257 tokens, ViT-L/14@336: 577).  Non-causal (every CLIP tower of that length): the ring kernel --
+  // persistent workgroups, 128-key blocks through a three-slot LDS ring, pinned fragment reads, query tiles in passes of eight with the last
+  // pass split by key tile.  Option attn_ring = 0, a causal mask, or a shape outside its limits keep the round-1 streaming kernel
+  // (two-slot ring of 128- / 224-key blocks; the reference of the ring kernel's parity test).
+  if (!causal && options().attn_ring.load(std::memory_order_relaxed) != 0 && L <= RMAXPASS * 8 * 32 && (int64_t)L * 3 * H * 64 * 2 < (1ll << 31))
+    return launch_ring(qkv, out, N, L, H, s);
   return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
 }
 

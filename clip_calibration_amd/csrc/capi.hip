@@ -43,6 +43,7 @@ const OptionDesc kOptions[] = {
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_loader", "CLIPMI_ATTN_LOADER", &Options::attn_loader},
+    {"attn_ring", "CLIPMI_ATTN_RING", &Options::attn_ring},
     {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
     {"vision_pass", "CLIPMI_VISION_PASS", &Options::vision_pass},
 };
@@ -237,18 +238,27 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
   }
 }
 
-// clipmi_encode_image_timed: one hipEvent behind every launch of a real tower pass (recorded asynchronously, read after the pass)
+// clipmi_encode_image_timed: one hipEvent behind every launch of a real tower pass (recorded asynchronously, read after the pass).  All events are
+// created BEFORE the first launch (reserve): between launches tick() only records, so no event creation lands in a measured launch gap.
 struct LaunchTimer {
   hipStream_t s;
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> pool, ev;
   bool ok = true;
+  bool reserve(int n) {
+    for (int i = 0; i < n; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) { ok = false; return false; }
+      pool.push_back(e);
+    }
+    return true;
+  }
   void tick() {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) { ok = false; return; }
+    if (ev.size() >= pool.size()) { ok = false; return; }
+    hipEvent_t e = pool[ev.size()];
     ev.push_back(e);
     if (hipEventRecord(e, s) != hipSuccess) ok = false;
   }
-  ~LaunchTimer() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  ~LaunchTimer() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
 };
 
 int run_block(const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded, int* parts,
@@ -779,6 +789,9 @@ int clipmi_encode_image_timed(clipmi_model* m, const void* image, int image_dtyp
                  "encode_image_timed: batch=%d must be one pass of the tower (option vision_pass)", batch);
   LaunchTimer timer;
   timer.s = (hipStream_t)stream;
+  const int max_events = 1 + 4 + 5 * m->g.vision_layers + 2;   // pass start, at most 4 embedding launches, 5 per block, ln_post + projection
+  CLIPMI_REQUIRE(n_us >= max_events - 1, CLIPMI_ERR_ARG, "encode_image_timed: us_out holds %d entries, up to %d needed", n_us, max_events - 1);
+  CLIPMI_REQUIRE(timer.reserve(max_events), CLIPMI_ERR_HIP, "encode_image_timed: hipEventCreate failed");
   int n_pre = 0;
   int rc = encode_image_pass(m, image, image_dtype, batch, nullptr, out, workspace, workspace_bytes, flags, stream, &timer, &n_pre);
   if (rc) return rc;

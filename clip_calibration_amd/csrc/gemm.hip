@@ -1298,6 +1298,10 @@ __global__ __launch_bounds__(T::NT, T::OCC) void gemm_pp_kernel(const KArgs a) {
   };
   // IM2COL: byte offset of the lane's 8 pixels of K-step 0 for each of its activation pieces (piece P = tile rows P * 64 + srow); rows at or
   // beyond M point past the descriptor and read as zero.  The lane's data chunk `schunk` is row segment schunk / (P / 8), pixels (schunk % (P / 8)) * 8 ..
+  // INVARIANT (tail rows): "read as zero" leans on the raw-buffer range check seeing voffset 0xFFFFFF00 + the K-step's scalar offset as out of range,
+  // which holds while num_records < 0x7FFFFF00 and the sum does not wrap (K-step offsets stay far below 2^24 for any CLIP image).  It is NOT relied on
+  // for results: rows >= M are never stored, and no epilogue of this mode (EPI_PATCH_POS only) reduces over rows.  A future IM2COL epilogue that
+  // does (row statistics, a fold) must clamp tail rows to a valid row instead, as epilogue_patch_pos_f16 does with its output rows.
   int xim[IM2COL ? T::XI : 1];
   int im_spc = 1, im_rps = 1;   // K-steps per channel, image rows per K-step
   if constexpr (IM2COL) {

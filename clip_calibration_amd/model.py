@@ -415,7 +415,12 @@ class CLIP(nn.Module):
 
     def _workspace(self, kind: str, nbytes: int) -> torch.Tensor:
         """Tower workspace of the CURRENT stream: launches on one stream run in order and may share a buffer; two tower calls in flight on
-        different streams (batches pipelined over two streams, the text tower beside the image tower) must not."""
+        different streams (batches pipelined over two streams, the text tower beside the image tower) must not.
+        Eviction (more than 8 (kind, stream) keys) drops a buffer that may still have a pass in flight on ITS stream.  That is safe because of
+        one property of torch's caching allocator this code relies on: a freed block is handed out again only to allocations made under the
+        stream it was allocated under (other streams get it after an event recorded at the free has passed), and a workspace is always allocated
+        under the stream that keys it -- so a re-use is stream-ordered behind the evicted buffer's last launch.  Cycling through more than 8
+        keys re-allocates (possibly a hipMalloc) on the hot path: keep to a handful of streams per model."""
         key = (kind, torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0)
         ws = self._ws.pop(key, None)
         if ws is None or ws.numel() < nbytes or ws.device != self.device:

@@ -298,6 +298,52 @@ def test_attention_vision_kernel_vs_persistent(ops, clipmi_option, n, l, h):
     assert err < 4e-3, f"max err {err}"
 
 
+@pytest.mark.parametrize("n,l,h", [(1, 577, 4), (2, 257, 16), (3, 225, 2), (1, 256, 1), (2, 300, 3), (1, 384, 2), (1, 512, 1), (2, 545, 2), (1, 576, 2),
+                                   (1, 640, 1), (1, 1025, 1), (70, 257, 16), (40, 577, 16)])
+def test_attention_ring_kernel(ops, clipmi_option, n, l, h):
+    """Non-causal attention over more than 224 tokens (ViT-L/14: 257, ViT-L/14@336: 577; clip/model.py:181-183): the ring kernel -- 128-key blocks
+    through a three-slot LDS ring, query tiles in passes of eight, the last pass split over the waves by key tile and merged -- against the fp32
+    reference and against the round-1 streaming kernel (attn_ring 0; another summation order: not the same bits).  Lengths that end a pass exactly
+    (256, 512), leave one row for the last tile (257, 577, 1025), split two / four / eight ways (300: 2 tiles, 384: 4, 545: 2 passes + 2, 640: 4);
+    the last two cases give every workgroup several items (ring and Q prefetch across item seams)."""
+    g = torch.Generator().manual_seed(n * 1000 + l + h)
+    qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
+    dq = _cuda(qkv)
+    got = ops.attention(dq, n, l, h, False)
+    again = ops.attention(dq, n, l, h, False)
+    clipmi_option("attn_ring", 0)
+    base = ops.attention(dq, n, l, h, False)
+    assert torch.equal(got, again), "not deterministic"
+    assert torch.isfinite(got.float()).all()
+    # another summation order, then one fp16 rounding of the output: one unit in the last place (2^-10 relative) apart at most, plus the absolute floor
+    d = ((got.float() - base.float()).abs() - base.float().abs() * 2.0 ** -10).max().item()
+    assert d < 2e-3, f"ring vs streaming kernel: {d}"
+    ns = min(n, 2)
+    ref = _attn_ref(qkv[: ns * l], ns, l, h, False)
+    for name, x in (("ring", got), ("stream", base)):
+        err = (x[: ns * l].float().cpu() - ref).abs().max().item()
+        assert err < 4e-3, f"{name}: max err {err}"
+    if n > 2:      # and the LAST sequence (the tail of the persistent walk)
+        ref = _attn_ref(qkv[(n - 1) * l:], 1, l, h, False)
+        err = (got[(n - 1) * l:].float().cpu() - ref).abs().max().item()
+        assert err < 4e-3, f"last sequence: max err {err}"
+
+
+def test_attention_ring_peaked_rows(ops):
+    """A dominant key in the LAST block and large queries: the running maximum moves late (rescale across blocks, and across the merged partials)."""
+    n, l, h = 1, 577, 2
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(n * l, 3 * 64 * h, generator=g)
+    qkv[:, :128] *= 5.0
+    qkv[570, 128:256] *= 5.0
+    qkv[3, 128:256] *= 4.0
+    qkv = qkv.half()
+    ref = _attn_ref(qkv, n, l, h, False)
+    got = ops.attention(_cuda(qkv), n, l, h, False).float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 8e-3
+
+
 def test_attention_peaked_rows(ops):
     """softmax with a dominant key (forces large score ranges through the online rescale across key groups)."""
     n, l, h = 1, 197, 2
