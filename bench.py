@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16
 HBM_PEAK_BYTES_PER_S = 8.0e12        # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 MFMA_PEAK_CLOCK_MHZ = 2400.0         # the clock the 2.5 PF figure is quoted at (same guide, peaks table)
-CPU_BASELINE_THREADS = 32            # fastest of 8 / 16 / 32 / 64 on the GPU box's host (profiles/r05_cpu_baseline_threads.txt)
+CPU_BASELINE_THREADS = 16            # fastest of 8 / 16 / 32 / 64 / 128 on the GPU box host in two sweeps (profiles/r05_cpu_baseline_threads.txt)
 CPU_BASELINE_WARMUPS = 2
 
 

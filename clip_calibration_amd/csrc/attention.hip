@@ -965,6 +965,19 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
   l_run += lacc[0];   // every row of the ones-tile holds the same sum
 }
 
+// The lane's LDS byte offsets of its four K (or Q) fragments and its two transposed-V read bases inside a (K | V) block image.
+__device__ __forceinline__ void frag_offsets(int lane, int (&kro)[4], int (&vro)[2]) {
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int kswz = (r32 >> 1) & 7;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+  const int fq = (qq >> 1) & 1;
+  const int lane_base = RIMG + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+  vro[0] = lane_base + fq * 64;
+  vro[1] = lane_base + (1 - fq) * 64;
+}
+
 // diagnostic build: stamps[((workgroup * 64 + step) * 9 + wave) * 8 + k], s_memtime (shader cycles) of lane 0, workgroups 0..7, steps 0..63.
 // compute waves 0-7: 0 loop top | 2 past the block's barrier | 3 S tiles of the LAST group issued | 4 its maximum + rescale done | 5 block computed | 6 step end
 // (pass end: merged + stored);  loader (wave 8): 0 loop top | 1 block g landed | 2 past the barrier | 7 DMA of block g + 2 (and the next Q tiles) issued
@@ -1088,24 +1101,10 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
   }
 
   // ================= compute waves: no vector-memory LOAD in their instruction stream =================
-#ifndef CLIPMI_RING_VARIANT
-#define CLIPMI_RING_VARIANT 0
-#endif
-  const bool late = wave >= 4;   // the second (younger) wave of every SIMD: it loses the arbitration for the vector issue port to its partner
-  if (CLIPMI_RING_VARIANT == 1 && late) __builtin_amdgcn_s_setprio(1);
   const unsigned my_info = plan.info[wave];             // (scalar load, once: see RingPlan)
   const int last_qt = ring_qt(my_info);
-  const int kswz = (r32 >> 1) & 7;
   int kro[4], vro[2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kro[ks] = r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
-  {
-    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
-    const int fq = (qq >> 1) & 1;
-    const int lane_base = RIMG + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
-    vro[0] = lane_base + fq * 64;
-    vro[1] = lane_base + (1 - fq) * 64;
-  }
+  frag_offsets(lane, kro, vro);
   f16x8 qf[4], ones;
   {   // 1.0 in every half: defined by inline asm, never written again
     unsigned o0, o1, o2, o3;
@@ -1117,7 +1116,6 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
   f32x16 oacc[2];
   float m_run = NEG_BIG, l_run = 0.f;
   const uint32_t q_lds = lds_base + (uint32_t)(RNSLOT * RSLOT + wave * 4096);
-  const uint32_t qa[4] = {q_lds + (uint32_t)kro[0], q_lds + (uint32_t)kro[1], q_lds + (uint32_t)kro[2], q_lds + (uint32_t)kro[3]};
 
   for (int g = 0; g < n_steps; ++g) {
     const int slot = g % RNSLOT;
@@ -1128,11 +1126,12 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
     __builtin_amdgcn_s_barrier();   // the loader's vmcnt wait came first: block g (and at a pass start this wave's Q tile) is in LDS
 #ifdef CLIPMI_TUNING
     if (sp) sp[2] = (long long)__builtin_amdgcn_s_memtime();
+    if (sp) sp[1] = (long long)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_ID.SIMD_ID of this wave (compute waves have no stamp 1)
 #endif
     const bool split = c.p == P - 1 && plan.n_rounds > 0;
-    if (CLIPMI_RING_VARIANT == 4 && late) __builtin_amdgcn_s_sleep(4);
-    if (CLIPMI_RING_VARIANT == 5 && late) __builtin_amdgcn_s_sleep(8);
     if (c.b == 0) {
+      auto qat = [&](int off) { uint32_t r; asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(off), "s"(q_lds)); return r; };
+      const uint32_t qa[4] = {qat(kro[0]), qat(kro[1]), qat(kro[2]), qat(kro[3])};
       read_k<0>(qf, qa);
       lds_wait4<0>(qf[0], qf[1], qf[2], qf[3]);
       m_run = NEG_BIG;
@@ -1147,7 +1146,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
       int first = split ? ring_first(my_info) : 0, count = split ? ring_count(my_info) : RTPB;
       const int live = (L - c.b * RKEYS + 31) >> 5;          // live key tiles of this block (>= 1)
       if (first + count > live) count = live - first;
-      if (qt >= 0 && !(CLIPMI_RING_VARIANT == 6 && late) && !(CLIPMI_RING_VARIANT == 7 && !late)) {   // 6 / 7: timing only (half the waves idle)
+      if (qt >= 0) {
 #ifdef CLIPMI_TUNING
         long long* spa = sp;
 #else
@@ -1155,15 +1154,12 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
 #endif
         // two loops with ONE body each: the accumulators then stay in their registers (a loop whose body chooses between two instantiations, or
         // a conditional rescale written on one element of an MFMA tuple, made hipcc copy all 48 accumulator registers at every join)
-        for (int grp = 0; count >= 2; count -= 2, first += 2, ++grp) {           // softmax groups of two key tiles ...
-          if (CLIPMI_RING_VARIANT == 2) { if (late && grp == 1) __builtin_amdgcn_s_setprio(1); }
-          if (CLIPMI_RING_VARIANT == 3) { if (late == (grp == 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        for (; count >= 2; count -= 2, first += 2) {           // softmax groups of two key tiles ...
           const uint32_t sb = lds_base + (uint32_t)(slot * RSLOT + first * 4096);
           const uint32_t ka[4] = {sb + (uint32_t)kro[0], sb + (uint32_t)kro[1], sb + (uint32_t)kro[2], sb + (uint32_t)kro[3]};
           const uint32_t va[2] = {sb + (uint32_t)vro[0], sb + (uint32_t)vro[1]};
           ring_attend<2>(ka, va, qf, ones, c.b * RKEYS + first * 32, L, hh, m_run, oacc, l_run, spa);
         }
-        if (CLIPMI_RING_VARIANT == 2 || CLIPMI_RING_VARIANT == 3) __builtin_amdgcn_s_setprio(0);
         for (; count >= 1; --count, ++first) {                   // ... and a last one of a single tile
           const uint32_t sb = lds_base + (uint32_t)(slot * RSLOT + first * 4096);
           const uint32_t ka[4] = {sb + (uint32_t)kro[0], sb + (uint32_t)kro[1], sb + (uint32_t)kro[2], sb + (uint32_t)kro[3]};

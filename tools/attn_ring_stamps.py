@@ -29,6 +29,7 @@ nb = (l + 127) // 128
 npass = ((l + 31) // 32 + 7) // 8
 steps = min(64, (n * h // 256) * npass * nb)
 s = s[:, :steps]
+print("SIMD of compute waves 0-7 (HW_ID.SIMD_ID), workgroups 0-3:", [[int(s[wg, 0, w, 1]) for w in range(8)] for wg in range(4)])
 print(f"{steps} steps per workgroup ({npass} passes x {nb} blocks per item); span of workgroup 0: {(s[0, :, :8, 6].max() - s[0, 0, :8, 0].min()):.0f} cycles")
 for kind, sel in (("full-pass steps (not the last block)", lambda p, b: p < npass - 1 and b < nb - 1), ("full-pass LAST block", lambda p, b: p < npass - 1 and b == nb - 1),
                   ("split-pass steps (not the last block)", lambda p, b: p == npass - 1 and b < nb - 1), ("split-pass LAST block", lambda p, b: p == npass - 1 and b == nb - 1)):
