@@ -267,6 +267,37 @@ def test_coop_per_batch_towers_on_two_streams_same_bits():
         assert torch.equal(la, lb) and torch.equal(ta, tb) and torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(pa, pb), f"batch {k}"
 
 
+@pytest.mark.parametrize("how", ["fresh", "rebind", "load_state_dict"])
+def test_coop_two_stream_towers_first_call_after_a_bind(how):
+    """The FIRST thing a freshly built (or re-bound) model sees is `CustomCLIP.towers()` with the text tower on its side stream: weight binding is lazy
+    and packs BOTH towers' operands with torch ops on the current stream, so it must happen on the caller's stream before the fork -- otherwise the
+    image tower, launched on the caller's stream right behind, could read vision operands that the side stream is still folding.  Twenty fresh binds,
+    each against a model that was bound and warmed up on one stream; the bits must agree."""
+    from clip_calibration_amd.trainers import CoOpCLIP
+    sd, ref_model = _build("tiny")
+    ids = syn.synthetic_token_ids(24, "tiny", seed=5, n_ctx_placeholders=4)
+    ref = CoOpCLIP(ref_model, ids, n_ctx=4, seed=1, cache_text_features=False)
+    ref.overlap_towers = False
+    images = syn.synthetic_images(9, "tiny", seed=21).cuda()
+    want = ref(images, want_conf_pred=True)
+    torch.cuda.synchronize()
+    _, model = _build("tiny")
+    a = CoOpCLIP(model, ids, n_ctx=4, seed=1, cache_text_features=False)
+    for trial in range(20):
+        if how == "fresh":
+            _, model = _build("tiny")
+            a = CoOpCLIP(model, ids, n_ctx=4, seed=1, cache_text_features=False)
+        elif how == "rebind":
+            model.rebind()
+        else:
+            model.load_state_dict(model.state_dict())
+        assert model._bound is None
+        got = a(images, want_conf_pred=True)          # first call after the bind was dropped: goes through towers() on two streams
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w), f"{how}, trial {trial}"
+
+
 @pytest.mark.parametrize("cached", [True, False])
 def test_coop_dac_tempscaling_pipeline_vs_oracle(cached):
     """BASELINE config 3 (scaled down in C): CoOp prompts -> cached text features; DAC fit on the four text-feature
