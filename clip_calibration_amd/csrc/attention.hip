@@ -1290,6 +1290,72 @@ int launch_ring(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t
   return check_launch("attention_ring_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (L <= 32: the text tower after dead-row elimination -- CoOp prompts end at token ~22 of 77, zero-shot templates at ~10 --, round 5).
+// One key tile and one query tile per (sequence, head) item: the persistent kernel above gives such an item a whole workgroup (four waves, one of them
+// working), two workgroup barriers and a 96-row staging loop.  Here an item belongs to ONE WAVE: the wave brings its K | V tile (32 rows x 128 B each,
+// rows >= L outside the buffer descriptor: zero) into its own 8 KiB of LDS by LDS-DMA, takes its Q fragments from global memory, waits for its own
+// vmcnt and computes -- no workgroup barrier anywhere; twelve to sixteen such waves per CU hide each other's load latency.  Same arithmetic as the
+// other kernels (attend_block: S^T = K Q^T, masks, in-register softmax, P as the B operand of O^T += V^T P^T, row sums on a ones-tile).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void attention_small_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int causal,
+                                                                 int n_items) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int D = H * 64;
+  const int64_t ld = 3 * (int64_t)D;
+  char* const mine = smem + wave * 8192;                 // K tile | V tile of this wave's current item
+  const int kswz = (r32 >> 1) & 7;
+  const char* kread[4];
+  const char* vread[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kread[ks] = mine + r32 * 128 + (((2 * ks + hh) ^ kswz) << 4);
+  {
+    const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3;
+    const int fq = (qq >> 1) & 1;
+    const int lane_base = 4096 + hh * 512 + qq * 128 + ((((lane >> 4) & 1) * 2 + (pp >> 1)) << 4) + (pp & 1) * 8;
+    vread[0] = mine + lane_base + fq * 64;
+    vread[1] = mine + lane_base + (1 - fq) * 64;
+  }
+  const int lr = lane >> 3, cs = lane & 7;
+  const int q = r32, qc = q < L ? q : L - 1;
+  const int stride = gridDim.x * 4;
+  for (int item = blockIdx.x * 4 + wave; item < n_items; item += stride) {
+    const int n = item / H, h = item - n * H;
+    const half_t* base = qkv + (int64_t)n * L * ld + h * 64;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, ((int64_t)L * ld - h * 64) * 2);   // rows >= L: outside, read as zero
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+      const int row = pc * 8 + lr;
+      const int koff = (row * (int)ld + D) * 2;
+      CLIPMI_BUFFER_LOAD_LDS16(rs, mine + pc * 1024, koff + ((cs ^ ((row >> 1) & 7)) << 4), 0);
+      CLIPMI_BUFFER_LOAD_LDS16(rs, mine + 4096 + pc * 1024, koff + D * 2 + ((cs ^ (((row >> 1) & 1) << 2)) << 4), 0);
+    }
+    f16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const f16x8*>(base + (int64_t)qc * ld + ks * 16 + hh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) :: "memory");   // this wave's tiles and fragments are in
+    f32x16 oacc[2], lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; lacc[e] = 0.f; }
+    float m_run = NEG_BIG;
+    attend_block<1, 1, 0>(kread, vread, qf, 0, L, causal, 0, q, hh, m_run, oacc, lacc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment read of this item is back before the next item's DMA may land on the tiles
+    store_out(out + ((int64_t)n * L + qc) * D + h * 64, oacc, lacc[0], hh, q < L);
+  }
+}
+
+int launch_small(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
+  const int n_items = N * H;
+  const int slots = device_cus() * 4;                     // four workgroups of four waves per CU
+  const int need = (n_items + 3) / 4;
+  hipLaunchKernelGGL(attention_small_kernel, dim3(need < slots ? need : slots), dim3(256), 0, s, qkv, out, L, H, causal, n_items);
+  return check_launch("attention_small_kernel");
+}
+
 template <int NKT, int GROUP, int DENSE>
 int launch_persist(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s) {
   constexpr int SMEM = 2 * 2 * NKT * 32 * 128;
@@ -1316,6 +1382,7 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   CLIPMI_REQUIRE(N > 0 && L > 0 && H > 0, CLIPMI_ERR_SHAPE, "attention: bad shape N=%d L=%d H=%d", N, L, H);
   CLIPMI_REQUIRE((int64_t)N * H < (1ll << 31), CLIPMI_ERR_SHAPE, "attention: grid too large");
   CLIPMI_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)out % 8 == 0, CLIPMI_ERR_ARG, "attention: unaligned pointer");
+  if (L <= 32 && options().attn_small.load(std::memory_order_relaxed) != 0) return launch_small(qkv, out, N, L, H, causal, s);
   if (L <= 96) {
     if (causal && L > 64) return launch_persist<3, 3, 2>(qkv, out, N, L, H, causal, s);
     return launch_persist<3, 3, 0>(qkv, out, N, L, H, causal, s);

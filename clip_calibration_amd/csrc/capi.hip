@@ -44,6 +44,7 @@ const OptionDesc kOptions[] = {
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},
     {"attn_loader", "CLIPMI_ATTN_LOADER", &Options::attn_loader},
     {"attn_ring", "CLIPMI_ATTN_RING", &Options::attn_ring},
+    {"attn_small", "CLIPMI_ATTN_SMALL", &Options::attn_small},
     {"tail_unfused", "CLIPMI_TAIL_UNFUSED", &Options::tail_unfused},
     {"vision_pass", "CLIPMI_VISION_PASS", &Options::vision_pass},
 };

@@ -136,6 +136,8 @@ struct Options {
   std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
                                        // from a loader wave, fragment reads pinned by inline asm, output rows stored non-temporal); 1 = the same with plain
                                        // stores; 0 = persistent kernel (all three: same bits)
+  std::atomic<int> attn_small{1};      // CLIPMI_ATTN_SMALL, attention over at most 32 tokens (the text tower after dead-row elimination): 1 (default) = one item per
+                                       // wave, no workgroup barrier (attention_small_kernel); 0 = the persistent kernel
   std::atomic<int> attn_ring{1};       // CLIPMI_ATTN_RING, non-causal attention over more than 224 tokens (ViT-L/14): 1 (default) = attention_ring_kernel;
                                        // 0 = the round-1 streaming kernel
   std::atomic<int> tail_unfused{0};    // CLIPMI_TAIL_UNFUSED: 1 = the three-kernel logits tail (A/B aid)

@@ -329,6 +329,29 @@ def test_attention_ring_kernel(ops, clipmi_option, n, l, h):
         assert err < 4e-3, f"last sequence: max err {err}"
 
 
+@pytest.mark.parametrize("n,l,h,causal", [(500, 24, 8, True), (1000, 16, 8, True), (3, 32, 2, False), (7, 31, 3, True), (5, 1, 2, False), (2, 9, 1, True),
+                                          (260, 8, 12, False), (4100, 24, 1, True)])
+def test_attention_small_kernel(ops, clipmi_option, n, l, h, causal):
+    """Attention over at most 32 tokens -- the text tower after dead-row elimination (CoOp prompts: 24 rows, zero-shot templates: 16; causal mask,
+    clip/model.py:585-591) --: one (sequence, head) item per WAVE, no workgroup barrier (attn_small 1, the default), against the persistent kernel
+    (attn_small 0: the same arithmetic in the same order -> the same bits) and the fp32 reference.  Item counts from a fraction of one workgroup to
+    several items per wave (the wave's LDS tiles are re-used: the reads of one item must be back before the next item's DMA)."""
+    g = torch.Generator().manual_seed(n * 1000 + l + h)
+    qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
+    dq = _cuda(qkv)
+    got = ops.attention(dq, n, l, h, causal)
+    again = ops.attention(dq, n, l, h, causal)
+    clipmi_option("attn_small", 0)
+    base = ops.attention(dq, n, l, h, causal)
+    assert torch.equal(got, again)
+    assert torch.equal(got, base)
+    ns = min(n, 3)
+    ref = _attn_ref(qkv[: ns * l], ns, l, h, causal)
+    assert (got[: ns * l].float().cpu() - ref).abs().max().item() < 4e-3
+    ref = _attn_ref(qkv[(n - 1) * l:], 1, l, h, causal)
+    assert (got[(n - 1) * l:].float().cpu() - ref).abs().max().item() < 4e-3
+
+
 def test_attention_ring_peaked_rows(ops):
     """A dominant key in the LAST block and large queries: the running maximum moves late (rescale across blocks, and across the merged partials)."""
     n, l, h = 1, 577, 2
