@@ -58,6 +58,17 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
 #define CLIPMI_VALU_TO_MFMA_FENCE3(x, y, z) asm volatile("s_nop %3" : "+v"(x), "+v"(y), "+v"(z) : "n"(CLIPMI_FENCE_SNOP))
 #endif
 
+// The other direction (round 5, profiles/r05_vitl_attention.txt "second hazard"): a VGPR an MFMA has just written, read by a VECTOR instruction.  hipcc
+// inserts wait states for this from its own table (`s_nop 10` behind a v_mfma_f32_32x32x16_f16 in the case that showed it) and the wave's own value is
+// right -- every parity test passed --, but beside a kernel that did this ten times per block (a per-group `sum += acc[0]` right behind the group's
+// last MFMAs) a co-resident wave of ANOTHER kernel lost registers: 52-57 of 200 LayerNorm launches wrong beside the 257-token ring attention, 127-160 of
+// 200 beside the 577-token one; 0 of 200 with 32 more wait states in front of the read, and 0 with the read moved out of the loop
+// (tools/probes/ring_hazard_probe.py).  Kernels here keep MFMA results in the matrix pipe's hands inside their loops and put this fence in front of
+// the one place per pass where the vector pipe takes the accumulators over.
+#ifndef CLIPMI_MFMA_TO_VALU_FENCE3   // (a diagnostic build may define it away on the command line: tools/lib_ab.py timing of the fence itself)
+#define CLIPMI_MFMA_TO_VALU_FENCE3(x, y, z) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(x), "+v"(y), "+v"(z))
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-wide reductions without LDS (DPP inside a 16-lane row, v_permlane16/32_swap across rows): every lane ends up with the
 // result, by the same tree in every lane -- deterministic, and ~10x shorter than six dependent ds_bpermute round trips.  A LATENCY

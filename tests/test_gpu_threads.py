@@ -77,21 +77,29 @@ def test_call_flag_f16_needs_the_fold():
         assert torch.isfinite(m.text_features_f32(ids, flags=_lib.CALL_STREAM_F16)).all()
 
 
-@pytest.mark.parametrize("hammer_kernel", ["vision attention (197 tokens) + tail", "text attention (77 tokens, causal)", "ViT-L/14 attention (257 tokens)"])
+HAMMERS = {"vision attention (197 tokens) + tail": (24, 197, 12, False), "text attention (77 tokens, causal)": (500, 77, 8, True),
+           "ViT-L/14 attention (257 tokens)": (16, 257, 16, False), "ViT-L/14@336 attention (577 tokens)": (8, 577, 16, False),
+           "truncated text attention (24 tokens, causal)": (500, 24, 8, True)}
+
+
+@pytest.mark.parametrize("hammer_kernel", list(HAMMERS))
 def test_small_kernel_beside_mfma_kernels_on_a_second_stream(hammer_kernel):
     """Regression guard for CLIPMI_VALU_TO_MFMA_FENCE (common.h; profiles/r03_gpu_sharing.txt): an MFMA that reads a source operand VALU
     instructions have just written (the softmax's P, a re-materialised constant, rescaled accumulators, the tail's hi / lo split) needs wait
     states hipcc does not insert on gfx950 -- its own result is right, but a wave of another kernel resident on the same SIMD loses a
     register quarter.  While an attention kernel (and the fused tail) loops on a second stream, the LayerNorm kernel (one wave per row, 56
     registers: it fits beside them) must keep returning the right rows.  Without the fences: 28-32 of 300 launches wrong beside the vision
-    kernel, 276 of 300 beside the text tower's, 24-26 of 300 beside the 257-token kernel."""
+    kernel, 276 of 300 beside the text tower's, 24-26 of 300 beside the 257-token kernel.  Round 5 found the same damage from the other direction --
+    a register an MFMA has just written, read by the vector pipe behind hipcc's own `s_nop 10` (CLIPMI_MFMA_TO_VALU_FENCE3): 52-160 of 200 launches
+    wrong beside the first form of the ring attention kernel (257 / 577 tokens), hence its two hammers here; the one-item-per-wave kernel of the
+    truncated text tower (four waves of 97 registers per workgroup: a victim fits on every SIMD) is the fifth."""
     from clip_calibration_amd import ops
     g = torch.Generator().manual_seed(0)
     M, K = 197 * 256, 768
     x = torch.randn(M, K, generator=g).cuda()
     gam, bet = torch.ones(K).cuda(), torch.zeros(K).cuda()
     truth = torch.nn.functional.layer_norm(x.double(), (K,)).float()
-    n, l, h, causal = {"vision": (24, 197, 12, False), "text a": (500, 77, 8, True), "ViT-L/": (16, 257, 16, False)}[hammer_kernel[:6]]
+    n, l, h, causal = HAMMERS[hammer_kernel]
     qkv = torch.randn(n * l, 3 * 64 * h, generator=g).half().cuda()
     feat = torch.randn(256, 512, generator=g).cuda()
     txt = ops.l2_normalize(torch.randn(1000, 512, generator=g).cuda())

@@ -19,6 +19,8 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "clip_calibration_amd", "csrc")
 WAIT = int(os.environ.get("WAIT", "4"))
+WAIT2 = int(os.environ.get("WAIT2", "32"))   # second check (round 5): MFMA-written register read by a vector / store instruction with another MFMA issued in between
+MFMA_WAIT = 8                                # ... an MFMA in between counts as the 8 cycles it holds the vector issue port (MI355X_MICROARCH.md), anything else as 1
 REG = re.compile(r"\b([va])(?:\[(\d+):(\d+)\]|(\d+)\b)")
 LOADS = ("global_load", "buffer_load", "flat_load", "scratch_load", "ds_read", "ds_bpermute", "ds_swizzle", "ds_permute")
 NO_FALLTHROUGH = ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64")
@@ -145,26 +147,91 @@ def scan_kernel(name, insts, labels):
     return [(name, x, m, w) for (x, m), w in sites.items()], n_mfma
 
 
+def scan_kernel_reads(name, insts, labels):
+    """Round 5's second hazard (common.h CLIPMI_MFMA_TO_VALU_FENCE3; profiles/r05_vitl_attention.txt): a register an MFMA has written, read by a vector (or
+    LDS / global store) instruction fewer than WAIT2 wait states later WITH at least one other MFMA issued in between -- the shape of `acc2 = mfma(..);
+    acc0 = mfma(..); s_nop 10; v_add x, x, acc2[0]` that corrupted co-resident waves.  (A read of the LATEST MFMA's result behind hipcc's own s_nop --
+    scores into the softmax maximum -- is the ordinary case every kernel here has and is not reported.)  Same data flow as scan_kernel: state =
+    {register: (wait states since the MFMA, other MFMAs since, text)}, merged at labels with the smallest distance."""
+    n = len(insts)
+    state_in = [None] * (n + 1)
+    state_in[0] = {}
+    sites = {}
+    dirty, passes = True, 0
+    while dirty:
+        dirty = False
+        passes += 1
+        if passes > 64:
+            raise ScanError(f"{name}: data flow did not settle")
+        for i, (op, ops, text) in enumerate(insts):
+            st = state_in[i]
+            if st is None:
+                continue
+            is_mfma = op.startswith(("v_mfma", "v_smfmac"))
+            reader = (op.startswith("v_") and not is_mfma and not op.startswith("v_nop")) or op.startswith(("ds_write", "global_store", "buffer_store", "scratch_store"))
+            if reader and st:
+                src_ops = ops[1:] if op.startswith("v_") else ops
+                srcs = set().union(*[regs(o) for o in src_ops]) if src_ops else set()
+                if op.startswith(("v_fmac", "v_mac", "v_pk_fmac", "v_dot2c")) and ops:
+                    srcs |= regs(ops[0])
+                for r in srcs & st.keys():
+                    w, others, x = st[r]
+                    if w < WAIT2 and others >= 1:
+                        sites[(x, text)] = min(w, sites.get((x, text), w))
+            out = dict(st)
+            step = (int(ops[0] or 0) + 1) if op == "s_nop" else (MFMA_WAIT if is_mfma else 1)
+            out = {r: (w + step, o + (1 if is_mfma else 0), x) for r, (w, o, x) in out.items() if w + step < WAIT2}
+            if is_mfma and ops:
+                for r in regs(ops[0]):
+                    out[r] = (0, 0, text)
+            elif ops and ops[0] and (op.startswith("v_") or op.startswith(LOADS)) and not op.startswith(("v_cmp", "v_cmpx")):
+                for r in regs(ops[0]):      # overwritten by something else: no longer an MFMA result
+                    out.pop(r, None)
+            targets = []
+            if not op.startswith(NO_FALLTHROUGH):
+                targets.append(i + 1)
+            if op.startswith(("s_branch", "s_cbranch")):
+                lab = ops[-1].strip()
+                if lab in labels:
+                    targets.append(labels[lab])
+            for t in targets:
+                if state_in[t] is None:
+                    state_in[t] = dict(out)
+                    if t <= i:
+                        dirty = True
+                else:
+                    changed = False
+                    for r, v in out.items():
+                        if r not in state_in[t] or v[0] < state_in[t][r][0] or (v[0] == state_in[t][r][0] and v[1] > state_in[t][r][1]):
+                            state_in[t][r] = v
+                            changed = True
+                    if changed and t <= i:
+                        dirty = True
+    return [(name, x, m, w) for (x, m), w in sites.items()]
+
+
 def scan(src, extra=()):
     """(sites, kernels with MFMAs, MFMA instructions) of one translation unit; raises ScanError when the file does not compile or holds no MFMA
     kernel at all (a guard that scans nothing must not pass)."""
     kernels = split_kernels(compile_to_isa(src, extra))
-    sites, with_mfma, total = [], 0, 0
+    sites, reads, with_mfma, total = [], [], 0, 0
     for name, insts, labels in kernels:
         s, n = scan_kernel(name, insts, labels)
         sites += s
+        if n:
+            reads += scan_kernel_reads(name, insts, labels)
         with_mfma += 1 if n else 0
         total += n
     if not with_mfma:
         raise ScanError(f"{src}: no kernel with a v_mfma found in {len(kernels)} functions -- nothing was checked")
-    return sites, with_mfma, total
+    return sites, with_mfma, total, reads
 
 
 def main():
     bad = 0
     for src in sys.argv[1:]:
         try:
-            sites, nk, nm = scan(src, tuple(os.environ.get("EXTRA", "").split()))
+            sites, nk, nm, reads = scan(src, tuple(os.environ.get("EXTRA", "").split()))
         except ScanError as e:
             print(f"{src}: SCAN FAILED: {e}")
             sys.exit(2)
@@ -174,6 +241,16 @@ def main():
             name = subprocess.run(["c++filt", kernel or "?"], capture_output=True, text=True).stdout.strip()[:90]
             print(f"   {name}\n      {w}\n      {m}      ({waited} wait states between)")
         bad += len(sites)
+        only = os.environ.get("KERNELS")         # second check: reported for the kernels named here (comma-separated substrings), all when unset
+        if only:
+            reads = [r for r in reads if any(k in r[0] for k in only.split(","))]
+        print(f"{src}: {len(reads)} MFMA result -> vector / store read sites with another MFMA in between and fewer than {WAIT2} wait states"
+              + (f"; smallest distance {min(w for _, _, _, w in reads)}" if reads else ""))
+        for kernel, w, m, waited in reads[:int(os.environ.get("SHOW", "12"))]:
+            name = subprocess.run(["c++filt", kernel or "?"], capture_output=True, text=True).stdout.strip()[:90]
+            print(f"   {name}\n      {w}\n      {m}      ({waited} wait states between)")
+        if os.environ.get("STRICT_READS", "0") == "1":
+            bad += len(reads)
     sys.exit(1 if bad else 0)
 
 
