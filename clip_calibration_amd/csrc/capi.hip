@@ -881,6 +881,9 @@ int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* 
   const bool f16res = residual_f16_enabled(m, folded, true, 0u, &prc);
   // the row partials a residual GEMM of this shape leaves behind (what the consumers read in the tower)
   int parts = (D + 255) / 256 > LN_MAX_PARTS ? LN_MAX_PARTS : (D + 255) / 256;
+  // One event pair around `iters` launches of a step queued back to back (after one untimed launch): the GPU stays under load for the whole
+  // measurement.  (Until round 5 every launch was timed and synchronised on its own: on a box whose clock sags in the idle gap between two
+  // synchronised launches that read 6-7 % above the same kernel inside the tower and above rocprofv3's average.)
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     set_error("profile: hipEventCreate failed");
@@ -890,21 +893,18 @@ int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* 
   for (int step = 0; step < 5 && rc == CLIPMI_OK; ++step) {
     ms_out[step] = 0.f;
     if (only >= 0 && only != step) continue;
-    double total = 0.0;
-    for (int i = -1; i < iters && rc == CLIPMI_OK; ++i) {   // i = -1: untimed warm-up launch
-      (void)hipEventRecord(e0, s);
-      rc = run_block_step(step, b, w, batch, L, D, 0, folded, &parts, s, f16res);
-      (void)hipEventRecord(e1, s);
-      if (hipEventSynchronize(e1) != hipSuccess) {
-        set_error("profile: hipEventSynchronize failed");
-        rc = CLIPMI_ERR_HIP;
-        break;
-      }
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      if (i >= 0) total += ms;
+    rc = run_block_step(step, b, w, batch, L, D, 0, folded, &parts, s, f16res);   // untimed warm-up launch
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters && rc == CLIPMI_OK; ++i) rc = run_block_step(step, b, w, batch, L, D, 0, folded, &parts, s, f16res);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) {
+      set_error("profile: hipEventSynchronize failed");
+      rc = CLIPMI_ERR_HIP;
+      break;
     }
-    ms_out[step] = (float)(total / iters);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ms_out[step] = ms / (float)iters;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -75,6 +75,11 @@ const char* clipmi_last_error(void);
  *   attn_loader      (CLIPMI_ATTN_LOADER)     2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
  *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
  *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)
+ *   attn_ring        (CLIPMI_ATTN_RING)       1 (default) = non-causal attention over more than 224 tokens (ViT-L/14: 257, 577) runs the ring kernel
+ *                                             (persistent workgroups, loader wave, 128-key blocks through a three-slot LDS ring); 0 = the round-1
+ *                                             streaming kernel (also taken for a causal mask of that length)
+ *   attn_small       (CLIPMI_ATTN_SMALL)      1 (default) = attention over at most 32 tokens (the text tower after dead-row elimination) gives every
+ *                                             (sequence, head) item to ONE wave, no workgroup barrier; 0 = the persistent kernel (same bits)
  *   tail_unfused     (CLIPMI_TAIL_UNFUSED)    1 = clipmi_logits / clipmi_fused_tail as separate launches instead of the fused tail kernel
  *   vision_pass      (CLIPMI_VISION_PASS)     stream elements (token rows x width) of one pass of clipmi_encode_image, default 50432 * 768
  *                                             (256 images of ViT-B/16, 128 of ViT-L/14, 64 of ViT-L/14@336): a batch of one and a half
@@ -418,9 +423,10 @@ int clipmi_encode_text(clipmi_model* m, const int64_t* ids, int n_prompts, int s
 /* Timing aid for bench.py (the per-kernel roofline of its JSON line): the five launches of the vision tower's residual
  * block 0 -- 0 in-proj, 1 attention, 2 out-proj + residual, 3 c_fc + QuickGELU, 4 c_proj + residual (clip/model.py:181-188)
  * -- issued exactly as clipmi_encode_image issues them (LayerNorm fold, fp16 stream, tile selection) on the operands the
- * workspace holds (call clipmi_encode_image on `batch` images first), each `iters` times after one untimed launch,
- * every launch bracketed by hipEvents on `stream`.  ms_out: host float[5], mean milliseconds per launch.  only = -1 times
- * all five, 0..4 just that one (the others report 0).  Synchronises the stream; overwrites the activations in the workspace. */
+ * workspace holds (call clipmi_encode_image on `batch` images first), each `iters` times back to back after one untimed launch,
+ * the `iters` launches bracketed by ONE pair of hipEvents on `stream` (the GPU stays under load for the whole measurement).
+ * ms_out: host float[5], mean milliseconds per launch.  only = -1 times all five, 0..4 just that one (the others report 0).
+ * Synchronises the stream; overwrites the activations in the workspace (the residual steps accumulate `iters` + 1 times). */
 int clipmi_profile_block(clipmi_model* m, int batch, int iters, int only, void* workspace, size_t workspace_bytes,
                          float* ms_out, clipmi_stream_t stream);
 
