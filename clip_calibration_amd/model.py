@@ -514,7 +514,10 @@ class CLIP(nn.Module):
         (clip/model.py:585-591) and only the EOT row = ``argmax(ids)`` leaves the tower (clip/model.py:611, coop.py:65), so nothing behind the
         last prompt's EOT can reach an output.  ``max(EOT) + 1`` rounded up to a multiple of 8 (few distinct shapes), at least the prompt
         tokens 1..n_ctx a hook overwrites, at most the context.  Costs one read-back of a scalar per NEW prompt set: the answer is kept with
-        the tensor it was computed for (which keeps that storage -- and so the key -- alive) and re-used while its version counter stands."""
+        the tensor it was computed for (which keeps that storage -- and so the key -- alive) and re-used while its version counter stands.
+        (Contract: token ids edited IN PLACE through ``tensor.data`` or another route that bypasses autograd's version counter are not seen;
+        pass a new tensor, or set ``text_dead_row_elimination = False``.  An EOT index at or beyond the bound is clamped by the library, as an
+        index at or beyond the context always was.)"""
         L = self.context_length
         if not self.text_dead_row_elimination:
             return L
