@@ -115,7 +115,7 @@ _SIGNATURES = {
     "clipmi_model_set_option": (_i, [_vp, C.c_char_p, _i]),
     "clipmi_model_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "clipmi_encode_image": (_i, [_vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
-    "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PromptHook), _vp, _sz, _u, _vp]),
+    "clipmi_text_blocks": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(PromptHook), _vp, _sz, _u, _vp]),
     "clipmi_text_encoder": (_i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(PromptHook), _vp, _vp, _sz, _u, _vp]),
     "clipmi_encode_text": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _u, _vp]),
     "clipmi_profile_block": (_i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_f), _vp]),

@@ -815,18 +815,21 @@ int clipmi_encode_image_timed(clipmi_model* m, const void* image, int image_dtyp
   return n;
 }
 
-int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, const clipmi_prompt_hook* hook,
+int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, int seq_rows, const clipmi_prompt_hook* hook,
                        void* workspace, size_t workspace_bytes, unsigned flags, clipmi_stream_t stream) {
   TowerWs w;
   bool folded, f16res;
-  int rc = text_prologue(m, n_prompts, 0, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
+  int rc = text_prologue(m, n_prompts, seq_rows, hook, workspace, workspace_bytes, flags, &w, &folded, &f16res);
   if (rc) return rc;
   if (n_prompts == 0) return CLIPMI_OK;
   CLIPMI_REQUIRE(x && y, CLIPMI_ERR_ARG, "text_blocks: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int L = m->g.context_length, D = m->g.text_width;
-  if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, L, D, s))) return rc;
+  const int Lc = m->g.context_length, L = live_rows(m, seq_rows), D = m->g.text_width;
+  CLIPMI_REQUIRE(L == Lc || x != y, CLIPMI_ERR_ARG, "text_blocks: in place (x == y) only without seq_rows");
+  if ((rc = launch_add_pos(x, dtype, nullptr, w.xres, n_prompts, L, Lc, D, s))) return rc;
   if ((rc = run_text_blocks(m, w, n_prompts, L, hook, folded, f16res, s))) return rc;
+  if (L < Lc)   // the caller said that only the first `seq_rows` token rows matter: they go back to their places, the rows behind them are zero
+    return f16res ? launch_rows_out(w.xn, CLIPMI_F16, y, dtype, n_prompts, L, Lc, D, s) : launch_rows_out(w.xres, CLIPMI_F32, y, dtype, n_prompts, L, Lc, D, s);
   if (f16res) return launch_cast_f16(w.xn, y, dtype, (int64_t)n_prompts * L * D, s);
   return launch_cast_f32(w.xres, y, dtype, (int64_t)n_prompts * L * D, s);
 }

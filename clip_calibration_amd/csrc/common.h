@@ -252,6 +252,7 @@ int launch_embed_tokens(const int64_t* ids, const float* table, const float* pos
 int launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);  // rows[c] = c*L + eot[c]
 int launch_cast_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStream_t s);
+int launch_rows_out(const void* src, int src_dtype, void* dst, int dst_dtype, int C, int rows, int L, int D, hipStream_t s);   // [C*rows, D] -> [C, L, D], zeros behind `rows`
 int launch_group_mean(const float* in, float* out, int G, int P, int E, hipStream_t s);
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s);
 int launch_l2_normalize_to(const void* in, int in_dtype, void* out, int out_dtype, int rows, int E, hipStream_t s);

@@ -184,6 +184,27 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   }
 }
 
+// y[c, l, :] = (TO)src[c * rows + l, :] for l < rows, 0 for rows <= l < L: the blocks' output back in the caller's [C, L, D] layout when only the first
+// `rows` token rows of every sequence were computed (clipmi_text_blocks with seq_rows).  One thread per 4 elements.
+template <typename TS, typename TO>
+__global__ __launch_bounds__(256) void rows_out_kernel(const TS* __restrict__ src, TO* __restrict__ dst, int rows, int L, int D4, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int d4 = (int)(i % D4);
+  const int64_t tok = i / D4;
+  const int l = (int)(tok % L);
+  const int64_t c = tok / L;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (l < rows) {
+    const TS* p = src + ((c * rows + l) * D4 + d4) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)p[e];
+  }
+  TO* q = dst + i * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q[e] = (TO)v[e];
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void cast16_kernel(const half_t* __restrict__ src, TO* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -377,6 +398,21 @@ int launch_cast_f16(const half_t* src, void* dst, int dtype, int64_t n, hipStrea
     return CLIPMI_ERR_ARG;
   }
   return check_launch("cast16_kernel");
+}
+
+int launch_rows_out(const void* src, int src_dtype, void* dst, int dst_dtype, int C, int rows, int L, int D, hipStream_t s) {
+  if (C == 0) return CLIPMI_OK;
+  CLIPMI_REQUIRE(src && dst, CLIPMI_ERR_ARG, "rows_out: null pointer");
+  CLIPMI_REQUIRE(D % 4 == 0 && rows > 0 && rows <= L, CLIPMI_ERR_SHAPE, "rows_out: bad shape");
+  const int64_t total4 = (int64_t)C * L * (D / 4);
+  const unsigned grid = (unsigned)((total4 + 255) / 256);
+  const bool s32 = src_dtype == CLIPMI_F32, d32 = dst_dtype == CLIPMI_F32;
+  CLIPMI_REQUIRE((s32 || src_dtype == CLIPMI_F16) && (d32 || dst_dtype == CLIPMI_F16), CLIPMI_ERR_ARG, "rows_out: bad dtype");
+  if (s32 && d32) hipLaunchKernelGGL((rows_out_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, rows, L, D / 4, total4);
+  else if (s32) hipLaunchKernelGGL((rows_out_kernel<float, half_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (half_t*)dst, rows, L, D / 4, total4);
+  else if (d32) hipLaunchKernelGGL((rows_out_kernel<half_t, float>), dim3(grid), dim3(256), 0, s, (const half_t*)src, (float*)dst, rows, L, D / 4, total4);
+  else hipLaunchKernelGGL((rows_out_kernel<half_t, half_t>), dim3(grid), dim3(256), 0, s, (const half_t*)src, (half_t*)dst, rows, L, D / 4, total4);
+  return check_launch("rows_out_kernel");
 }
 
 int launch_l2_normalize(const void* in, int in_dtype, float* out, int rows, int E, hipStream_t s) {

@@ -98,7 +98,18 @@ def _policy_dtype(name: str) -> torch.dtype:
 
 class TextTransformer(nn.Module):
     """``clip_model.transformer``: callable on LND activations (coop.py:58-60) or on MaPLe's ``[x, deep_prompts, counter]``
-    list (maple.py:64-66); causal mask inside (clip/model.py:585-591)."""
+    list (maple.py:64-66); causal mask inside (clip/model.py:585-591).
+
+    ``live_rows`` (opt-in, Level 1): the blocks return every token row, so they run every row -- they cannot know where the caller's
+    prompts end.  A caller that reads only the EOT rows afterwards (every ``TextEncoder`` of the reference does: coop.py:65, maple.py:72) may
+    say so with ONE line where it holds the tokenised prompts, e.g. in ``CustomCLIP.__init__``::
+
+        clip_model.transformer.live_rows = tokenized_prompts          # or an int; None (default) = every row
+
+    Then only the rows up to the last prompt's EOT are computed (include/clipmi.h ``seq_rows``; the causal mask makes the rows behind them
+    irrelevant to any row in front), those rows come back bit for bit as before, and the rows behind come back as ZEROS."""
+
+    live_rows = None
 
     def __init__(self, owner: "CLIP", width: int, layers: int):
         super().__init__()
@@ -106,16 +117,24 @@ class TextTransformer(nn.Module):
         self.resblocks = nn.ModuleList([_Block(width) for _ in range(layers)])
         object.__setattr__(self, "_owner", owner)  # not a sub-module (avoids a reference cycle in module traversal)
 
+    def _rows(self, n_ctx: int) -> int:
+        hint, owner = self.live_rows, self._owner
+        if hint is None:
+            return 0
+        if isinstance(hint, torch.Tensor):
+            return owner.live_rows(hint, n_ctx)
+        return max(int(hint), 1 + int(n_ctx))
+
     def forward(self, x):
         owner: CLIP = self._owner
         if isinstance(x, (list, tuple)):
             xt, deep, counter = x
             n_ctx = owner.design_details.get("maple_length", deep[0].shape[0] if len(deep) else 0)
-            y = owner._text_blocks(xt, list(deep), n_ctx)
+            y = owner._text_blocks(xt, list(deep), n_ctx, rows=self._rows(n_ctx if len(deep) else 0))
             used = min(len(deep), self.layers - 1)
             return [y, deep, counter + used]
         deep, n_ctx = owner.ivlp_text_prompts()
-        return owner._text_blocks(x, deep, n_ctx)
+        return owner._text_blocks(x, deep, n_ctx, rows=self._rows(n_ctx if deep else 0))
 
 
 class VisionTransformer(nn.Module):
@@ -483,11 +502,11 @@ class CLIP(nn.Module):
         """clip/model.py:597-598."""
         return self.visual(image.type(self.dtype))
 
-    def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int, flags: int = _lib.CALL_DEFAULT) -> torch.Tensor:
+    def _text_blocks(self, x_lnd: torch.Tensor, deep: Optional[List[torch.Tensor]], n_ctx: int, flags: int = _lib.CALL_DEFAULT, rows: int = 0) -> torch.Tensor:
         twin = self._elsewhere(x_lnd)
         if twin is not None:
             with torch.cuda.device(x_lnd.device):
-                return twin._text_blocks(x_lnd, deep, n_ctx, flags)
+                return twin._text_blocks(x_lnd, deep, n_ctx, flags, rows)
         self._ensure_bound()
         g = self.geometry
         x_lnd = ops._dev(x_lnd, "x", (torch.float16, torch.float32))
@@ -500,9 +519,10 @@ class CLIP(nn.Module):
         if deep:
             hook, keep = self._hook(n_ctx, None, deep, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
+        rows = int(rows) if 0 < int(rows) < g.context_length else 0
         with self._launch_lock:
-            ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, 0))
-            check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, hook_ref, ws.data_ptr(),
+            ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
+            check(lib.clipmi_text_blocks(self._handle, x.data_ptr(), y.data_ptr(), _DT[x.dtype], Cn, rows, hook_ref, ws.data_ptr(),
                                          ws.numel(), int(flags), ops._stream()), "clipmi_text_blocks")
         return y.permute(1, 0, 2)
 

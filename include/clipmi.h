@@ -395,8 +395,11 @@ int clipmi_encode_image(clipmi_model* m, const void* image, int image_dtype, int
                         unsigned flags, clipmi_stream_t stream);
 
 /* `clip_model.transformer(x)` as the trainers' TextEncoder uses it (coop.py:58-60, maple.py:64-66): the causal
- * blocks only.  x fp16|fp32 [C, L, Dt] token-major in, y same dtype/shape out (x == y allowed). */
-int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts,
+ * blocks only.  x fp16|fp32 [C, L, Dt] token-major in, y same dtype/shape out (x == y allowed when seq_rows covers the context).
+ * seq_rows (see clipmi_text_encoder below; 0 = every row): an OPT-IN of the caller, who alone knows where its prompts end -- the blocks return
+ * every row, so by default they run every row.  With 0 < seq_rows < L only the first seq_rows token rows of every sequence are read and
+ * computed; y receives them in place and ZEROS in the rows behind (Python: `clip_model.transformer.live_rows = ...`, INTEGRATION.md Level 1). */
+int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n_prompts, int seq_rows,
                        const clipmi_prompt_hook* hook, void* workspace, size_t workspace_bytes,
                        unsigned flags, clipmi_stream_t stream);
 
@@ -409,8 +412,7 @@ int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n
  * their [C,L,..] layout; rows >= seq_rows are never read): identical features, L / seq_rows times fewer rows through every GEMM
  * ("X X X X a photo of a <name>." ends at token ~22 of 77).  The CALLER guarantees max(eot) < seq_rows -- it holds the tokenised prompts on the
  * host side and computes the bound once, without a per-call device sync -- and 1 + hook->n_ctx <= seq_rows; an EOT index outside is clamped
- * to seq_rows - 1 as it is to L - 1 today.  seq_rows <= 0 or >= L: the whole context.  `clip_model.transformer(x)` (clipmi_text_blocks)
- * returns every row and therefore always runs every row. */
+ * to seq_rows - 1 as it is to L - 1 today.  seq_rows <= 0 or >= L: the whole context. */
 int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts, int seq_rows,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
                         unsigned flags, clipmi_stream_t stream);

@@ -209,3 +209,68 @@ def test_workspace_follows_the_row_count():
     rc = lib.clipmi_text_encoder(model._handle, prompts.data_ptr(), _lib.F16, eot.data_ptr(), 100, 32, None, out.data_ptr(), ws.data_ptr(), ws.numel(), 0,
                                  ops._stream())
     assert rc == _lib.ERR_WORKSPACE
+
+
+# ---- Level 1: clip_model.transformer(x) with the opt-in row hint (clipmi_text_blocks `seq_rows`) -----------------------------------
+def test_transformer_row_hint_returns_the_live_rows_and_zeros_behind(clipmi_option):
+    """``clip_model.transformer.live_rows = tokenized_prompts``: rows up to the bound are the rows of the full-length call, the rows behind
+    are zero, and the reference's TextEncoder arithmetic on top (coop.py:56-67) gives the same features; without the hint nothing changes."""
+    clipmi_option("gemm_variant", 0)
+    clipmi_option("gemm_stream", 0)
+    clipmi_option("gemm_rstream", 0)
+    sd, model = _build("tiny")
+    ids = _ragged_ids(21, "tiny", seed=17, longest=37).cuda()
+    x = (model.token_embedding(ids) + model.positional_embedding).permute(1, 0, 2)       # LND, as coop.py:57-58 hands it over
+    with torch.no_grad():
+        full = model.transformer(x)
+        model.transformer.live_rows = ids
+        short = model.transformer(x)
+        model.transformer.live_rows = 38                                                   # an int: taken as is
+        tight = model.transformer(x)
+        model.transformer.live_rows = None
+        again = model.transformer(x)
+    torch.cuda.synchronize()
+    rows = model.live_rows(ids)
+    assert rows == 40 and full.shape == short.shape == x.shape
+    assert torch.equal(again, full)
+    assert torch.equal(short[:rows], full[:rows]) and not short[rows:].any()
+    assert torch.equal(tight[:38], full[:38]) and not tight[38:].any()
+    eot = ids.argmax(-1)
+    pick = lambda y: model.ln_final(y.permute(1, 0, 2)).float()[torch.arange(21), eot] @ model.text_projection.float()
+    assert torch.equal(pick(short), pick(full))
+
+
+def test_transformer_row_hint_with_the_maple_list_form():
+    dd = {"trainer": "MaPLe", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0, "maple_length": 2}
+    sd, model = _build("tiny", dd)
+    g = model.geometry
+    ids = _ragged_ids(10, "tiny", seed=19).cuda()
+    gen = torch.Generator().manual_seed(5)
+    deep = [(0.02 * torch.randn(2, g.transformer_width, generator=gen)).cuda() for _ in range(g.transformer_layers - 1)]
+    x = (model.token_embedding(ids) + model.positional_embedding).permute(1, 0, 2).half()
+    with torch.no_grad():
+        full, _, n_full = model.transformer([x, deep, 0])
+        model.transformer.live_rows = ids
+        short, _, n_short = model.transformer([x, deep, 0])
+        model.transformer.live_rows = 1                     # below the hook's tokens: raised to 1 + n_ctx, never cut into them
+        tiny, _, _ = model.transformer([x, deep, 0])
+    torch.cuda.synchronize()
+    rows = model.live_rows(ids, 2)
+    assert n_full == n_short and short.dtype == x.dtype
+    assert float((short[:rows].float() - full[:rows].float()).abs().max()) <= 2e-3 * float(full.float().abs().max()) and not short[rows:].any()
+    assert float((tiny[:3].float() - full[:3].float()).abs().max()) <= 2e-3 * float(full.float().abs().max()) and not tiny[3:].any()
+
+
+def test_text_blocks_in_place_only_without_a_row_bound():
+    sd, model = _build("tiny")
+    model._ensure_bound()
+    g = model.geometry
+    x = torch.randn(6, g.context_length, g.transformer_width, device="cuda")
+    ws = torch.empty(lib.clipmi_text_workspace_bytes(model._handle, 6, 0), dtype=torch.uint8, device="cuda")
+    args = (_lib.F32, 6)
+    rc = lib.clipmi_text_blocks(model._handle, x.data_ptr(), x.data_ptr(), *args, 24, None, ws.data_ptr(), ws.numel(), 0, ops._stream())
+    assert rc == _lib.ERR_ARG and "in place" in _lib.last_error()
+    for r in (0, 77, 500):                                  # every row: in place is fine, as before
+        check(lib.clipmi_text_blocks(model._handle, x.data_ptr(), x.data_ptr(), *args, r, None, ws.data_ptr(), ws.numel(), 0, ops._stream()), "text_blocks")
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
