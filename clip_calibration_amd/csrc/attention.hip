@@ -883,6 +883,11 @@ __host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 18) & 
 // The row sums stay in `lacc` (ones-tile MFMA accumulator) for the WHOLE pass and are read by the vector pipe once, at the pass end, behind
 // CLIPMI_MFMA_TO_VALU_FENCE3 (common.h): a per-group `l += lacc[0]` right behind the group's last MFMAs -- hipcc put `s_nop 10` between them -- is
 // the second co-residency hazard of this code base (52-160 of 200 LayerNorm launches wrong beside the kernel, 0 with more wait states).
+// CLIPMI_RING_ABLATE (build-time, diagnostic builds only: results are wrong with any bit set; make ring_ablate, tools/lib_ab.py):
+// 1 no exponent work (P = the raw score bits) | 2 no MFMAs (S and P.V) | 4 no LDS fragment reads | 8 no maximum | 16 no fma in front of v_exp
+#ifndef CLIPMI_RING_ABLATE
+#define CLIPMI_RING_ABLATE 0
+#endif
 template <int CNT>
 __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint32_t (&va)[2], const f16x8 (&qf)[4], const f16x8& ones, int k_lo, int L,
                                             int hh, float& m_run, f32x16 (&oacc)[2], f32x16& lacc, long long* sp = nullptr) {
@@ -892,19 +897,37 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
   f16x4 vf[2][4];
   f32x16 s[CNT];
   static_assert(CNT == 1 || CNT == 2, "one or two key tiles per softmax group");
-  read_k<0>(kf[0], ka);
+  constexpr bool NO_LDS = (CLIPMI_RING_ABLATE & 4) != 0, NO_MFMA = (CLIPMI_RING_ABLATE & 2) != 0;
+  if constexpr (NO_LDS) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kf[i][j] = qf[j];
+        vf[i][j] = f16x4{qf[j][0], qf[j][1], qf[j][2], qf[j][3]};
+        asm volatile("" : "+v"(kf[i][j]), "+v"(vf[i][j]));
+      }
+  } else {
+    read_k<0>(kf[0], ka);
+  }
   auto s_tile = [&](auto t_tag) {
     constexpr int T = decltype(t_tag)::value;
     constexpr int CUR = T & 1;
-    if constexpr (T + 1 < CNT) {
+    if constexpr (NO_LDS) {
+    } else if constexpr (T + 1 < CNT) {
       read_k<T + 1>(kf[CUR ^ 1], ka);
       lds_wait4<4>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
     } else {
       lds_wait4<0>(kf[CUR][0], kf[CUR][1], kf[CUR][2], kf[CUR][3]);
     }
-    s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
+    if constexpr (NO_MFMA) {
 #pragma unroll
-    for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+      for (int e = 0; e < 16; ++e) s[T][e] = (float)kf[CUR][e & 3][e >> 2] + (float)qf[e & 3][e >> 2];
+    } else {
+      s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[CUR][ks], qf[ks], s[T], 0, 0, 0);
+    }
     if (k_lo + T * 32 + 32 > L) {   // wave-uniform: the item's last key tile
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -916,13 +939,17 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
   s_tile(std::integral_constant<int, 0>{});
   if constexpr (CNT > 1) s_tile(std::integral_constant<int, 1>{});
   CLIPMI_RING_STAMP(3, s[CNT - 1][0]);
-  read_v<0>(vf[0], va);   // the P.V phase opens with these: behind the maximum and the rescale by the time they are needed
+  if constexpr (!NO_LDS) read_v<0>(vf[0], va);   // the P.V phase opens with these: behind the maximum and the rescale by the time they are needed
   float mloc = NEG_BIG;
+  if constexpr (CLIPMI_RING_ABLATE & 8) {
+    mloc = s[0][0];
+  } else {
 #pragma unroll
-  for (int t = 0; t < CNT; ++t)
+    for (int t = 0; t < CNT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
-  mloc = fmaxf(mloc, swap32_f(mloc));
+      for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
+    mloc = fmaxf(mloc, swap32_f(mloc));
+  }
   const float m_new = fmaxf(m_run, mloc);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull, 0)) {   // wave-uniform; exact either way (alpha == 1 where the maximum stands)
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
@@ -941,11 +968,20 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
     constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
     constexpr int STEP = T * 2 + SS, CUR = STEP & 1;
     constexpr bool LAST = STEP == 2 * CNT - 1;
-    if constexpr (!LAST) read_v<((STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
+    if constexpr (!LAST && !NO_LDS) read_v<((STEP + 1) / 2) * 4096 + ((STEP + 1) & 1) * 2048>(vf[CUR ^ 1], va);
     f16x8 pf;
+    if constexpr (CLIPMI_RING_ABLATE & 1) {
+      const f32x4 raw = f32x4{s[T][8 * SS], s[T][8 * SS + 1] + mc, s[T][8 * SS + 2], s[T][8 * SS + 3]};
+      pf = __builtin_bit_cast(f16x8, raw);
+    } else if constexpr (CLIPMI_RING_ABLATE & 16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
-    if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
+      for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(s[T][8 * SS + j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (half_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[T][8 * SS + j], C, -mc));
+    }
+    if constexpr (NO_LDS) {
+    } else if constexpr (!LAST) lds_wait4h<4>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
     else lds_wait4h<0>(vf[CUR][0], vf[CUR][1], vf[CUR][2], vf[CUR][3]);
     f16x8 v8[2];
 #pragma unroll
@@ -954,9 +990,15 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
       v8[dt] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
     CLIPMI_VALU_TO_MFMA_FENCE3(pf, v8[0], v8[1]);   // ONE fence: P comes from conversions, the V halves may have been moved together by VALU copies
-    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[0], pf, oacc[0], 0, 0, 0);
-    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[1], pf, oacc[1], 0, 0, 0);
-    lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+    if constexpr (NO_MFMA) {
+      oacc[0][STEP] += (float)pf[0] * (float)v8[0][0] + (float)pf[2] * (float)v8[0][5];
+      oacc[1][STEP] += (float)pf[4] * (float)v8[1][0] + (float)pf[6] * (float)v8[1][5];
+      lacc[STEP] += (float)pf[1] + (float)pf[3] + (float)pf[5] + (float)pf[7];
+    } else {
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[0], pf, oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v8[1], pf, oacc[1], 0, 0, 0);
+      lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf, lacc, 0, 0, 0);
+    }
   };
   pv_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
   pv_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
