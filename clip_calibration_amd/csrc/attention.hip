@@ -848,25 +848,31 @@ constexpr int RKEYS = RTPB * 32;            // keys per block
 constexpr int RIMG = RKEYS * 128;           // one operand image of a block
 constexpr int RSLOT = 2 * RIMG;             // K | V
 constexpr int RNSLOT = 3;
-constexpr int RQ = 8 * 32 * 128;            // the eight Q tiles of a pass
-constexpr int RSMEM = RNSLOT * RSLOT + RQ;  // 131072
+#ifndef CLIPMI_RING_WAVES
+#define CLIPMI_RING_WAVES 11
+#endif
+constexpr int RNW = CLIPMI_RING_WAVES;      // compute waves = query tiles per pass; the loader is wave RNW.  11 + 1 = 12 waves: three on every SIMD, 168 VGPRs
+constexpr int RTHREADS = (RNW + 1) * 64;
+constexpr int RQ = RNW * 32 * 128;          // the Q tiles of a pass
+constexpr int RSMEM = RNSLOT * RSLOT + RQ;  // 96 KiB + 44 KiB
+static_assert(RNW >= 4 && RNW <= 12 && RSMEM <= 160 * 1024, "ring attention: 4..12 compute waves, LDS <= 160 KiB");
 constexpr int RSPOT = 8192 + 512;           // a partial: O (32 registers x 64 lanes x 4 B) + m + l per lane
-constexpr int RMAXPASS = 8;                 // 8 passes x 8 tiles x 32 rows = 2048 tokens
+constexpr int RMAXPASS = 8;                 // 8 passes x RNW tiles x 32 rows = 2560 tokens
 
 // 32-bit words only: a wave reads its entry by a wave-uniform index, which must stay a scalar load (a byte array in the kernel arguments is
 // read with global_load_sbyte + s_waitcnt vmcnt(0), and that wait would drain the DMA ring at every step).
 struct RingPlan {
   int n_pass, n_blocks, n_rounds;   // passes per item; key blocks per item; merge rounds of the split (last) pass (0: not split)
-  // LAST pass, wave w: bits 0-7 query tile + 1 (0: idle) | 8-9 first key tile of every block | 10-12 key tiles per block | 13-15 the wave that
-  // owns the tile's result (== w: this wave stores it) | 16-17 merge round (partner waves) | 18-19 scratch spot.  Earlier passes: tile 8 p + w, whole blocks.
-  unsigned info[8];
+  // LAST pass, wave w: bits 0-7 query tile + 1 (0: idle) | 8-9 first key tile of every block | 10-12 key tiles per block | 13-16 the wave that
+  // owns the tile's result (== w: this wave stores it) | 17-18 merge round (partner waves) | 19-20 scratch spot.  Earlier passes: tile RNW p + w, whole blocks.
+  unsigned info[RNW];
 };
 __host__ __device__ inline int ring_qt(unsigned i) { return (int)(i & 255u) - 1; }
 __host__ __device__ inline int ring_first(unsigned i) { return (int)((i >> 8) & 3u); }
 __host__ __device__ inline int ring_count(unsigned i) { return (int)((i >> 10) & 7u); }
-__host__ __device__ inline int ring_leader(unsigned i) { return (int)((i >> 13) & 7u); }
-__host__ __device__ inline int ring_round(unsigned i) { return (int)((i >> 16) & 3u); }
-__host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 18) & 3u); }
+__host__ __device__ inline int ring_leader(unsigned i) { return (int)((i >> 13) & 15u); }
+__host__ __device__ inline int ring_round(unsigned i) { return (int)((i >> 17) & 3u); }
+__host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 19) & 3u); }
 
 // One block's share of a wave: CNT key tiles (LDS images at ka / va, first key = k_lo) against the wave's 32 queries.  One softmax
 // group per call; fragment reads pinned as in attend_dense_pf; only the item's very last key tile can hold keys >= L (wave-uniform test).
@@ -884,7 +890,8 @@ __host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 18) & 
 // CLIPMI_MFMA_TO_VALU_FENCE3 (common.h): a per-group `l += lacc[0]` right behind the group's last MFMAs -- hipcc put `s_nop 10` between them -- is
 // the second co-residency hazard of this code base (52-160 of 200 LayerNorm launches wrong beside the kernel, 0 with more wait states).
 // CLIPMI_RING_ABLATE (build-time, diagnostic builds only: results are wrong with any bit set; make ring_ablate, tools/lib_ab.py):
-// 1 no exponent work (P = the raw score bits) | 2 no MFMAs (S and P.V) | 4 no LDS fragment reads | 8 no maximum | 16 no fma in front of v_exp
+// 1 no exponent work (P = the raw score bits) | 2 no MFMAs (S and P.V) | 4 no LDS fragment reads | 8 no maximum | 16 no fma in front of v_exp |
+// 32 no per-block barrier (loader and compute waves run free: races, timing only)
 #ifndef CLIPMI_RING_ABLATE
 #define CLIPMI_RING_ABLATE 0
 #endif
@@ -1024,12 +1031,12 @@ __device__ __forceinline__ void frag_offsets(int lane, int (&kro)[4], int (&vro)
 // diagnostic build: stamps[((workgroup * 64 + step) * 9 + wave) * 8 + k], s_memtime (shader cycles) of lane 0, workgroups 0..7, steps 0..63.
 // compute waves 0-7: 0 loop top | 2 past the block's barrier | 3 S tiles of the LAST group issued | 4 its maximum + rescale done | 5 block computed | 6 step end
 // (pass end: merged + stored);  loader (wave 8): 0 loop top | 1 block g landed | 2 past the barrier | 7 DMA of block g + 2 (and the next Q tiles) issued
-__global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items,
+__global__ __launch_bounds__(RTHREADS) void attention_ring_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items,
                                                              const RingPlan plan CLIPMI_VISION_STAMPS_PARAM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7 compute, 8 loader
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..RNW-1 compute, RNW loader
   const int r32 = lane & 31, hh = lane >> 5;
   const int D = H * 64;
   const int ld = 3 * D;                                   // halves per qkv row (< 2^31 / L: checked by the launcher)
@@ -1054,7 +1061,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
   };
   Cur c{(int)blockIdx.x, (int)blockIdx.x / H, (int)blockIdx.x % H, 0, 0};
 
-  if (wave == 8) {
+  if (wave == RNW) {
     // ================= loader wave: every LDS-DMA piece of the workgroup (a dedicated wave issues a piece in tens of cycles; a wave in the middle of
     // MFMA / exponent work was measured at ~200 per piece, a fifth of the step: profiles/r05_vitl_attention.txt) =================
     // A piece = 8 rows x 128 B; lane -> row lr of the piece, 16-byte chunk cs.  Lane-constant byte offsets by piece parity (the swizzle of a row
@@ -1085,8 +1092,8 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
     auto dma_q = [&](const Cur& u) {   // the Q tiles of pass u.p, tile of wave w into region w: 32 pieces
       const __amdgpu_buffer_rsrc_t rs = item_rsrc(u);
       char* Q = smem + RNSLOT * RSLOT;
-      for (int w = 0; w < 8; ++w) {
-        int qt = u.p == P - 1 ? ring_qt(plan.info[w]) : u.p * 8 + w;
+      for (int w = 0; w < RNW; ++w) {
+        int qt = u.p == P - 1 ? ring_qt(plan.info[w]) : u.p * RNW + w;
         qt = qt < 0 ? 0 : qt;
         const int toff = qt * 32 * ld * 2;
 #pragma unroll
@@ -1108,7 +1115,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
     }
     for (int g = 0; g < n_steps; ++g) {
 #ifdef CLIPMI_TUNING
-      long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * 9 + wave) * 8 : nullptr;
+      long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * (RNW + 1) + wave) * 8 : nullptr;
       if (sp) sp[0] = (long long)__builtin_amdgcn_s_memtime();
 #endif
       // Block g (and every Q tile a pass start needs) has landed once at most the 32 youngest pieces are in flight: those are block g + 1's, issued
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
 #ifdef CLIPMI_TUNING
       if (sp) sp[1] = (long long)__builtin_amdgcn_s_memtime();
 #endif
-      __builtin_amdgcn_s_barrier();   // block g is in LDS for every wave; every wave is done with block g - 1, whose slot block g + 2 takes
+      if constexpr (!(CLIPMI_RING_ABLATE & 32)) __builtin_amdgcn_s_barrier();   // block g is in LDS for every wave; every wave is done with block g - 1, whose slot block g + 2 takes
 #ifdef CLIPMI_TUNING
       if (sp) sp[2] = (long long)__builtin_amdgcn_s_memtime();
 #endif
@@ -1163,10 +1170,10 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
   for (int g = 0; g < n_steps; ++g) {
     const int slot = g % RNSLOT;
 #ifdef CLIPMI_TUNING
-    long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * 9 + wave) * 8 : nullptr;
+    long long* sp = (stamps != nullptr && lane == 0 && blockIdx.x < 8 && g < 64) ? stamps + (((size_t)blockIdx.x * 64 + g) * (RNW + 1) + wave) * 8 : nullptr;
     if (sp) sp[0] = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    __builtin_amdgcn_s_barrier();   // the loader's vmcnt wait came first: block g (and at a pass start this wave's Q tile) is in LDS
+    if constexpr (!(CLIPMI_RING_ABLATE & 32)) __builtin_amdgcn_s_barrier();   // the loader's vmcnt wait came first: block g (and at a pass start this wave's Q tile) is in LDS
 #ifdef CLIPMI_TUNING
     if (sp) sp[2] = (long long)__builtin_amdgcn_s_memtime();
     if (sp) sp[1] = (long long)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_ID.SIMD_ID of this wave (compute waves have no stamp 1)
@@ -1183,7 +1190,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
       CLIPMI_VALU_TO_MFMA_FENCE3(oacc[0], oacc[1], lacc);
     }
     // ---- this wave's share of block g
-    const int qt = c.p == P - 1 ? last_qt : c.p * 8 + wave;
+    const int qt = c.p == P - 1 ? last_qt : c.p * RNW + wave;
     {
       int first = split ? ring_first(my_info) : 0, count = split ? ring_count(my_info) : RTPB;
       const int live = (L - c.b * RKEYS + 31) >> 5;          // live key tiles of this block (>= 1)
@@ -1240,7 +1247,7 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
           __builtin_amdgcn_s_barrier();
           if (owner == wave && qt >= 0) {
             constexpr float C = 0.125f * LOG2E;
-            for (int w2 = 0; w2 < 8; ++w2) {
+            for (int w2 = 0; w2 < RNW; ++w2) {
               const unsigned i2 = plan.info[w2];
               if (w2 == wave || ring_leader(i2) != wave || ring_round(i2) != round || ring_qt(i2) < 0) continue;   // wave-uniform
               const uint32_t spot = scratch + (uint32_t)(ring_spot(i2) * RSPOT);
@@ -1279,43 +1286,32 @@ __global__ __launch_bounds__(576) void attention_ring_kernel(const half_t* __res
   }
 }
 
-// Host side of the plan: passes of 8 query tiles; the tiles of a short last pass are split over the waves by key tile.
+// Host side of the plan: passes of RNW query tiles.  A short last pass is split by key tile only when EVERY tile of it can be (R tiles x `ways`
+// waves <= RNW, ways = 2 or 4): a pass lasts as long as its largest share, so splitting some of the tiles buys nothing and costs merge rounds.
 static RingPlan make_ring_plan(int L) {
   RingPlan pl;
   memset(&pl, 0, sizeof(pl));
   const int nqt = (L + 31) / 32;
-  pl.n_pass = (nqt + 7) / 8;
+  pl.n_pass = (nqt + RNW - 1) / RNW;
   pl.n_blocks = (L + RKEYS - 1) / RKEYS;
   auto pack = [](int qt, int first, int count, int leader, int round, int spot) {
-    return (unsigned)(qt + 1) | (unsigned)first << 8 | (unsigned)count << 10 | (unsigned)leader << 13 | (unsigned)round << 16 | (unsigned)spot << 18;
+    return (unsigned)(qt + 1) | (unsigned)first << 8 | (unsigned)count << 10 | (unsigned)leader << 13 | (unsigned)round << 17 | (unsigned)spot << 19;
   };
-  const int base = (pl.n_pass - 1) * 8;
-  const int R = nqt - base;                                // tiles of the last pass (1..8)
-  for (int w = 0; w < 8; ++w) pl.info[w] = pack(w < R ? base + w : -1, 0, RTPB, w, 0, 0);
-  if (R < 8) {
-    // ways[i] in {1, 2, 4}: double the tile with the fewest ways while the waves last (ties: the LAST tile first -- the ragged one)
-    int ways[8];
-    for (int i = 0; i < R; ++i) ways[i] = 1;
-    for (;;) {
-      int used = 0, best = -1;
-      for (int i = 0; i < R; ++i) used += ways[i];
-      for (int i = R - 1; i >= 0; --i)
-        if (ways[i] < RTPB && used + ways[i] <= 8 && (best < 0 || ways[i] < ways[best])) best = i;
-      if (best < 0) break;
-      ways[best] *= 2;
-    }
-    // waves in order of DESCENDING share (count = RTPB / ways), so that wave w and wave w + 4 -- the two waves of a SIMD -- pair a heavy and a light share
+  const int base = (pl.n_pass - 1) * RNW;
+  const int R = nqt - base;                                // tiles of the last pass (1..RNW)
+  for (int w = 0; w < RNW; ++w) pl.info[w] = pack(w < R ? base + w : -1, 0, RTPB, w, 0, 0);
+  const int ways = 4 * R <= RNW ? 4 : 2 * R <= RNW ? 2 : 1;
+  if (ways > 1) {
+    const int cnt = RTPB / ways;
     int w = 0, partners = 0;
-    for (int w2 = 0; w2 < 8; ++w2) pl.info[w2] = pack(-1, 0, RTPB, w2, 0, 0);
-    for (int cnt = RTPB; cnt >= 1; cnt /= 2)
-      for (int i = 0; i < R; ++i) {
-        if (RTPB / ways[i] != cnt) continue;
-        const int lead = w;
-        for (int j = 0; j < ways[i]; ++j, ++w) {
-          pl.info[w] = pack(base + i, j * cnt, cnt, lead, j > 0 ? partners / 3 : 0, j > 0 ? partners % 3 : 0);
-          if (j > 0) ++partners;
-        }
+    for (int i = 0; i < R; ++i) {
+      const int lead = w;
+      for (int j = 0; j < ways; ++j, ++w) {
+        pl.info[w] = pack(base + i, j * cnt, cnt, lead, j > 0 ? partners / 3 : 0, j > 0 ? partners % 3 : 0);
+        if (j > 0) ++partners;
       }
+    }
+    for (; w < RNW; ++w) pl.info[w] = pack(-1, 0, RTPB, w, 0, 0);
     pl.n_rounds = (partners + 2) / 3;
   }
   return pl;
@@ -1329,9 +1325,9 @@ int launch_ring(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t
   const int n_items = N * H;
   const int grid = n_items < n_cu ? n_items : n_cu;
 #ifdef CLIPMI_TUNING
-  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(576), RSMEM, s, qkv, out, L, H, n_items, plan, g_tuning_stamps.load(std::memory_order_relaxed));
+  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(RTHREADS), RSMEM, s, qkv, out, L, H, n_items, plan, g_tuning_stamps.load(std::memory_order_relaxed));
 #else
-  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(576), RSMEM, s, qkv, out, L, H, n_items, plan);   // 8 compute waves + the loader
+  hipLaunchKernelGGL(attention_ring_kernel, dim3(grid), dim3(RTHREADS), RSMEM, s, qkv, out, L, H, n_items, plan);   // RNW compute waves + the loader
 #endif
   return check_launch("attention_ring_kernel");
 }
@@ -1448,7 +1444,7 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
   // persistent workgroups, 128-key blocks through a three-slot LDS ring, pinned fragment reads, query tiles in passes of eight with the last
   // pass split by key tile.  Option attn_ring = 0, a causal mask, or a shape outside its limits keep the round-1 streaming kernel
   // (two-slot ring of 128- / 224-key blocks; the reference of the ring kernel's parity test).
-  if (!causal && options().attn_ring.load(std::memory_order_relaxed) != 0 && L <= RMAXPASS * 8 * 32 && (int64_t)L * 3 * H * 64 * 2 < (1ll << 31))
+  if (!causal && options().attn_ring.load(std::memory_order_relaxed) != 0 && L <= RMAXPASS * RNW * 32 && (int64_t)L * 3 * H * 64 * 2 < (1ll << 31))
     return launch_ring(qkv, out, N, L, H, s);
   return L <= 320 ? launch_stream<4>(qkv, out, N, L, H, causal, s) : launch_stream<7>(qkv, out, N, L, H, causal, s);
 }

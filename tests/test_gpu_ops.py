@@ -299,13 +299,16 @@ def test_attention_vision_kernel_vs_persistent(ops, clipmi_option, n, l, h):
 
 
 @pytest.mark.parametrize("n,l,h", [(1, 577, 4), (2, 257, 16), (3, 225, 2), (1, 256, 1), (2, 300, 3), (1, 384, 2), (1, 512, 1), (2, 545, 2), (1, 576, 2),
-                                   (1, 640, 1), (1, 1025, 1), (70, 257, 16), (40, 577, 16)])
+                                   (1, 640, 1), (1, 1025, 1), (70, 257, 16), (40, 577, 16), (1, 352, 2), (1, 448, 1), (2, 480, 2), (1, 2560, 1), (2, 416, 2), (1, 2816, 1),
+                                   (300, 577, 1)])
 def test_attention_ring_kernel(ops, clipmi_option, n, l, h):
     """Non-causal attention over more than 224 tokens (ViT-L/14: 257, ViT-L/14@336: 577; clip/model.py:181-183): the ring kernel -- 128-key blocks
-    through a three-slot LDS ring, query tiles in passes of eight, the last pass split over the waves by key tile and merged -- against the fp32
+    through a three-slot LDS ring, query tiles in passes of eleven, a short last pass split over the waves by key tile and merged -- against the fp32
     reference and against the round-1 streaming kernel (attn_ring 0; another summation order: not the same bits).  Lengths that end a pass exactly
-    (256, 512), leave one row for the last tile (257, 577, 1025), split two / four / eight ways (300: 2 tiles, 384: 4, 545: 2 passes + 2, 640: 4);
-    the last two cases give every workgroup several items (ring and Q prefetch across item seams)."""
+    (352: 11 tiles, 1025: 33 with one live row in the last), leave one row for the last tile (257, 577), split the last pass four ways (384: 1 tile;
+    416: 2 tiles, two merge rounds) or two ways (448: 3 tiles; 480: 4 tiles and 512: 5 tiles, two rounds), leave waves idle (300, 545, 640), the
+    longest sequences the kernel takes (2560, 2816 = 8 passes); (70, 257, 16), (40, 577, 16) and (300, 577, 1) give every workgroup several items
+    (ring and Q prefetch across item seams)."""
     g = torch.Generator().manual_seed(n * 1000 + l + h)
     qkv = (torch.randn(n * l, 3 * 64 * h, generator=g) * 1.5).half()
     dq = _cuda(qkv)
