@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, int mfma_waves) {
+__global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, int mfma_waves, int indep) {
   float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   float b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
   const float c = 0.999f, d = 1e-6f;
@@ -23,9 +23,19 @@ __global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, i
   f16x8 fa = {1, 1, 1, 1, 1, 1, 1, 1}, fb = fa;
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
+  f32x16 acc2 = {0};
   if (wave < mfma_waves) {   // partner waves: back-to-back MFMAs on their SIMD (waves w and w+4 share a SIMD)
-    for (int i = 0; i < iters; ++i) {
-      REP8(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);)
+    if (indep) {
+      for (int i = 0; i < iters; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
+      }
+    } else {
+      for (int i = 0; i < iters; ++i) {
+        REP8(acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);)
+      }
     }
   } else {
     for (int i = 0; i < iters; ++i) {
@@ -78,20 +88,30 @@ __global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, i
     }
   }
   const long long t1 = __builtin_readcyclecounter();
-  float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + acc[0] + acc[5];
+  float sink = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + acc[0] + acc[5] + acc2[3];
   if (sink == 123.456f) out[4096] = 1;
-  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {
+    out[wave] = t1 - t0;
+    out[32 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11));   // HW_ID bits 0-15: wave 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13
+  }
 }
 
 template <int MODE>
-int run(const char* what, int per_iter, long long* dev, int waves, int mfma_waves) {
+int run(const char* what, int per_iter, long long* dev, int waves, int mfma_waves, int indep = 0) {
   const int iters = 4000;
-  rate_kernel<MODE><<<256, waves * 64>>>(dev, iters, mfma_waves);
+  rate_kernel<MODE><<<256, waves * 64>>>(dev, iters, mfma_waves, indep);
   CHECK(hipDeviceSynchronize());
-  rate_kernel<MODE><<<256, waves * 64>>>(dev, iters, mfma_waves);
+  rate_kernel<MODE><<<256, waves * 64>>>(dev, iters, mfma_waves, indep);
   CHECK(hipDeviceSynchronize());
-  std::vector<long long> h(16);
-  CHECK(hipMemcpy(h.data(), dev, 16 * 8, hipMemcpyDeviceToHost));
+  std::vector<long long> h(64);
+  CHECK(hipMemcpy(h.data(), dev, 64 * 8, hipMemcpyDeviceToHost));
+  static int shown = 0;
+  if (shown != waves) {
+    shown = waves;
+    printf("   SIMD of waves 0..%d of workgroup 0:", waves - 1);
+    for (int w = 0; w < waves; ++w) printf(" %lld", (h[32 + w] >> 4) & 3);
+    printf("   (CU %lld)\n", (h[32] >> 8) & 15);
+  }
   // readcyclecounter = s_memtime: 100 MHz-class constant clock on gfx9?  report raw ticks AND ticks relative to the fma case
   long long valu = 0;
   for (int w = mfma_waves; w < waves; ++w) valu = h[w] > valu ? h[w] : valu;
@@ -121,5 +141,21 @@ int main() {
   run<0>("v_exp_f32 beside MFMA partner", 8, dev, 8, 4);
   run<2>("exp + fma 1:1 beside MFMA partner", 8, dev, 8, 4);
   run<1>("MFMA alone (fma waves idle: iters same)", 8, dev, 4, 4);
+  // one MFMA wave + two / three vector waves per SIMD: what is left of the vector pipe's 4 cycles per instruction beside a busy matrix pipe?
+  for (int waves : {12, 16}) {
+    run<1>("v_fma_f32 beside MFMA partner", 8, dev, waves, 4);
+    run<0>("v_exp_f32 beside MFMA partner", 8, dev, waves, 4);
+    run<2>("exp + fma 1:1 beside MFMA partner", 8, dev, waves, 4);
+    run<5>("v_max3_f32 beside MFMA partner", 8, dev, waves, 4);
+    run<6>("v_cvt_pk_f16_f32 beside MFMA partner", 8, dev, waves, 4);
+  }
+  // two MFMA waves + two vector waves per SIMD
+  run<1>("MFMA alone, two INDEPENDENT accumulators", 8, dev, 4, 4, 1);
+  run<1>("2 MFMA waves per SIMD alone (dependent chain)", 8, dev, 8, 8);
+  run<1>("2 MFMA waves per SIMD alone (independent)", 8, dev, 8, 8, 1);
+  run<1>("v_fma_f32 beside MFMA partner (independent acc)", 8, dev, 12, 4, 1);
+  run<2>("exp + fma 1:1 beside MFMA partner (indep. acc)", 8, dev, 12, 4, 1);
+  run<1>("v_fma_f32 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
+  run<2>("exp + fma 1:1 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
   return 0;
 }
