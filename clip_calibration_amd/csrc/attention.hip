@@ -825,23 +825,23 @@ int launch_stream(const half_t* qkv, half_t* out, int N, int L, int H, int causa
 // 32 keys) tile where the matrix pipe needs 256-320: compiler-placed fragment reads (an LDS round trip in front of every MFMA), one
 // workgroup per CU, K | V re-staged per query split behind a load -> wait -> barrier -> compute chain.  Here:
 //
-//   * persistent workgroups (one per CU, 8 waves = two per SIMD, 256 registers each) walk the (sequence, head) items; all 8 waves
-//     compute, each on the 32-query tile it holds in registers (the round-3 vision form: S^T = K Q^T, a lane owns a query column,
-//     softmax in registers, P is directly the B operand of O^T += V^T P^T), with every LDS fragment read pinned ahead of its MFMA;
-//   * the keys of an item pass by in BLOCKS of 128 (K | V: 32 KiB) through a THREE-slot LDS ring filled by LDS-DMA: at step g the 8
-//     waves issue the 32 pieces of block g + 2 (4 each: no loader wave -- a ninth wave would put three on one SIMD and cap every wave
-//     at 168 registers), so a block has two whole steps to land; one workgroup barrier per block;
-//   * an item's query tiles are worked in PASSES of 8 (577 tokens: 19 tiles = 8 + 8 + 3); the 32 rows x 128 B of a wave's Q tile come by
-//     DMA into its own 4 KiB of LDS a whole pass ahead.  The last pass of an item has fewer tiles than waves: its tiles are SPLIT over
-//     the idle waves by key tile within every block (577: two tiles on two waves each, the one-row class... last tile on four), and the
-//     partial (max, sum, O) of a tile are merged through the ring slot that falls free at the pass end -- 19 tile-passes cost
-//     2 + 3/8 passes instead of 3 (the plan is built on the host: RingPlan);
-//   * output tiles leave as full 128-byte lines, non-temporal (store_out_lines), staged in the same free slot.
+//   * persistent workgroups (one per CU: RNW = 11 compute waves + a loader wave = three waves on every SIMD, <= 168 registers) walk the
+//     (sequence, head) items; a compute wave works on the 32-query tile it holds in registers (the round-3 vision form: S^T = K Q^T, a lane owns a
+//     query column, softmax in registers, P is directly the B operand of O^T += V^T P^T), with every LDS fragment read pinned ahead of its MFMA;
+//   * the keys of an item pass by in BLOCKS of 128 (K | V: 32 KiB) through a THREE-slot LDS ring filled by LDS-DMA from the loader wave (a
+//     piece issued from a wave in the middle of MFMA / exponent work cost ~200 cycles, from a dedicated wave ~20): at step g it issues block
+//     g + 2, so a block has two whole steps to land; one workgroup barrier per block;
+//   * an item's query tiles are worked in PASSES of RNW (577 tokens: 19 tiles = 11 + 8, 257 tokens: 9 tiles = one pass); the 32 rows x 128 B of a
+//     wave's Q tile come by DMA into its own 4 KiB of LDS a whole pass ahead.  A last pass whose tiles can ALL be shared (R tiles x 2 or 4 waves
+//     <= RNW) is SPLIT over the waves by key tile within every block, and the partial (max, sum, O) of a tile are merged through the ring slot
+//     that falls free at the pass end (the plan is built on the host: RingPlan); a pass lasts as long as its largest share, so nothing else is split;
+//   * outputs straight from registers (store_out).
 //
-// LDS: 3 x 32 KiB ring + 32 KiB of Q tiles = 128 KiB.  vmcnt discipline: every wave issues exactly 4 pieces per block, so
-// `s_waitcnt vmcnt(4)` at step g leaves at most the 4 youngest operations in flight -- block g + 1's pieces or something younger
-// still -- and block g's pieces (two steps old) have landed; Q pieces are at least one block older than the block they are waited
-// with (needs >= 2 blocks per item: L > 128).
+// LDS: 3 x 32 KiB ring + 44 KiB of Q tiles = 140 KiB.  vmcnt discipline (loader): a block is 32 pieces; `s_waitcnt vmcnt(32)` at step g leaves
+// at most the 32 youngest pieces in flight -- block g + 1's -- so block g has landed; the Q pieces of a step are issued BEFORE its block pieces
+// and are never among the 32 youngest when a pass start needs them (needs >= 2 blocks per item: L > 128).
+// History and measurements: profiles/r05_vitl_attention.txt, r05_ring_waves.txt (8 / 10 / 11 waves; LDS counters instead of the barrier and a
+// pre-scaled-Q form measured and removed), r05_ring_ablate.txt (what the launch is made of).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RTPB = 4;                     // key tiles per block
 constexpr int RKEYS = RTPB * 32;            // keys per block
