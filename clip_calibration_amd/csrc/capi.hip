@@ -39,6 +39,7 @@ const OptionDesc kOptions[] = {
     {"gemm_band", "CLIPMI_GEMM_BAND", &Options::gemm_band},
     {"gemm_stream", "CLIPMI_GEMM_STREAM", &Options::gemm_stream},
     {"gemm_rstream", "CLIPMI_GEMM_RSTREAM", &Options::gemm_rstream},
+    {"gemm_split_rows", "CLIPMI_GEMM_SPLIT_ROWS", &Options::gemm_split_rows},
     {"cls_only_last_block", "CLIPMI_CLS_ONLY_LAST_BLOCK", &Options::cls_only_last_block},
     {"ln_fold", "CLIPMI_LN_FOLD", &Options::ln_fold},
     {"residual_f16", "CLIPMI_RESIDUAL_F16", &Options::residual_f16},

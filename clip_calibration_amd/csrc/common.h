@@ -138,6 +138,8 @@ struct Options {
   std::atomic<int> gemm_band{0};       // CLIPMI_GEMM_BAND: 0 = default traversal band
   std::atomic<int> gemm_stream{1};     // CLIPMI_GEMM_STREAM: 1 (default) = ping-pong persistent kernel with streamed epilogue for multi-round fp16-out GEMMs
                                        // with K >= 512 (in-proj / c_fc); 0 = one tile per workgroup (the bit-identity reference of the race screen)
+  std::atomic<int> gemm_split_rows{1}; // CLIPMI_GEMM_SPLIT_ROWS: 1 (default) = a ragged last row of tiles that would open a round of its own in the persistent
+                                        // kernel goes to the tile kernels as a second launch (gemm.hip launch_one); 0 = one launch
   std::atomic<int> gemm_rstream{1};    // CLIPMI_GEMM_RSTREAM: 1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
                                        // residual GEMMs with K <= 1536 (out-proj); 0 = one 320 x 256 tile per workgroup (the same fp32 sum, added in another order)
   std::atomic<int> cls_only_last_block{0};   // CLIPMI_CLS_ONLY_LAST_BLOCK: 1 = the image tower's last block runs out-proj / MLP on the class rows only

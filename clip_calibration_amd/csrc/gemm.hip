@@ -51,7 +51,7 @@ __device__ __forceinline__ void ln_row_params(const KArgs& a, int m, float& rstd
   const int mm = m < a.M ? m : a.M - 1;
   double s = 0.0, ss = 0.0;
   for (int p = 0; p < a.ln_parts; ++p) {
-    const float2 st = *reinterpret_cast<const float2*>(a.ln_stats + 2 * ((int64_t)p * a.M + mm));
+    const float2 st = *reinterpret_cast<const float2*>(a.ln_stats + 2 * ((int64_t)p * a.ln_M + mm));
     s += (double)st.x;
     ss += (double)st.y;
   }
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     if (wave < 2) {
       if (raw) {
         for (int p = 0; p < a.ln_parts; ++p) {   // [parts][M] float2: 2 KiB of each partial belong to this tile's rows
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_stats + 2 * ((int64_t)p * a.M + row0), (int64_t)(a.M - row0) * 8);
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_stats + 2 * ((int64_t)p * a.ln_M + row0), (int64_t)(a.M - row0) * 8);
           CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + p * (BM * 8) + wave * 1024, (wave * 64 + lane) * 16, 0);
         }
       } else if (fold) {
@@ -1680,7 +1680,28 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
     const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
                       stream_offsets_ok(k);
     const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
-    if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) return launch_stream<EPI>(k, ln_rows, s);
+    if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) {
+      // A ragged last row of tiles that opens a round of its own -- ViT-L/14@336 at 64 images: c_fc is 145 x 16 tiles = 9.06 rounds of 256 persistent
+      // workgroups, the tenth for 64 rows; ViT-L/14 at 128 images: 8.06 and 6.05 rounds -- goes to the one-tile-per-workgroup kernels as a launch of
+      // its own (a few tens of tiles, ~10 us) and the persistent kernel runs whole rounds (profiles/r05_gemm_remainder.txt).
+      const int n_cu = device_cus() & ~7;
+      const int64_t tm = (k.M + 255) / 256, tn = (k.N + 255) / 256;
+      const int rem = k.M % 256;
+      const bool split = !forced && rem != 0 && rem <= 128 && tm > 2 && n_cu > 0 && options().gemm_split_rows.load(std::memory_order_relaxed) == 1 &&
+                         ((tm - 1) * tn + n_cu - 1) / n_cu < (tm * tn + n_cu - 1) / n_cu;
+      if (!split) return launch_stream<EPI>(k, ln_rows, s);
+      KArgs head = k, tail = k;
+      head.M = k.M - rem;
+      int rc = launch_stream<EPI>(head, ln_rows, s);
+      if (rc) return rc;
+      tail.M = rem;
+      tail.A = k.A + (int64_t)head.M * k.lda;
+      tail.out = static_cast<half_t*>(k.out) + (int64_t)head.M * k.ldo;
+      if (k.ln_stats) tail.ln_stats = k.ln_stats + 2 * (int64_t)head.M;
+      int tv = pick_variant(tail);
+      if (tv == 13 || tv == 16) tv = 1;
+      return launch_by_variant<void, EPI, OUT_F32>(tv, tail, s);
+    }
   }
   if constexpr (EPI == EPI_RESIDUAL_FOLD16) {
     // fp16-stream residual GEMMs whose row ranges split into tall tiles: the persistent row-range kernel.  By default for K <= 1536
@@ -1726,7 +1747,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.im_R = a.im_R; k.im_P = a.im_P; k.im_G = a.im_P > 0 ? a.im_R / a.im_P : 0;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
-  k.ln_eps = a.ln_eps; k.x16 = a.x16; k.stats_out = a.stats_out;
+  k.ln_eps = a.ln_eps; k.ln_M = a.M; k.x16 = a.x16; k.stats_out = a.stats_out;
 #ifdef CLIPMI_TUNING
   k.stamps = g_tuning_stamps.load(std::memory_order_relaxed);   // clipmi_tuning_set_stamps (tools/gemm_stamps.py), tuning build only
   k.knob = g_tuning_knob.load(std::memory_order_relaxed);

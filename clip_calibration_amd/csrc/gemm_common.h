@@ -34,6 +34,7 @@ struct KArgs {
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
+  int ln_M;      // rows per partial plane of ln_stats ([parts][ln_M] float2): the producer's M -- not this launch's, when a launch covers a row range of it
   half_t* x16; float* stats_out;
 #ifdef CLIPMI_TUNING
   long long* stamps;   // diagnostic build only (make tuning, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps

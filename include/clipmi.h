@@ -72,6 +72,9 @@ const char* clipmi_last_error(void);
  *   gemm_rstream     (CLIPMI_GEMM_RSTREAM)    1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
  *                                             residual GEMMs with K <= 1536 (out-proj); 0 = one 320 x 256 tile per workgroup.  The row-range
  *                                             kernel adds the residual inside its K loop: both round the same fp32 sum once, in another order
+ *   gemm_split_rows  (CLIPMI_GEMM_SPLIT_ROWS) 1 (default) = where the ragged last row of 256-row tiles (M % 256 <= 128 rows) would open a round of
+ *                                             its own in the persistent kernel (ViT-L/14@336 at 64 images: c_fc 9.06 rounds), those rows go to
+ *                                             the tile kernels as a second launch; 0 = one launch
  *   attn_loader      (CLIPMI_ATTN_LOADER)     2 (default) = 193..200-token non-causal attention runs the kernel whose operands all arrive
  *                                             by LDS-DMA from a dedicated loader wave and whose output rows are stored non-temporal;
  *                                             1 = the same with plain stores; 0 = the persistent kernel (all three: same bits)

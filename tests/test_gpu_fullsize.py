@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from clip_calibration_amd import synthetic as syn  # noqa: E402
+from clip_calibration_amd import _lib, synthetic as syn  # noqa: E402
 from oracle import clip_oracle as orc  # noqa: E402  (checker only)
 
 COS_TOL = 1e-3
@@ -205,9 +205,15 @@ def test_config5_vit_l14_336_full_batch():
         parts = torch.cat([model.image_features_f32(images[i:i + 8]) for i in range(0, 64, 8)])
         picks = [0, 21, 37, 63]
         ref = orc.encode_image(sd, images[picks].cpu()).numpy()
+        _lib.set_option("gemm_split_rows", 0)      # M = 36 928 = 144 x 256 + 64: c_fc's ragged last tile row is a launch of its own by default (gemm.hip launch_one)
+        try:
+            single = model.image_features_f32(images)
+        finally:
+            _lib.set_option("gemm_split_rows", 1)
     assert torch.equal(a, b) and torch.isfinite(a).all()
     an, pn = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(parts, dim=1)
     assert (an - pn).abs().max() < 2e-4
+    assert (an - torch.nn.functional.normalize(single, dim=1)).abs().max() < 2e-4      # 64 of 36 928 rows per layer through another kernel's QuickGELU contraction
     rn = ref / np.linalg.norm(ref, axis=1, keepdims=True)
     got = an.cpu().numpy()
     cos = got @ rn.T                                                                # [64, 4]

@@ -107,6 +107,33 @@ def test_gemm_stream_kernel_race_screen(ops, clipmi_option):
     assert bad == 0, f"{bad} of 60 launches differ"
 
 
+@pytest.mark.parametrize("M,N,K", [(16448, 3072, 768), (36928, 4096, 1024), (32896, 3072, 1024), (33000, 4096, 1024)])
+def test_gemm_ragged_last_tile_row_as_its_own_launch(ops, clipmi_option, M, N, K):
+    """gemm_split_rows (default 1): a last row of 256-row tiles with <= 128 live rows that would open a round of its own in the persistent kernel
+    (65 x 12 tiles = 3.05 rounds of 256 workgroups; ViT-L/14@336 c_fc: 145 x 16 = 9.06; ViT-L/14 in-proj: 129 x 12 = 6.05) goes to the tile kernels as
+    a second launch.  With the bias epilogue every kernel involved shares one arithmetic: bit for bit against the single launch; QuickGELU: the usual
+    1-ulp contraction difference on a few elements; (33000, ...): 232 live rows in the last tile row -- not split, the same launch either way."""
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_QUICKGELU):
+        clipmi_option("gemm_split_rows", 0)
+        one = ops.gemm_f16(a, w, bias, epilogue=epi, out_dtype=torch.float16)
+        clipmi_option("gemm_split_rows", 1)
+        two = ops.gemm_f16(a, w, bias, epilogue=epi, out_dtype=torch.float16)
+        again = ops.gemm_f16(a, w, bias, epilogue=epi, out_dtype=torch.float16)
+        assert torch.equal(two, again)
+        if epi == _lib.EPI_BIAS:
+            assert torch.equal(one, two)
+        else:
+            assert float((one.float() - two.float()).abs().max()) <= 2 ** -8 and int((one != two).sum()) < 1e-4 * one.numel()
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])
+    ref = torch.nn.functional.linear(a[rows].float(), w.float(), bias)
+    ref = ref * torch.sigmoid(1.702 * ref)
+    assert float((two[rows].float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 def test_gemm_pingpong_tile_kernel_race_screen(ops, clipmi_option):
     """gemm_pp_kernel (the 320 x 256 one-tile-per-workgroup kernel with the ping-pong main loop, gemm_variant 10: what the cost
     model picks for N = 768 at M = 50432) against the compiler-scheduled two-stage loop of gemm_f16_kernel (256 x 256, variant 1):
