@@ -543,13 +543,15 @@ class CLIP(nn.Module):
             return L
         t = tokenized_prompts
         key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device))
-        hit = self._live_rows.pop(key, None)
+        with self._copies_lock:                      # (nn.DataParallel's clones ask the owner from their threads)
+            hit = self._live_rows.pop(key, None)
         if hit is None:
             last = int(t.reshape(-1, t.shape[-1]).argmax(dim=-1).max()) if t.numel() else 0
             hit = (t, min(L, max((last + 1 + 7) // 8 * 8, 1 + int(n_ctx))))
-        self._live_rows[key] = hit                   # (re-inserted last: the dict is the LRU order)
-        while len(self._live_rows) > 16:
-            self._live_rows.pop(next(iter(self._live_rows)))
+        with self._copies_lock:
+            self._live_rows[key] = hit               # (re-inserted last: the dict is the LRU order)
+            while len(self._live_rows) > 16:
+                self._live_rows.pop(next(iter(self._live_rows)))
         return max(hit[1], min(L, 1 + int(n_ctx)))
 
     def text_encoder_f32(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor,

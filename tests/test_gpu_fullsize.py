@@ -297,3 +297,27 @@ def test_config4_per_rank_path_towers_and_tail(Cn):
     assert np.array_equal(got_pred[clear], rp[clear]) and clear.sum() >= 1
     ref_bins = bin_statistics(conf.cpu().numpy(), pred.cpu().numpy(), labels.cpu().numpy(), 10)
     assert np.array_equal(bins.cpu().numpy().reshape(3, 11)[[0, 2]], ref_bins[[0, 2]])
+
+
+def test_vit_l14_ragged_tile_rows_launched_apart():
+    """ViT-L/14 at 128 images (M = 32 896 = 128 x 256 + 128): BOTH persistent GEMMs of a block have a ragged last tile row that opens a round of its own
+    (in-proj 129 x 12 tiles = 6.05 rounds -- with the LayerNorm fold's row partials read at a row offset --, c_fc 129 x 16 = 8.06) and run it as a second
+    launch (gemm_split_rows, gemm.hip launch_one).  Against the single launch: the in-projection's bias epilogue gives the same bits, c_fc's QuickGELU the
+    usual 1-ulp contraction difference on 128 of 32 896 rows per layer -- the features stay within the fp16 stream's own noise."""
+    from clip_calibration_amd.model import build_model
+    gname = "ViT-L/14"
+    model = build_model(dict(syn.synthetic_state_dict(gname, seed=0)), None).cuda()
+    images = syn.synthetic_images(128, gname, seed=5, device="cuda")
+    with torch.no_grad():
+        apart = model.image_features_f32(images)
+        again = model.image_features_f32(images)
+        _lib.set_option("gemm_split_rows", 0)
+        try:
+            single = model.image_features_f32(images)
+        finally:
+            _lib.set_option("gemm_split_rows", 1)
+    assert torch.equal(apart, again) and torch.isfinite(apart).all()
+    d = (torch.nn.functional.normalize(apart, dim=1) - torch.nn.functional.normalize(single, dim=1)).abs().max()
+    print(f"ViT-L/14 x 128: max |d feature| between one launch and remainder apart {float(d):.2e}")
+    assert d < 2e-4
+
