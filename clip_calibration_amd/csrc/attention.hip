@@ -891,7 +891,7 @@ __host__ __device__ inline int ring_spot(unsigned i) { return (int)((i >> 19) & 
 // the second co-residency hazard of this code base (52-160 of 200 LayerNorm launches wrong beside the kernel, 0 with more wait states).
 // CLIPMI_RING_ABLATE (build-time, diagnostic builds only: results are wrong with any bit set; make ring_ablate, tools/lib_ab.py):
 // 1 no exponent work (P = the raw score bits) | 2 no MFMAs (S and P.V) | 4 no LDS fragment reads | 8 no maximum | 16 no fma in front of v_exp |
-// 32 no per-block barrier (loader and compute waves run free: races, timing only)
+// 32 no per-block barrier (loader and compute waves run free: races, timing only) | 64 no LDS-DMA at all (compute on whatever the LDS holds)
 #ifndef CLIPMI_RING_ABLATE
 #define CLIPMI_RING_ABLATE 0
 #endif
@@ -1080,6 +1080,7 @@ __global__ __launch_bounds__(RTHREADS) void attention_ring_kernel(const half_t* 
       return make_rsrc(qkv + (int64_t)u.n * L * ld + u.h * 64, ((int64_t)L * ld - u.h * 64) * 2);   // rows >= L: outside the descriptor, read as zero
     };
     auto dma_block = [&](const Cur& u, int slot) {   // 32 pieces: K | V of 128 keys
+      if constexpr (CLIPMI_RING_ABLATE & 64) return;
       const __amdgpu_buffer_rsrc_t rs = item_rsrc(u);
       char* B = smem + slot * RSLOT;
       const int boff = u.b * RKEYS * ld * 2;
@@ -1089,7 +1090,8 @@ __global__ __launch_bounds__(RTHREADS) void attention_ring_kernel(const half_t* 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, CLIPMI_LDS_PTR(B + RIMG + pc * 1024), 16, radd(lane_row + swv + 2 * D * 2, boff + pc * piece_bytes), 0, 0, 0);     // V
       }
     };
-    auto dma_q = [&](const Cur& u) {   // the Q tiles of pass u.p, tile of wave w into region w: 32 pieces
+    auto dma_q = [&](const Cur& u) {   // the Q tiles of pass u.p, tile of wave w into region w: 4 pieces per wave
+      if constexpr (CLIPMI_RING_ABLATE & 64) return;
       const __amdgpu_buffer_rsrc_t rs = item_rsrc(u);
       char* Q = smem + RNSLOT * RSLOT;
       for (int w = 0; w < RNW; ++w) {

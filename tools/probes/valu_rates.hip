@@ -25,7 +25,13 @@ __global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, i
   const long long t0 = __builtin_readcyclecounter();
   f32x16 acc2 = {0};
   if (wave < mfma_waves) {   // partner waves: back-to-back MFMAs on their SIMD (waves w and w+4 share a SIMD)
-    if (indep) {
+    if (indep == 2) {   // accumulator in AccVGPRs
+      for (int i = 0; i < iters; ++i) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+                     : "+a"(acc) : "v"(fa), "v"(fb));
+      }
+    } else if (indep) {
       for (int i = 0; i < iters; ++i) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0); acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc2, 0, 0, 0);
@@ -155,6 +161,10 @@ int main() {
   run<1>("2 MFMA waves per SIMD alone (independent)", 8, dev, 8, 8, 1);
   run<1>("v_fma_f32 beside MFMA partner (independent acc)", 8, dev, 12, 4, 1);
   run<2>("exp + fma 1:1 beside MFMA partner (indep. acc)", 8, dev, 12, 4, 1);
+  run<1>("v_fma_f32 beside MFMA partner (AccVGPR acc)", 8, dev, 12, 4, 2);
+  run<0>("v_exp_f32 beside MFMA partner (AccVGPR acc)", 8, dev, 12, 4, 2);
+  run<2>("exp + fma 1:1 beside MFMA partner (AccVGPR)", 8, dev, 12, 4, 2);
+  run<6>("v_cvt_pk_f16_f32 beside MFMA (AccVGPR acc)", 8, dev, 12, 4, 2);
   run<1>("v_fma_f32 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
   run<2>("exp + fma 1:1 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
   return 0;
