@@ -87,6 +87,26 @@ __global__ __launch_bounds__(1024) void rate_kernel(long long* out, int iters, i
       } else if constexpr (MODE == 7) {   // 8 v_rcp_f32
         asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+      } else if constexpr (MODE == 10 || MODE == 11 || MODE == 12) {   // ONE wave: 8 x [1 MFMA + 5 v_fma] (10) / [1 MFMA + 3 v_exp] (11) / [1 MFMA + 7 v_fma] (12)
+#define MF "v_mfma_f32_32x32x16_f16 %16, %17, %18, %16\n"
+#define F5(a) "v_fma_f32 %" #a ", %" #a ", %19, %20\n v_fma_f32 %" #a ", %" #a ", %19, %20\n v_fma_f32 %" #a ", %" #a ", %19, %20\n v_fma_f32 %" #a ", %" #a ", %19, %20\n v_fma_f32 %" #a ", %" #a ", %19, %20\n"
+#define F2(a) "v_fma_f32 %" #a ", %" #a ", %19, %20\n v_fma_f32 %" #a ", %" #a ", %19, %20\n"
+#define E3(a, b, c) "v_exp_f32 %" #a ", %" #a "\n v_exp_f32 %" #b ", %" #b "\n v_exp_f32 %" #c ", %" #c "\n"
+        if constexpr (MODE == 10)
+          asm volatile(MF F5(0) MF F5(1) MF F5(2) MF F5(3) MF F5(4) MF F5(5) MF F5(6) MF F5(7)
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                         "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(acc)
+                       : "v"(fa), "v"(fb), "v"(c), "v"(d));
+        else if constexpr (MODE == 12)
+          asm volatile(MF F5(0) F2(8) MF F5(1) F2(9) MF F5(2) F2(10) MF F5(3) F2(11) MF F5(4) F2(12) MF F5(5) F2(13) MF F5(6) F2(14) MF F5(7) F2(15)
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                         "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(acc)
+                       : "v"(fa), "v"(fb), "v"(c), "v"(d));
+        else
+          asm volatile(MF E3(0, 1, 2) MF E3(3, 4, 5) MF E3(6, 7, 8) MF E3(9, 10, 11) MF E3(12, 13, 14) MF E3(15, 0, 1) MF E3(2, 3, 4) MF E3(5, 6, 7)
+                       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                         "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7), "+v"(acc)
+                       : "v"(fa), "v"(fb), "v"(c), "v"(d));
       } else if constexpr (MODE == 8) {   // 8 v_exp_f16
         asm volatile("v_exp_f16 %0, %0\n v_exp_f16 %1, %1\n v_exp_f16 %2, %2\n v_exp_f16 %3, %3\n v_exp_f16 %4, %4\n v_exp_f16 %5, %5\n v_exp_f16 %6, %6\n v_exp_f16 %7, %7"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
@@ -165,6 +185,12 @@ int main() {
   run<0>("v_exp_f32 beside MFMA partner (AccVGPR acc)", 8, dev, 12, 4, 2);
   run<2>("exp + fma 1:1 beside MFMA partner (AccVGPR)", 8, dev, 12, 4, 2);
   run<6>("v_cvt_pk_f16_f32 beside MFMA (AccVGPR acc)", 8, dev, 12, 4, 2);
+  // ONE instruction stream that interleaves MFMAs with independent vector instructions (per group of 1 MFMA + n vector instructions; 32 cycles = the MFMA alone)
+  for (int waves : {4, 8, 12}) {
+    run<10>("same wave: [MFMA + 5 v_fma] per group", 8, dev, waves, 0);
+    run<12>("same wave: [MFMA + 7 v_fma] per group", 8, dev, waves, 0);
+    run<11>("same wave: [MFMA + 3 v_exp] per group", 8, dev, waves, 0);
+  }
   run<1>("v_fma_f32 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
   run<2>("exp + fma 1:1 beside 2 MFMA waves per SIMD", 8, dev, 16, 8);
   return 0;
