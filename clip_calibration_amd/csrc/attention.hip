@@ -1028,9 +1028,9 @@ __device__ __forceinline__ void frag_offsets(int lane, int (&kro)[4], int (&vro)
   vro[1] = lane_base + (1 - fq) * 64;
 }
 
-// diagnostic build: stamps[((workgroup * 64 + step) * 9 + wave) * 8 + k], s_memtime (shader cycles) of lane 0, workgroups 0..7, steps 0..63.
-// compute waves 0-7: 0 loop top | 2 past the block's barrier | 3 S tiles of the LAST group issued | 4 its maximum + rescale done | 5 block computed | 6 step end
-// (pass end: merged + stored);  loader (wave 8): 0 loop top | 1 block g landed | 2 past the barrier | 7 DMA of block g + 2 (and the next Q tiles) issued
+// diagnostic build: stamps[((workgroup * 64 + step) * (RNW + 1) + wave) * 8 + k], s_memtime (shader cycles) of lane 0, workgroups 0..7, steps 0..63.
+// compute waves 0 .. RNW-1: 0 loop top | 2 past the block's barrier | 3 S tiles of the LAST group issued | 4 its maximum + rescale done | 5 block computed | 6 step end
+// (pass end: merged + stored);  loader (wave RNW): 0 loop top | 1 block g landed | 2 past the barrier | 7 DMA of block g + 2 (and the next Q tiles) issued
 __global__ __launch_bounds__(RTHREADS) void attention_ring_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int L, int H, int n_items,
                                                              const RingPlan plan CLIPMI_VISION_STAMPS_PARAM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1443,7 +1443,7 @@ int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int ca
     return launch_persist<7, 4, 0>(qkv, out, N, L, H, causal, s);
   }
   // Longer than one key block (ViT-L/14: 257 tokens, ViT-L/14@336: 577).  Non-causal (every CLIP tower of that length): the ring kernel --
-  // persistent workgroups, 128-key blocks through a three-slot LDS ring, pinned fragment reads, query tiles in passes of eight with the last
+  // persistent workgroups, 128-key blocks through a three-slot LDS ring, pinned fragment reads, query tiles in passes of RNW = 11, a short last
   // pass split by key tile.  Option attn_ring = 0, a causal mask, or a shape outside its limits keep the round-1 streaming kernel
   // (two-slot ring of 128- / 224-key blocks; the reference of the ring kernel's parity test).
   if (!causal && options().attn_ring.load(std::memory_order_relaxed) != 0 && L <= RMAXPASS * RNW * 32 && (int64_t)L * 3 * H * 64 * 2 < (1ll << 31))
