@@ -957,8 +957,13 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
       for (int e = 0; e < 16; e += 2) mloc = fmaxf(fmaxf(s[t][e], s[t][e + 1]), mloc);
     mloc = fmaxf(mloc, swap32_f(mloc));
   }
+  // The reference point of the exponentials moves only when some query's maximum has grown by more than RING_SLACK (2^8 in P): with 32 queries per wave
+  // "some lane saw a new maximum" holds in nearly every group (SQ_INSTS_VALU: 96 vector instructions per tile where the straight path has 56 -- the 48
+  // accumulator multiplies of this branch), while a maximum that jumps by e^5.5 after the first group is rare.  In between P = 2^((s - m_run) C) <= 256:
+  // exact in fp16 to the same 2^-11, sums and O in fp32; O / l does not depend on the reference point.  A lane's m_run is its reference, not its maximum.
+  constexpr float RING_SLACK = 8.0f / C;
   const float m_new = fmaxf(m_run, mloc);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull, 0)) {   // wave-uniform; exact either way (alpha == 1 where the maximum stands)
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new > m_run + RING_SLACK) != 0ull, 0)) {   // wave-uniform; every lane then moves to its own maximum
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -967,9 +972,9 @@ __device__ __forceinline__ void ring_attend(const uint32_t (&ka)[4], const uint3
 #pragma unroll
     for (int e = 0; e < 16; ++e) lacc[e] *= alpha;   // the WHOLE tuple (an element write into an MFMA tuple makes hipcc copy it at every join)
     CLIPMI_VALU_TO_MFMA_FENCE3(oacc[0], oacc[1], lacc);   // VALU-written accumulators are MFMA sources (SrcC) below
+    m_run = m_new;
   }
-  const float mc = m_new * C;
-  m_run = m_new;
+  const float mc = m_run * C;
   CLIPMI_RING_STAMP(4, mc);
   auto pv_step = [&](auto t_tag, auto ss_tag) {
     constexpr int T = decltype(t_tag)::value, SS = decltype(ss_tag)::value;
