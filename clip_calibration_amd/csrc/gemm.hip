@@ -76,6 +76,27 @@ struct Tile {
 __device__ __forceinline__ float quick_gelu(float t) {
   return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * t));
 }
+// The same on the SCALED pre-activation z = k x, k = 1.702 log2(e) (round 6): the epilogues of the fp16-out GEMMs form z straight from the
+// accumulator -- the scale rides in the row / column terms they multiply and add anyway --, so the separate product k x goes away, and
+// x / (1 + 2^-z) = z / (k + k 2^-z): exp2 with a free source negation, ONE fused multiply-add for the denominator, the reciprocal, the product.
+// Per element 4 + (c, z) instead of 5 + (c, v) vector instructions (profiles/r06_epilogue_diet.txt).  z -> +inf: 2^-z = 0, z / k = x; z -> -inf:
+// 2^-z = inf, rcp = 0, z * 0 = -0.
+constexpr float GELU_K = 2.4554669595930157f;
+__device__ __forceinline__ f32x4 quick_gelu_scaled(const f32x4& z) {
+  f32x4 d, o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[q] = __builtin_fmaf(__builtin_amdgcn_exp2f(-z[q]), GELU_K, GELU_K);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = z[q] * __builtin_amdgcn_rcpf(d[q]);
+  return o;
+}
+// z = acc * (k rstd) + (k bias - (k mean rstd) g), explicit fused multiply-adds: the same bits in every kernel that inlines it
+__device__ __forceinline__ f32x4 gelu_preact_scaled(const f32x4& acc, float rs_k, float mrs_k, const f32x4& bias_k, const f32x4& g) {
+  f32x4 z;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z[q] = __builtin_fmaf(acc[q], rs_k, __builtin_fmaf(-mrs_k, g[q], bias_k[q]));
+  return z;
+}
 
 // Tile traversal.  blockIdx % 8 labels the XCD (blocks are dealt round-robin over the 8 XCDs); each label gets a
 // contiguous range of logical tile ids (bijective remap), and logical ids walk the tile grid in BANDS of `band`
@@ -143,10 +164,11 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
           const int i = h * 4 + ii;
-          f32x4 v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
+          f32x4 v;
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            v = quick_gelu_scaled(gelu_preact_scaled(acc[i][jc * CH + jj], rs * GELU_K, mrs * GELU_K, bias[i] * GELU_K, lng[i]));
+          } else {
+            v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
           }
           if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
             const int mr = m0 + wave_m * T::WTM + (jc * CH + jj) * 16 + r16;
@@ -491,10 +513,15 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
       const int n = n0 + wave_n * T::WTN + i * 16 + g4 * 4;
       if (n >= a.N) continue;
       f32x4 v = acc[i][j];
-      if constexpr (EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+      if constexpr (EPI == CLIPMI_EPI_BIAS) {
         f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
         if (a.ln_stats) b -= mrs * *reinterpret_cast<const f32x4*>(a.ln_g + n);
         v = v * rs + b;
+      }
+      if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+        const f32x4 g = a.ln_stats ? *reinterpret_cast<const f32x4*>(a.ln_g + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v = quick_gelu_scaled(gelu_preact_scaled(v, rs * GELU_K, mrs * GELU_K, b * GELU_K, g));
       }
       if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL || EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -507,10 +534,6 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
       if constexpr (EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
       }
       if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL) {
         const f32x4 rr = *reinterpret_cast<const f32x4*>(a.residual + orow * a.ldo + n);
@@ -771,13 +794,17 @@ constexpr int STREAM_RAW_PARTS = 4;   // row-partial slots of gemm_stream_kernel
 // (more than STREAM_RAW_PARTS column tiles) go through one ln_finalize_kernel launch per folded GEMM, which needs a scratch row
 inline bool stream_raw_ok(const KArgs& k) { return k.ln_parts <= STREAM_RAW_PARTS; }
 
+// floor(n / d) for wave-uniform n through the multiplier mg = ceil(2^32 / d) the launcher prepared (exact while n d < 2^32: checked there);
+// d = 1 has no 32-bit multiplier.  Two scalar instructions instead of the ~25 of a division by a run-time divisor -- and none of its vector ones
+__device__ __forceinline__ int div_magic(int n, int d, uint32_t mg) { return d == 1 ? n : (int)__umulhi((uint32_t)n, mg); }
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
   using T = TStream;
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN;   // TM = 8, TN = 4
   // LDS behind the stages: 2 x (row parameters of a tile) | 2 x ([BN] bias | [BN] g).  Row parameters are either the finalised
   // (rstd, mean * rstd) pairs of ln_finalize_kernel (ln_rows != nullptr) or -- RAW mode, ln_rows == nullptr with a.ln_stats set, up
-  // to STREAM_RAW_PARTS partials -- the producer's (sum, sumsq) row partials themselves, finalised in the epilogue with the
+  // to STREAM_RAW_PARTS partials -- the producer's (sum, sumsq) row partials themselves, finalised at the tile start with the
   // arithmetic of ln_row_params: the launch of ln_finalize_kernel in front of every folded GEMM (4.8 us + a launch gap, 24 per
   // image-tower step) goes away for ~100 instructions per wave and tile.
   constexpr int LNP_PAR = STREAM_RAW_PARTS * BM * 8;
@@ -787,7 +814,6 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave % T::WGM, wave_n = wave / T::WGM;
-  const int tiles_m = (a.M + BM - 1) / BM;
   const bool raw = ln_rows == nullptr && a.ln_stats != nullptr;   // kernel arguments: uniform
   const bool fold = ln_rows != nullptr || raw;
 
@@ -810,62 +836,73 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   const int wbase = T::XBYTES + wave_n * T::WTN * 128;
   const int nk = a.K / BK;
 
+  // virtual block id -> tile: the XCD label's contiguous range of logical ids, bands of a.band n-tiles, m slow and n fast inside a band (tile_coords);
+  // the two divisions by multipliers from the launcher
   auto coords = [&](int vb, int& m0, int& n0) {
     const int xcd = vb & 7, q = a.nwg >> 3, r = a.nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    const int per_band = tiles_m * a.band;
-    const int b = wg / per_band;
-    const int within = wg - b * per_band;
-    const int rem = a.tiles_n - b * a.band;
-    const int gw = rem < a.band ? rem : a.band;
-    const int tm = within / gw;
+    const int b = div_magic(wg, a.per_band, a.mg_per_band);
+    const int within = wg - b * a.per_band;
+    const bool last = (b + 1) * a.band > a.tiles_n;   // the ragged last band
+    const int gw = last ? a.tiles_n - b * a.band : a.band;
+    const int tm = div_magic(within, gw, last ? a.mg_gw_last : a.mg_band);
     m0 = tm * BM;
     n0 = (b * a.band + (within - tm * gw)) * BN;
   };
-  auto stage = [&](const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
-    char* xs = smem + buf * T::STAGE + lds_wave_off;
-    char* ws = xs + T::XBYTES;
-    const int k0 = kt * BK * 2;
-#pragma unroll
-    for (int i = 0; i < T::XI; ++i) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + i * (NT * 16), row_off(xoff0, i * xstep), k0);
-#pragma unroll
-    for (int i = 0; i < T::WI; ++i) CLIPMI_BUFFER_LOAD_LDS16(wrs, ws + i * (NT * 16), row_off(woff0, i * wstep), k0);
-  };
+  // ---- ONE descriptor per matrix for the whole launch (round 6): a tile's first row / column goes into the offsets -- as a scalar added to the
+  // lane's VGPR offset, the operand the hardware range-checks: rows at or beyond M and weight rows at or beyond N still read as zero, output rows
+  // at or beyond M are still dropped.  The per-tile descriptors of rounds 2-5 cost a 64-bit multiply-add, a 64-bit clamp (vector compares: the
+  // scalar unit has none) and four live SGPRs each at every tile change; the launcher checks that a whole matrix stays below 2 GiB.
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A, (int64_t)a.M * a.lda * 2);
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W, (int64_t)a.N * a.ldw * 2);
+  constexpr int OUT_OF_RANGE = (int)0x80000000;   // as a tile offset: every lane's sum lies beyond any descriptor (lane offsets stay below 2^31)
   // one 1 KiB piece per wave of a stage (P = 0 .. XI-1: activations, XI .. XI+WI-1: weights): the K loop issues a stage's pieces
   // one per 4-MFMA step instead of all at once -- eight waves each issuing eight LDS-DMA instructions right behind the barrier
   // queued up behind the CU's one address path (64 KB at 64 B/clk) with no MFMA in flight: that, not the LDS reads, held the
   // first version of this loop at ~50 % of the matrix rate (in-kernel clock stamps: 46 k cycles per tile against 24.6 k of MFMAs)
-  auto stage_piece = [&](auto p_tag, const __amdgpu_buffer_rsrc_t& xrs, const __amdgpu_buffer_rsrc_t& wrs, int buf, int kt) {
+  // xo / wo: byte offset of the tile's first activation / weight row (scalars)
+  auto stage_piece = [&](auto p_tag, int buf, int kt, int xo, int wo) {
     constexpr int P = decltype(p_tag)::value;
     char* xs = smem + buf * T::STAGE + lds_wave_off;
     const int k0 = kt * BK * 2;
-    if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, P * xstep), k0);
-    else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, (P - T::XI) * wstep), k0);
+    if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, xo + P * xstep), k0);
+    else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, wo + (P - T::XI) * wstep), k0);
   };
-  // row / column parameters of a tile -> LDS by DMA, one 1 KiB piece per wave (waves 0-3); rows / columns outside the
-  // matrix lie outside the descriptors and read as zero.  They ride on the same vmcnt wait as the tile's first stage.
+  static_assert(T::XI + T::WI == 8, "eight DMA pieces per wave and stage");
+  auto stage = [&](int buf, int kt, int xo, int wo) {
+    stage_piece(std::integral_constant<int, 0>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 1>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 2>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 3>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 4>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 5>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 6>{}, buf, kt, xo, wo);
+    stage_piece(std::integral_constant<int, 7>{}, buf, kt, xo, wo);
+  };
+  // row / column parameters of a tile -> LDS by DMA, one 1 KiB piece per wave (waves 0-3), through whole-array descriptors like the operands:
+  // columns at or beyond N and rows beyond the last partial plane read as zero; rows at or beyond M inside a plane read the next plane's first
+  // rows -- finite numbers that only ever reach output rows the store descriptor drops.
   auto params = [&](int row0, int col0, int which) {
     char* lnp = smem + LNP_OFF + which * LNP_PAR;
     char* colp = smem + COLP_OFF + which * (2 * BN * 4);
     if (wave < 2) {
       if (raw) {
-        for (int p = 0; p < a.ln_parts; ++p) {   // [parts][M] float2: 2 KiB of each partial belong to this tile's rows
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_stats + 2 * ((int64_t)p * a.ln_M + row0), (int64_t)(a.M - row0) * 8);
-          CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + p * (BM * 8) + wave * 1024, (wave * 64 + lane) * 16, 0);
-        }
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_stats, ((int64_t)(a.ln_parts - 1) * a.ln_M + a.M) * 8);
+        for (int p = 0; p < a.ln_parts; ++p)   // [parts][ln_M] float2: 2 KiB of each partial belong to this tile's rows
+          CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + p * (BM * 8) + wave * 1024, row_off((wave * 64 + lane) * 16, (p * a.ln_M + row0) * 8), 0);
       } else if (fold) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows + row0, (int64_t)(a.M - row0) * 8);
-        CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, (wave * 64 + lane) * 16, 0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(ln_rows, (int64_t)a.M * 8);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, lnp + wave * 1024, row_off((wave * 64 + lane) * 16, row0 * 8), 0);
       }
     } else if (wave == 2) {
       if constexpr (EPI != CLIPMI_EPI_NONE) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bias + col0, (int64_t)(a.N - col0) * 4);
-        CLIPMI_BUFFER_LOAD_LDS16(rs, colp, lane * 16, 0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bias, (int64_t)a.N * 4);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, colp, row_off(lane * 16, col0 * 4), 0);
       }
     } else if (wave == 3) {
       if (fold) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_g + col0, (int64_t)(a.N - col0) * 4);
-        CLIPMI_BUFFER_LOAD_LDS16(rs, colp + BN * 4, lane * 16, 0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.ln_g, (int64_t)a.N * 4);
+        CLIPMI_BUFFER_LOAD_LDS16(rs, colp + BN * 4, row_off(lane * 16, col0 * 4), 0);
       }
     }
   };
@@ -887,10 +924,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #else
 #define STREAM_A_ROW(m) (m)
 #endif
-  __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.A + (int64_t)STREAM_A_ROW(m0) * a.lda, ((int64_t)(a.M - STREAM_A_ROW(m0)) * a.lda) * 2);
-  __amdgpu_buffer_rsrc_t wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
+  int txo = STREAM_A_ROW(m0) * (int)a.lda * 2, two = n0 * (int)a.ldw * 2;   // byte offsets of the tile's operand panels
   int first_buf = 0, par = 0;
-  stage(xrs, wrs, first_buf, 0);
+  stage(first_buf, 0, txo, two);
   params(m0, n0, 0);
 
   // ---- outputs of the previous tile.  The first HD 16-row slices of a wave's 128 x 64 part are stored as soon as they are
@@ -907,19 +943,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int j = 0; j < NHELD; ++j) held[p][j] = u32x4{0u, 0u, 0u, 0u};
-  // Stores go through a buffer descriptor that starts at the tile's first element and ends with the matrix: rows at or beyond
-  // M are dropped by the hardware range check, "nothing held yet" is a descriptor of zero bytes.  The whole byte offset goes
-  // into the VGPR operand -- only that (not the scalar offset) takes part in the range check -- as (lane constant) + (scalar:
-  // wave, slice and column-block part); columns at or beyond N (last n-tile when N is not a multiple of 256) are sent out of
-  // range the same way (a select, no divergent branch around the stores).
+  // Stores go through the descriptor of the whole output matrix: rows at or beyond M are dropped by the hardware range check.  The whole byte
+  // offset goes into the VGPR operand -- only that (not the scalar offset) takes part in the range check -- as (lane constant) + (scalar: tile,
+  // wave, slice and column-block part); columns at or beyond N (last n-tile when N is not a multiple of 256) are sent out of range by a select
+  // (no divergent branch around the stores), and so is everything while nothing is held yet (hn0 = N: no column passes).
   // A converted slice is 4 n-blocks x 4 consecutive columns (8 bytes) per lane; v_permlane16_swap on each block pair (i, i + 1)
   // -- odd 16-lane rows of block i against even rows of block i + 1 -- leaves every lane with 8 consecutive columns: lanes
   // g4 = 0, 2 get columns 16 i + 4 g4 .. + 7 of block i, lanes g4 = 1, 3 columns 16 (i + 1) + 4 (g4 - 1) .. + 7 of block i + 1.
   // Two 16-byte stores per slice (64 contiguous bytes per row and instruction) instead of four 8-byte ones: VMEM issue, not
   // bandwidth, is what these stores cost the K loop.
   half_t* out = static_cast<half_t*>(a.out);
-  __amdgpu_buffer_rsrc_t ors = make_rsrc(out, 0);
-  int hn0 = 0;               // first column of the tile `ors` describes
+  const __amdgpu_buffer_rsrc_t ors = make_rsrc(out, (int64_t)a.M * a.ldo * 2);
+  int hn0 = a.N;             // first column of the tile the held slices belong to
+  int tso = 0;               // byte offset of that tile's first element + this wave's part of it
   const int lcol = (g4 & 1) * 16 + (g4 >> 1) * 8;          // the lane's first column inside a block pair after the swap
   const int st_lane = (r16 * (int)a.ldo + lcol) * 2;
   const int slice_bytes = 16 * (int)a.ldo * 2;
@@ -935,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   };
   auto store_piece = [&](int j, int p, const u32x4& v) {   // rows 16 j .. 16 j + 15 of this wave's part of the tile, block pair p
     const int col = hn0 + wave_n * 64 + lcol + p * 32;
-    const int in_range = row_off(st_lane, wave_soff + j * slice_bytes + p * 64);
+    const int in_range = row_off(st_lane, tso + j * slice_bytes + p * 64);
     const int voff = col < a.N ? in_range : (int)0xFFFFFFF0;
     if constexpr (CLIPMI_ABLATE & 1) asm volatile("" ::"v"(v), "v"(voff));   // (energy ablation: no output stores at all)
     else __builtin_amdgcn_raw_buffer_store_b128(v, ors, voff, 0, CLIPMI_STORE_AUX);
@@ -944,11 +980,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 
   // ---- operand fragments: inline-asm LDS reads, pinned ahead of the MFMAs that use them (cdna_hip_programming.md §5.7 form
   // (ii); same construction as attend_dense_pf in attention.hip).  Per K-step and wave: 2 k-halves x 8 activation blocks
-  // (B operand, xf) x 4 weight blocks (A operand, wf) = 64 MFMAs.  The four weight fragments of a k-half stay resident (two
-  // register sets: the second half's are read during the first half), the activation fragments stream through a ring of
-  // three: the read for step s + 3 is issued right after the MFMAs of step s, so a fragment has two steps (128 matrix-pipe
-  // cycles of this wave, 256 of the SIMD) to arrive.  LDS returns in order: the counted waits below name how many reads were
-  // issued after the awaited one.
+  // (B operand, xf) x 4 weight blocks (A operand, wf) = 64 MFMAs.  LDS returns in order: the counted waits below name how many
+  // reads were issued after the awaited one.
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t xo[2] = {(uint32_t)(xbase + foff[0]), (uint32_t)(xbase + foff[1])};
   const uint32_t wo[2] = {(uint32_t)(wbase + foff[0]), (uint32_t)(wbase + foff[1])};
@@ -967,13 +1000,16 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   //        that ends slot 8k - 1; the first piece is issued in slot 8k.
   //   RAW  the last pieces are issued in slot 8k + 5; every wave waits for its own pieces at the end of slot 8k + 7 (group 0:
   //        after its compute part, group 1: after its load part), the first read of stage k + 1 is in slot 8k + 8.
+  // The LAST K-step of a tile stages the NEXT tile's first stage the same way (round 6: knext = 0 with the next tile's offsets; until then
+  // those eight pieces went out between the slices of the epilogue and the tile change waited for them): by the time the epilogue is
+  // converted the next K loop can start at once -- no vmcnt wait and no workgroup barrier between two tiles.
   // The fragment registers are single-buffered: a wave overwrites them in its load part, after its MFMAs of the previous
   // compute part have been issued.
   const int grp = wave >> 2;   // uniform
-  auto kstep = [&](auto slice_tag, auto first_tag, auto more_tag, int kt) {
+  auto kstep = [&](auto slice_tag, auto first_tag, auto more_tag, int kt, int knext, int nxo, int nwo) {
     constexpr int SLICE = decltype(slice_tag)::value;
     constexpr bool FIRSTK = decltype(first_tag)::value;   // the accumulators start at 0
-    constexpr bool MORE = decltype(more_tag)::value;      // a next K-step exists: its stage is DMA'd during this one
+    constexpr bool MORE = decltype(more_tag)::value;      // a stage is DMA'd during this K-step: K-step knext of the tile at (nxo, nwo)
     constexpr int NST = (SLICE >= 0 && !(CLIPMI_ABLATE & 1)) ? SPS : 0;   // stores issued behind this K-step's DMA pieces
     const int buf = (first_buf + kt) & 1;
     const uint32_t sb = lds_base + (uint32_t)(buf * T::STAGE);
@@ -999,19 +1035,18 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       }
       if constexpr (MORE && !(CLIPMI_ABLATE & 2)) {
         if constexpr (P == 0) {
-          stage_piece(std::integral_constant<int, 0>{}, xrs, wrs, buf ^ 1, kt + 1);
-          stage_piece(std::integral_constant<int, 1>{}, xrs, wrs, buf ^ 1, kt + 1);
-          stage_piece(std::integral_constant<int, 2>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 0>{}, buf ^ 1, knext, nxo, nwo);
+          stage_piece(std::integral_constant<int, 1>{}, buf ^ 1, knext, nxo, nwo);
+          stage_piece(std::integral_constant<int, 2>{}, buf ^ 1, knext, nxo, nwo);
         } else if constexpr (P == 1) {
-          stage_piece(std::integral_constant<int, 3>{}, xrs, wrs, buf ^ 1, kt + 1);
-          stage_piece(std::integral_constant<int, 4>{}, xrs, wrs, buf ^ 1, kt + 1);
-          stage_piece(std::integral_constant<int, 5>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 3>{}, buf ^ 1, knext, nxo, nwo);
+          stage_piece(std::integral_constant<int, 4>{}, buf ^ 1, knext, nxo, nwo);
+          stage_piece(std::integral_constant<int, 5>{}, buf ^ 1, knext, nxo, nwo);
         } else if constexpr (P == 2) {
-          stage_piece(std::integral_constant<int, 6>{}, xrs, wrs, buf ^ 1, kt + 1);
-          stage_piece(std::integral_constant<int, 7>{}, xrs, wrs, buf ^ 1, kt + 1);
+          stage_piece(std::integral_constant<int, 6>{}, buf ^ 1, knext, nxo, nwo);
+          stage_piece(std::integral_constant<int, 7>{}, buf ^ 1, knext, nxo, nwo);
         }
       }
-      static_assert(T::XI + T::WI == 8, "eight DMA pieces per wave and stage");
       if constexpr (P == 3 && NST > 0) {
         store_piece(HD + SLICE, 0, held[0][SLICE]);
         store_piece(HD + SLICE, 1, held[1][SLICE]);
@@ -1069,9 +1104,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       a.stamps[vb * 8 + 5] = (long long)blockIdx.x;
     }
 #endif
-    // RAW mode: the tile's row partials have landed (the wait and barrier above): thread t owns row t, reduces its partials with
-    // the arithmetic of ln_row_params and leaves (rstd, mean * rstd) in slot 0 of the table, in place.  Read in the epilogue, a
-    // whole K loop of workgroup barriers later.  Rows past M read as zeros and are never stored.
+    // RAW mode: the tile's row partials have landed (behind the last K-step of the previous tile): thread t owns row t, reduces its partials
+    // with the arithmetic of ln_row_params and leaves (rstd, mean * rstd) in slot 0 of the table, in place.  Read in the epilogue, a
+    // whole K loop of workgroup barriers later.  Rows past M hold other rows' numbers and are never stored.
     if (raw && tid < BM) {
       float2* rp = reinterpret_cast<float2*>(smem + LNP_OFF + par * LNP_PAR) + tid;
       double ps = 0.0, pss = 0.0;
@@ -1088,49 +1123,51 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     constexpr std::true_type yes{};
     using I = std::integral_constant<int, -1>;
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 starts one part later
-    kstep(I{}, yes, yes, 0);
+    kstep(I{}, yes, yes, 0, 1, txo, two);
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
     }
 #endif
-    kstep(std::integral_constant<int, 0 < NHELD ? 0 : -1>{}, no, yes, 1);   // K-steps 1 .. NHELD carry the held slices
-    kstep(std::integral_constant<int, 1 < NHELD ? 1 : -1>{}, no, yes, 2);
-    kstep(std::integral_constant<int, 2 < NHELD ? 2 : -1>{}, no, yes, 3);
-    kstep(std::integral_constant<int, 3 < NHELD ? 3 : -1>{}, no, yes, 4);
-    kstep(std::integral_constant<int, 4 < NHELD ? 4 : -1>{}, no, yes, 5);
-    kstep(std::integral_constant<int, 5 < NHELD ? 5 : -1>{}, no, yes, 6);
-    for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt);   // K >= 8 K-steps (checked by the launcher)
-    kstep(I{}, no, no, nk - 1);
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and group 0 waits out group 1's last compute part
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+    kstep(std::integral_constant<int, 0 < NHELD ? 0 : -1>{}, no, yes, 1, 2, txo, two);   // K-steps 1 .. NHELD carry the held slices
+    kstep(std::integral_constant<int, 1 < NHELD ? 1 : -1>{}, no, yes, 2, 3, txo, two);
+    kstep(std::integral_constant<int, 2 < NHELD ? 2 : -1>{}, no, yes, 3, 4, txo, two);
+    kstep(std::integral_constant<int, 3 < NHELD ? 3 : -1>{}, no, yes, 4, 5, txo, two);
+    kstep(std::integral_constant<int, 4 < NHELD ? 4 : -1>{}, no, yes, 5, 6, txo, two);
+    kstep(std::integral_constant<int, 5 < NHELD ? 5 : -1>{}, no, yes, 6, 7, txo, two);
+    for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt, kt + 1, txo, two);   // K >= 8 K-steps (checked by the launcher)
 
-    const int last_buf = (first_buf + nk - 1) & 1;
+    // ---- the next tile, before this one's last K-step: its first stage and its parameters are DMA'd during that K-step.  Nothing left to
+    // do: the offsets point beyond the descriptors, the pieces fetch nothing.
     const int cm0 = m0, cn0 = n0;
     [[maybe_unused]] const int cvb = vb;
+    const int nvb = vb + gridDim.x;
+    const bool has_next = nvb < a.nwg;
+    txo = OUT_OF_RANGE;
+    two = OUT_OF_RANGE;
+    if (has_next) {
+      vb = nvb;
+      coords(vb, m0, n0);
+      txo = STREAM_A_ROW(m0) * (int)a.lda * 2;
+      two = n0 * (int)a.ldw * 2;
+      params(m0, n0, par ^ 1);
+    }
+    kstep(I{}, no, yes, nk - 1, 0, txo, two);
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and group 0 waits out group 1's last compute part
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+    first_buf = ((first_buf + nk - 1) & 1) ^ 1;         // where the next tile's first stage has just landed
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[cvb * 8 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[cvb * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
     }
 #endif
-    const int nvb = vb + gridDim.x;
-    const bool has_next = nvb < a.nwg;
-    if (has_next) {   // the buffer that is NOT the last one read is free: the next tile's first stage goes there (below)
-      vb = nvb;
-      coords(vb, m0, n0);
-      xrs = make_rsrc(a.A + (int64_t)STREAM_A_ROW(m0) * a.lda, ((int64_t)(a.M - STREAM_A_ROW(m0)) * a.lda) * 2);
-      wrs = make_rsrc(a.W + (int64_t)n0 * a.ldw, ((int64_t)(a.N - n0) * a.ldw) * 2);
-      first_buf = last_buf ^ 1;
-      params(m0, n0, par ^ 1);
-    }
     // ---- element-wise epilogue (row / column parameters from LDS, DMA'd a whole tile ago): slices 0 .. HD-1 are stored at
     // once, slices HD .. TM-1 go into `held`.  All parameters of the tile are read up front (the fragment registers are free
-    // now: 8 column vectors + 8 row pairs, one LDS round trip instead of one per slice), and the next tile's first stage is
-    // DMA'd one piece per slice, between the slices' arithmetic.
-    ors = make_rsrc(out + (int64_t)cm0 * a.ldo + cn0, ((int64_t)(a.M - cm0) * a.ldo - cn0) * 2);
+    // now: 8 column vectors + 8 row pairs, one LDS round trip instead of one per slice).
     hn0 = cn0;
+    tso = (cm0 * (int)a.ldo + cn0) * 2 + wave_soff;
     {
       int le = lane;
       asm volatile("" : "+v"(le));   // keeps the lane-derived offsets below out of the K loop's live ranges
@@ -1144,12 +1181,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         const int nl = wave_n * 64 + eg4 * 4 + i * 16;
         bb[i] = *reinterpret_cast<const f32x4*>(colp + nl);
         gg[i] = *reinterpret_cast<const f32x4*>(colp + BN + nl);
+        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) bb[i] = bb[i] * GELU_K;   // the scaled pre-activation: see quick_gelu_scaled
       }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) pr[j] = lnp[wave_m * T::WTM + j * 16 + er16];
-      auto piece = [&](auto p_tag) {
-        if (has_next) stage_piece(p_tag, xrs, wrs, first_buf, 0);
-      };
+      for (int j = 0; j < TM; ++j) {
+        pr[j] = lnp[wave_m * T::WTM + j * 16 + er16];
+        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) pr[j] = make_float2(pr[j].x * GELU_K, pr[j].y * GELU_K);
+      }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #ifdef CLIPMI_TUNING
@@ -1159,18 +1197,9 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         f16x4 cv[TN];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          f32x4 v = acc[i][j] * rs + (bb[i] - mrs * gg[i]);
-          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-            const f32x4 t = v * -2.4554669595930157f;   // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): packed where hipcc can
-            f32x4 e;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = __builtin_amdgcn_exp2f(t[q]);
-            const f32x4 d = e + 1.0f;
-            f32x4 r;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = __builtin_amdgcn_rcpf(d[q]);
-            v = v * r;
-          }
+          f32x4 v;
+          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) v = quick_gelu_scaled(gelu_preact_scaled(acc[i][j], rs, mrs, bb[i], gg[i]));
+          else v = acc[i][j] * rs + (bb[i] - mrs * gg[i]);
           cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         }
         u32x4 pk[2];
@@ -1182,21 +1211,6 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
           held[0][j - HD] = pk[0];
           held[1][j - HD] = pk[1];
         }
-#if CLIPMI_STREAM_PREFETCH == 1   // two pieces behind each of the first four slices: the last one has half the conversion to land
-        if (j == 0) { piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{}); }
-        if (j == 1) { piece(std::integral_constant<int, 2>{}); piece(std::integral_constant<int, 3>{}); }
-        if (j == 2) { piece(std::integral_constant<int, 4>{}); piece(std::integral_constant<int, 5>{}); }
-        if (j == 3) { piece(std::integral_constant<int, 6>{}); piece(std::integral_constant<int, 7>{}); }
-#else
-        if (j == 0) piece(std::integral_constant<int, 0>{});
-        if (j == 1) piece(std::integral_constant<int, 1>{});
-        if (j == 2) piece(std::integral_constant<int, 2>{});
-        if (j == 3) piece(std::integral_constant<int, 3>{});
-        if (j == 4) piece(std::integral_constant<int, 4>{});
-        if (j == 5) piece(std::integral_constant<int, 5>{});
-        if (j == 6) piece(std::integral_constant<int, 6>{});
-        if (j == 7) piece(std::integral_constant<int, 7>{});
-#endif
         __builtin_amdgcn_sched_barrier(0);   // one 16-row slice at a time: the accumulators die as they are converted
       }
     }
@@ -1205,9 +1219,6 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     if (stamp) a.stamps[cvb * 8 + 3] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     if (!has_next) break;
-    wait_vmcnt<0>();                 // the next tile's stage 0 and parameters (their pieces went out between the slices, the last one
-                                     // behind the direct stores)
-    __builtin_amdgcn_s_barrier();
   }
   // the last tile's held slices: nothing left to hide them behind
 #pragma unroll
@@ -1235,8 +1246,16 @@ int launch_stream(KArgs k, float2* ln_rows, hipStream_t s) {
   k.band = pick_band(k.tiles_n, T::BN, k.K);
   const int64_t nwg = (int64_t)tiles_m * k.tiles_n;
   CLIPMI_REQUIRE(nwg < (1ll << 30), CLIPMI_ERR_SHAPE, "gemm: grid too large");
-  CLIPMI_REQUIRE(stream_offsets_ok(k), CLIPMI_ERR_SHAPE, "gemm: leading dimensions too long for the 32-bit tile offsets of the streamed kernel");
+  CLIPMI_REQUIRE(stream_offsets_ok(k) && stream_whole_matrix_ok(k), CLIPMI_ERR_SHAPE, "gemm: operands too large for the 32-bit offsets of the streamed kernel");
   k.nwg = (int)nwg;
+  // tile traversal by multiplication (div_magic): bands of k.band n-tiles, the last one possibly narrower
+  const auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint32_t)d - 1) / (uint32_t)d) : 0u; };
+  k.per_band = tiles_m * k.band;
+  const int gw_last = k.tiles_n % k.band ? k.tiles_n % k.band : k.band;
+  k.mg_per_band = magic(k.per_band);
+  k.mg_band = magic(k.band);
+  k.mg_gw_last = magic(gw_last);
+  CLIPMI_REQUIRE(nwg * (int64_t)(k.per_band > k.band ? k.per_band : k.band) < (1ll << 32), CLIPMI_ERR_SHAPE, "gemm: tile grid too large for the streamed kernel's traversal");
   // RAW mode: the kernel finalises the row partials itself; with more partials than its LDS table holds they are reduced to
   // (rstd, mean * rstd) once per GEMM by ln_finalize_kernel
   const bool raw = k.ln_stats && stream_raw_ok(k);
@@ -1678,7 +1697,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   // (the cost model only ranks the one-tile-per-workgroup kernels)
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
     const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
-                      stream_offsets_ok(k);
+                      stream_offsets_ok(k) && stream_whole_matrix_ok(k);
     const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
     if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) {
       // A ragged last row of tiles that opens a round of its own -- ViT-L/14@336 at 64 images: c_fc is 145 x 16 tiles = 9.06 rounds of 256 persistent

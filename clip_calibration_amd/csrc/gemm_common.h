@@ -33,6 +33,7 @@ struct KArgs {
   int im_R, im_P, im_G;   // implicit im2col (gemm_pp_kernel<..., IM2COL>): A is the fp16 NCHW image [M / patches, 3, R, R], patch size P, grid G = R / P
   int tiles_n; int nwg;
   int band;      // n-tiles per band of the tile traversal (see tile_coords)
+  int per_band; uint32_t mg_per_band, mg_band, mg_gw_last;   // gemm_stream_kernel: tiles per band and the multipliers of its divisions (launch_stream)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   int ln_M;      // rows per partial plane of ln_stats ([parts][ln_M] float2): the producer's M -- not this launch's, when a launch covers a row range of it
   half_t* x16; float* stats_out;
@@ -122,6 +123,14 @@ __device__ __forceinline__ void lgkm_wait_x(f16x8 (&x)[H]) {
 inline bool stream_offsets_ok(const KArgs& k) {
   const int64_t lim = (1ll << 31) / (2 * 257);
   return k.lda < lim && k.ldw < lim && k.ldo < lim && (device_cus() & ~7) >= 8;
+}
+// gemm_stream_kernel (round 6) addresses every operand from the start of its matrix with ONE descriptor per launch: a whole matrix (plus the rows
+// a lane offset can reach beyond it) has to stay below 2 GiB, and so do the tile ids times their divisors (div_magic)
+inline bool stream_whole_matrix_ok(const KArgs& k) {
+  const int64_t lim = (1ll << 31) - (1ll << 24);
+  const int64_t tiles = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256);
+  return ((int64_t)k.M + 256) * k.lda * 2 < lim && ((int64_t)k.N + 256) * k.ldw * 2 < lim && ((int64_t)k.M + 256) * k.ldo * 2 < lim &&
+         (!k.ln_stats || ((int64_t)k.ln_parts * k.ln_M + 256) * 8 < lim) && tiles * tiles < (1ll << 32);
 }
 
 // gemm_rstream.hip: the persistent row-range kernel of the fp16-stream residual GEMMs (variant 16)
