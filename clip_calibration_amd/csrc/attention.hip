@@ -857,7 +857,7 @@ constexpr int RQ = RNW * 32 * 128;          // the Q tiles of a pass
 constexpr int RSMEM = RNSLOT * RSLOT + RQ;  // 96 KiB + 44 KiB
 static_assert(RNW >= 4 && RNW <= 12 && RSMEM <= 160 * 1024, "ring attention: 4..12 compute waves, LDS <= 160 KiB");
 constexpr int RSPOT = 8192 + 512;           // a partial: O (32 registers x 64 lanes x 4 B) + m + l per lane
-constexpr int RMAXPASS = 8;                 // 8 passes x RNW tiles x 32 rows = 2560 tokens
+constexpr int RMAXPASS = 8;                 // 8 passes x RNW tiles x 32 rows = 2816 tokens with RNW = 11 (the dispatcher's limit below)
 
 // 32-bit words only: a wave reads its entry by a wave-uniform index, which must stay a scalar load (a byte array in the kernel arguments is
 // read with global_load_sbyte + s_waitcnt vmcnt(0), and that wait would drain the DMA ring at every step).

@@ -186,11 +186,14 @@ int check_block(const clipmi_block_weights& b) {
 // folded == true: on entry AND on exit w.xn holds fp16(xres) and w.stats the *parts row-sum partials of xres (written
 // by the residual epilogues); ln_1 / ln_2 are applied inside the in-proj / c_fc GEMM epilogues.
 // folded == false: separate LayerNorm kernels (launched with steps 0 and 3).
-// cls_only (image tower, LAST block, option cls_only_last_block): only the class token's row of every sequence leaves the
-// tower (clip/model.py:419: ln_post(x[:, 0, :])), so steps 2..4 of the last block -- out-proj, c_fc, c_proj and their LayerNorms
-// -- run on the n_seq class rows alone: the same GEMMs with M = n_seq and row stride L * D on the token-major buffers (the
-// in-projection and the attention stay whole: every token is a key).  Same arithmetic per element; 1/12 of the MLP flops of
-// a 12-layer tower are never issued.  Off by default: bench.py's headline number always runs every row.
+// cls_only (image tower, LAST block, option cls_only_last_block, the product default since round 6): only the class token's row of every
+// sequence leaves the tower (clip/model.py:419: ln_post(x[:, 0, :])), so the last block computes what that row needs and nothing else:
+//   0  the in-projection's K | V thirds for every token (every token is a key) -- the same GEMM on weight rows D .. 3D -- and its Q third for
+//      the n_seq class rows (M = n_seq, row stride L * D, LayerNorm statistics read with the same stride);
+//   1  attention of ONE query per (sequence, head) against every key (attention_cls.hip);
+//   2..4  out-proj, c_fc, c_proj and their LayerNorms on the class rows: the same GEMMs with M = n_seq and row stride L * D.
+// Same arithmetic per element as the every-row block; of a 12-layer tower's 35.1 GFLOP per image 2.6 are never issued.  bench.py's headline
+// `value` runs every row of every block (option 0) and reports this path as `value_cls_only`.
 int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, int n_seq, int L, int D, int causal, bool folded,
                    int* parts, hipStream_t s, bool f16res, bool cls_only = false) {
   const int H = D / 64;
@@ -201,7 +204,7 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
   int rc;
   GemmArgs a{};
   switch (step) {
-    case 0:
+    case 0: {
       if (!folded) {
         if ((rc = launch_layernorm(w.xres, CLIPMI_F32, D, nullptr, b.ln1_g, b.ln1_b, w.xn, CLIPMI_F16, D, M, D, 1e-5f, s))) return rc;
         a.W = (const half_t*)b.w_qkv; a.bias = b.b_qkv;
@@ -212,8 +215,17 @@ int run_block_step(int step, const clipmi_block_weights& b, const TowerWs& w, in
       }
       a.A = w.xn; a.lda = D; a.ldw = D; a.out = w.qkv; a.ldo = 3 * D;
       a.out_dtype = CLIPMI_F16; a.M = M; a.N = 3 * D; a.K = D; a.epilogue = CLIPMI_EPI_BIAS;
-      return launch_gemm(a, s);
+      if (!cls_only) return launch_gemm(a, s);
+      GemmArgs q = a;                                  // Q third, class rows: q | k | v row n * L of the packed buffer, columns 0 .. D
+      q.lda = (int64_t)L * D; q.ldo = (int64_t)L * 3 * D; q.M = n_seq; q.N = D; q.ln_rows = nullptr;
+      q.ln_plane = Mfull; q.ln_row_stride = L;         // the producer wrote one statistics row per token row
+      a.W += (int64_t)D * D; a.bias += D; a.out = w.qkv + D; a.N = 2 * D;   // K | V thirds, every row
+      if (a.ln_g) a.ln_g += D;
+      if ((rc = launch_gemm(a, s))) return rc;
+      return launch_gemm(q, s);
+    }
     case 1:
+      if (cls_only && !causal) return launch_attention_cls(w.qkv, w.att, n_seq, L, H, s);
       return launch_attention(w.qkv, w.att, n_seq, L, H, causal, s);
     case 2:
       a.A = w.att; a.lda = rowD; a.W = (const half_t*)b.w_out; a.ldw = D; a.bias = b.b_out; a.residual = w.xres; a.out = w.xres;

@@ -142,8 +142,8 @@ struct Options {
                                         // kernel goes to the tile kernels as a second launch (gemm.hip launch_one); 0 = one launch
   std::atomic<int> gemm_rstream{1};    // CLIPMI_GEMM_RSTREAM: 1 (default) = persistent row-range kernel with streamed residual epilogue for the fp16-stream
                                        // residual GEMMs with K <= 1536 (out-proj); 0 = one 320 x 256 tile per workgroup (the same fp32 sum, added in another order)
-  std::atomic<int> cls_only_last_block{0};   // CLIPMI_CLS_ONLY_LAST_BLOCK: 1 = the image tower's last block runs out-proj / MLP on the class rows only
-                                             // (identical features; not the default: the headline benchmark computes every row)
+  std::atomic<int> cls_only_last_block{1};   // CLIPMI_CLS_ONLY_LAST_BLOCK: 1 (default since round 6) = the image tower's last block computes K | V of every
+                                             // token and everything else for the class rows only (run_block_step); 0 = every row (bench.py's headline `value`)
   std::atomic<int> ln_fold{1};         // CLIPMI_LN_FOLD
   std::atomic<int> residual_f16{2};    // CLIPMI_RESIDUAL_F16: 0 fp32 everywhere | 1 both towers | 2 image tower only (default, 'v') | 3 text tower only ('t')
   std::atomic<int> attn_loader{2};     // CLIPMI_ATTN_LOADER, 193..200-token non-causal attention: 2 (default) = attention_vision_nt_kernel (all operands by LDS-DMA
@@ -219,6 +219,9 @@ struct GemmArgs {
   //   stats_out and report the number of partials per row (= its n-tile count) through *parts_out (host pointer)
   const float* ln_stats; int ln_parts; const float* ln_g; int ln_dim; float ln_eps;
   float* ln_rows = nullptr;   // consumer, optional scratch [M][2] fp32: lets the streamed-epilogue kernel reduce the partials once per GEMM
+  // consumer over a strided subset of the producer's rows (the class rows of the last image block): statistics row of GEMM row m =
+  // ln_stats[p * ln_plane + m * ln_row_stride]; ln_plane 0 = M rows per partial plane
+  int64_t ln_plane = 0; int ln_row_stride = 1;
   half_t* x16; float* stats_out; int* parts_out;
   bool residual_f16 = false;   // producer: the residual operand is x16 itself (fp16 stream, updated in place); `residual`/`out` unused
 };
@@ -232,6 +235,8 @@ int launch_layernorm(const void* x, int x_dtype, int64_t in_stride, const int32_
 // n*L + first + j, j < n_ctx.  M = N*L is the partial stride.
 int launch_row_stats(const float* x, half_t* x16, float* stats, int parts, int N, int L, int D, int first, int n_ctx, hipStream_t s);
 int launch_attention(const half_t* qkv, half_t* out, int N, int L, int H, int causal, hipStream_t s);
+// attention_cls.hip: the output row of token 0 of every sequence only (the image tower's last block: clip/model.py:419 reads nothing else)
+int launch_attention_cls(const half_t* qkv, half_t* out, int N, int L, int H, hipStream_t s);
 int launch_patchify(const void* image, int image_dtype, half_t* col, int B, int R, int P, int Kpad, hipStream_t s);
 // patch_embed.hip: conv1 as a GEMM whose loader reads the (fp16) NCHW image directly (+ pos, token-row scatter) and ln_pre over every token row with the
 // class / shallow-prompt rows formed on the fly   (clip/model.py:394-402,413)

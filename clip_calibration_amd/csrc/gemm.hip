@@ -51,7 +51,7 @@ __device__ __forceinline__ void ln_row_params(const KArgs& a, int m, float& rstd
   const int mm = m < a.M ? m : a.M - 1;
   double s = 0.0, ss = 0.0;
   for (int p = 0; p < a.ln_parts; ++p) {
-    const float2 st = *reinterpret_cast<const float2*>(a.ln_stats + 2 * ((int64_t)p * a.ln_M + mm));
+    const float2 st = *reinterpret_cast<const float2*>(a.ln_stats + 2 * ((int64_t)p * a.ln_M + (int64_t)mm * a.ln_rs));
     s += (double)st.x;
     ss += (double)st.y;
   }
@@ -72,30 +72,58 @@ struct Tile {
   static_assert((NT / 8) % 16 == 0, "staging swizzle assumes NT/8 rows per instruction is a multiple of 16");
 };
 
-// x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): one v_exp_f32 + one v_rcp_f32 (1 ulp) instead of the IEEE division sequence
-__device__ __forceinline__ float quick_gelu(float t) {
-  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * t));
-}
-// The same on the SCALED pre-activation z = k x, k = 1.702 log2(e) (round 6): the epilogues of the fp16-out GEMMs form z straight from the
-// accumulator -- the scale rides in the row / column terms they multiply and add anyway --, so the separate product k x goes away, and
-// x / (1 + 2^-z) = z / (k + k 2^-z): exp2 with a free source negation, ONE fused multiply-add for the denominator, the reciprocal, the product.
-// Per element 4 + (c, z) instead of 5 + (c, v) vector instructions (profiles/r06_epilogue_diet.txt).  z -> +inf: 2^-z = 0, z / k = x; z -> -inf:
-// 2^-z = inf, rcp = 0, z * 0 = -0.
+// QuickGELU (clip/model.py:162-164): x * sigmoid(1.702 x) = x / (1 + 2^(-k x)), k = 1.702 log2(e): one v_exp_f32 + one v_rcp_f32 (1 ulp) instead of
+// the IEEE division sequence.  Round 6: the activation is taken of the pre-activation ROUNDED TO fp16 -- the reference's own fp16 path has exactly this
+// rounding point (clip/model.py:174-177: c_fc's output is an fp16 tensor before QuickGELU reads it) -- which lets gemm_stream_kernel keep a tile's
+// pre-activations as 64 fp16 registers and apply the activation inside the NEXT tile's K loop, two registers per 16-MFMA compute part, where the vector
+// pipe has nothing else to do (profiles/r06_gelu_in_compute_part.txt).  Every kernel goes through gelu_preact / quick_gelu_h (or, in that K loop, the
+// same five operations as single instructions: gelu_uop): the same bits wherever the activation is applied.
+//   t = -k h (one rounding); e = 2^t; d = 1 + e; r = 1 / d; out = fp16(h r)      h -> +big: e = 0, out = h; h -> -big: e = inf, r = 0, out = -0
 constexpr float GELU_K = 2.4554669595930157f;
-__device__ __forceinline__ f32x4 quick_gelu_scaled(const f32x4& z) {
-  f32x4 d, o;
+// v = acc * rstd + (bias - mean rstd g), explicit fused multiply-adds
+__device__ __forceinline__ f16x4 gelu_preact(const f32x4& acc, float rs, float mrs, const f32x4& bias, const f32x4& g) {
+  f32x4 v;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) d[q] = __builtin_fmaf(__builtin_amdgcn_exp2f(-z[q]), GELU_K, GELU_K);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) o[q] = z[q] * __builtin_amdgcn_rcpf(d[q]);
-  return o;
+  for (int q = 0; q < 4; ++q) v[q] = __builtin_fmaf(acc[q], rs, __builtin_fmaf(-mrs, g[q], bias[q]));
+  return f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
 }
-// z = acc * (k rstd) + (k bias - (k mean rstd) g), explicit fused multiply-adds: the same bits in every kernel that inlines it
-__device__ __forceinline__ f32x4 gelu_preact_scaled(const f32x4& acc, float rs_k, float mrs_k, const f32x4& bias_k, const f32x4& g) {
-  f32x4 z;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) z[q] = __builtin_fmaf(acc[q], rs_k, __builtin_fmaf(-mrs_k, g[q], bias_k[q]));
-  return z;
+__device__ __forceinline__ float quick_gelu_h1(half_t h) {
+  const float z = (float)h;
+  const float t = z * -GELU_K;
+  const float d = 1.0f + __builtin_amdgcn_exp2f(t);
+  return z * __builtin_amdgcn_rcpf(d);
+}
+__device__ __forceinline__ f16x4 quick_gelu_h(const f16x4& h) {
+  return f16x4{(half_t)quick_gelu_h1(h[0]), (half_t)quick_gelu_h1(h[1]), (half_t)quick_gelu_h1(h[2]), (half_t)quick_gelu_h1(h[3])};
+}
+// fp32 outputs (OUT_F32 callers: tests, fp32 hidden activations): nothing is rounded on the way
+__device__ __forceinline__ float quick_gelu(float z) {
+  return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -GELU_K));
+}
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// One instruction of the activation of ONE packed register w = (h_lo, h_hi) -> (out_lo, out_hi), Q = 0 .. 10 in order; tl / th are its two
+// temporaries.  gemm_stream_kernel places them between the MFMAs of a compute part (asm volatile: they stay where they are written), two registers
+// interleaved so that no instruction reads the result of the one in front of it.
+// MFMA with the accumulator tied to the destination (see gemm_stream_kernel); a function template, not a generic lambda: clang does not implicitly
+// capture a variable that a generic lambda names only as an asm operand
+template <bool ZERO>
+__device__ __forceinline__ void mfma_tied(f32x4& acc, const f16x8& w, const f16x8& x) {
+  if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+}
+template <int Q, int E>
+__device__ __forceinline__ void gelu_uop(u32x4_t& w4, float& tl, float& th, float neg_k) {   // w = element E of w4
+  if constexpr (Q == 0) asm volatile("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(tl) : "v"(w4[E]), "s"(neg_k));
+  if constexpr (Q == 1) asm volatile("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(th) : "v"(w4[E]), "s"(neg_k));
+  if constexpr (Q == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(tl));
+  if constexpr (Q == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(th));
+  if constexpr (Q == 4) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(tl));
+  if constexpr (Q == 5) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(th));
+  if constexpr (Q == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(tl));
+  if constexpr (Q == 7) asm volatile("v_rcp_f32 %0, %0" : "+v"(th));
+  if constexpr (Q == 8) asm volatile("v_fma_mix_f32 %0, %1, %0, 0 op_sel_hi:[1,0,0]" : "+v"(tl) : "v"(w4[E]));
+  if constexpr (Q == 9) asm volatile("v_fma_mix_f32 %0, %1, %0, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(th) : "v"(w4[E]));
+  if constexpr (Q == 10) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w4[E]) : "v"(tl), "v"(th));
 }
 
 // Tile traversal.  blockIdx % 8 labels the XCD (blocks are dealt round-robin over the 8 XCDs); each label gets a
@@ -166,7 +194,8 @@ __device__ __forceinline__ void epilogue_f16_staged(f32x4 (&acc)[T::TN][T::TM], 
           const int i = h * 4 + ii;
           f32x4 v;
           if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
-            v = quick_gelu_scaled(gelu_preact_scaled(acc[i][jc * CH + jj], rs * GELU_K, mrs * GELU_K, bias[i] * GELU_K, lng[i]));
+            const f16x4 o = quick_gelu_h(gelu_preact(acc[i][jc * CH + jj], rs, mrs, bias[i], lng[i]));
+            v = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};   // (exact: rounded again below without change)
           } else {
             v = acc[i][jc * CH + jj] * rs + (bias[i] - mrs * lng[i]);
           }
@@ -521,7 +550,13 @@ __device__ __forceinline__ void epilogue_direct(f32x4 (&acc)[T::TN][T::TM], cons
       if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
         const f32x4 g = a.ln_stats ? *reinterpret_cast<const f32x4*>(a.ln_g + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        v = quick_gelu_scaled(gelu_preact_scaled(v, rs * GELU_K, mrs * GELU_K, b * GELU_K, g));
+        if constexpr (OUT_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(__builtin_fmaf(v[e], rs, __builtin_fmaf(-mrs, g[e], b[e])));
+        } else {
+          const f16x4 o = quick_gelu_h(gelu_preact(v, rs, mrs, b, g));
+          v = f32x4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        }
       }
       if constexpr (EPI == CLIPMI_EPI_BIAS_RESIDUAL || EPI == CLIPMI_EPI_BIAS_RELU || EPI == CLIPMI_EPI_BIAS_RESIDUAL16_RELU) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -798,6 +833,26 @@ inline bool stream_raw_ok(const KArgs& k) { return k.ln_parts <= STREAM_RAW_PART
 // d = 1 has no 32-bit multiplier.  Two scalar instructions instead of the ~25 of a division by a run-time divisor -- and none of its vector ones
 __device__ __forceinline__ int div_magic(int n, int d, uint32_t mg) { return d == 1 ? n : (int)__umulhi((uint32_t)n, mg); }
 
+// Where the held slices of the previous tile get their activation (QuickGELU) and leave, by K-step index (0 .. 6; STREAM_LAST = the tile's last
+// K-step, whatever its number).  The activation is a stream of 64 registers x 11 instructions (gelu_uop; two registers interleaved) dealt out over
+// the MFMA slots of K-steps 0 .. 6 and of the last one, 11 instructions per 8 MFMAs: slice g is complete at the end of K-step g (the last K-step:
+// g = 7) and leaves in phase 3 of the K-step behind it -- K-steps 1 .. 6, the last K-step (g = 6), right behind the loop (g = 7).
+// Measured on c_fc of ViT-B/16 (profiles/r06_gelu_in_compute_part.txt): the 704 instructions cost the K loop ~1.6 us per tile (2.2 cycles each: three
+// quarters of their stand-alone time are hidden) against 3.2 us of the tile change they leave.  A second schedule for K >= 12 K-steps -- one
+// instruction per MFMA over K-steps 0 .. 10, every slice stored inside the loop -- measured the same within 0.3 % (c_fc 222.6 against 223.2 us in an
+// interleaved A/B) and cost 256 registers and a scratch slot: not kept.
+constexpr int STREAM_LAST = 100;
+constexpr int GELU_OPS = 64 * 11;
+template <bool GELU>
+constexpr int stream_store_slice(int ksi, int nheld) {
+  if (!GELU) return (ksi >= 1 && ksi <= 6 && ksi - 1 < nheld) ? ksi - 1 : -1;
+  return (ksi >= 1 && ksi <= 6) ? ksi - 1 : (ksi == STREAM_LAST ? 6 : -1);
+}
+constexpr int stream_gelu_op(int slot) {   // first instruction of the activation stream that MFMA slot `slot` of the K loop carries
+  const int n = slot * 11 / 8;
+  return n < GELU_OPS ? n : GELU_OPS;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
   using T = TStream;
@@ -934,8 +989,14 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   // per K-step inside the next tile's K loop (K-steps 1 .. TM - HD).  Holding all eight slices (the first version) left 24
   // registers for operand fragments: every 16-MFMA block then opened with an un-hidden LDS round trip (ds_read x 6,
   // s_waitcnt lgkmcnt(1)) and the loop ran at 48 % of the matrix rate at 2.3 GHz (in-kernel clock stamps, tools/gemm_stamps.py).
-  constexpr int HD = CLIPMI_STREAM_HD, NHELD = TM - HD;
-  static_assert(NHELD >= 1 && NHELD <= 6, "K-steps 1 .. NHELD carry the held slices");
+  // QuickGELU (round 6): ALL eight slices are held, as fp16 PRE-activations, and get their activation between the MFMAs of the next tile's compute
+  // parts (stream_gelu_op / stream_store_slice above).  What the tile change still has to do per element is the fold and a conversion (3
+  // instructions) instead of those and the activation (8.5): 4.6 -> 1.4 us per c_fc tile with nothing else running on the CU.
+  constexpr bool GELU = EPI == CLIPMI_EPI_BIAS_QUICKGELU;
+  constexpr int HD = GELU ? 0 : CLIPMI_STREAM_HD, NHELD = TM - HD;
+  static_assert(GELU ? NHELD == 8 : (NHELD >= 1 && NHELD <= 6), "K-steps 1 .. 6 carry held slices; QuickGELU: two more behind them");
+  const float neg_k = -GELU_K;
+  float ga_l, ga_h, gb_l, gb_h;   // the two temporaries of each of the two registers the activation stream is working on
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 held[2][NHELD];
@@ -1006,8 +1067,11 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
   // The fragment registers are single-buffered: a wave overwrites them in its load part, after its MFMAs of the previous
   // compute part have been issued.
   const int grp = wave >> 2;   // uniform
-  auto kstep = [&](auto slice_tag, auto first_tag, auto more_tag, int kt, int knext, int nxo, int nwo) {
-    constexpr int SLICE = decltype(slice_tag)::value;
+  auto kstep = [&](auto ksi_tag, auto first_tag, auto more_tag, int kt, int knext, int nxo, int nwo) {
+    constexpr int KSI = decltype(ksi_tag)::value;         // K-step index 0 .. 10, STREAM_LAST, or -1 (a K-step of the run-time loop: carries nothing)
+    constexpr int SLICE = KSI < 0 ? -1 : stream_store_slice<GELU>(KSI, NHELD);   // held slice stored in phase 3 (-1: none)
+    // first MFMA slot of this K-step in the activation stream (-1: none)
+    constexpr int GSLOT = !GELU || KSI < 0 ? -1 : (KSI == STREAM_LAST ? 7 * 64 : KSI * 64);
     constexpr bool FIRSTK = decltype(first_tag)::value;   // the accumulators start at 0
     constexpr bool MORE = decltype(more_tag)::value;      // a stage is DMA'd during this K-step: K-step knext of the tile at (nxo, nwo)
     constexpr int NST = (SLICE >= 0 && !(CLIPMI_ABLATE & 1)) ? SPS : 0;   // stores issued behind this K-step's DMA pieces
@@ -1068,15 +1132,39 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         // the first k-half to 64 fresh registers and brings them back in the second (v_mfma v[192:195], .., v[12:15] ...), which
         // this kernel does not have -- it spilled the held outputs to scratch.  Back-to-back MFMAs on different accumulators, or
         // accumulating in place, need no wait states; nothing but MFMAs reads an accumulator before the tile's epilogue.
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            if constexpr (FIRSTK && KS == 0)
-              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[i][JH * 4 + j]) : "v"(wf[i]), "v"(xf[j]));
-            else
-              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][JH * 4 + j]) : "v"(wf[i]), "v"(xf[j]));
-          }
+        auto mfma = [&](auto m_tag) {
+          constexpr int M = decltype(m_tag)::value, j = M >> 2, i = M & 3;
+          mfma_tied<(FIRSTK && KS == 0)>(acc[i][JH * 4 + j], wf[i], xf[j]);
+        };
+        if constexpr (GSLOT >= 0) {
+          // instruction n of the stream: register pair n / 22, registers 2 k (even n) and 2 k + 1 (odd n) alternate, step (n % 22) / 2
+          auto uop = [&](auto n_tag) {
+            constexpr int N = decltype(n_tag)::value, W = N % 22, R = 2 * (N / 22) + (W & 1), Q = W >> 1;
+            if constexpr (W & 1) gelu_uop<Q, R % 4>(held[(R % 8) / 4][R / 8], gb_l, gb_h, neg_k);
+            else gelu_uop<Q, R % 4>(held[(R % 8) / 4][R / 8], ga_l, ga_h, neg_k);
+          };
+          auto group = [&](auto m_tag) {
+            constexpr int M = decltype(m_tag)::value;
+            mfma(m_tag);
+            constexpr int S0 = stream_gelu_op(GSLOT + P * 16 + M), S1 = stream_gelu_op(GSLOT + P * 16 + M + 1);
+            static_assert(S1 - S0 <= 2, "at most two instructions of the activation behind an MFMA");
+            if constexpr (S1 - S0 >= 1) uop(std::integral_constant<int, S0>{});
+            if constexpr (S1 - S0 == 2) uop(std::integral_constant<int, S0 + 1>{});
+          };
+          group(std::integral_constant<int, 0>{});  group(std::integral_constant<int, 1>{});  group(std::integral_constant<int, 2>{});
+          group(std::integral_constant<int, 3>{});  group(std::integral_constant<int, 4>{});  group(std::integral_constant<int, 5>{});
+          group(std::integral_constant<int, 6>{});  group(std::integral_constant<int, 7>{});  group(std::integral_constant<int, 8>{});
+          group(std::integral_constant<int, 9>{});  group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+          group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{});
+          group(std::integral_constant<int, 15>{});
+        } else {
+          mfma(std::integral_constant<int, 0>{});  mfma(std::integral_constant<int, 1>{});  mfma(std::integral_constant<int, 2>{});
+          mfma(std::integral_constant<int, 3>{});  mfma(std::integral_constant<int, 4>{});  mfma(std::integral_constant<int, 5>{});
+          mfma(std::integral_constant<int, 6>{});  mfma(std::integral_constant<int, 7>{});  mfma(std::integral_constant<int, 8>{});
+          mfma(std::integral_constant<int, 9>{});  mfma(std::integral_constant<int, 10>{}); mfma(std::integral_constant<int, 11>{});
+          mfma(std::integral_constant<int, 12>{}); mfma(std::integral_constant<int, 13>{}); mfma(std::integral_constant<int, 14>{});
+          mfma(std::integral_constant<int, 15>{});
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (P == 3) {
@@ -1107,8 +1195,11 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     // RAW mode: the tile's row partials have landed (behind the last K-step of the previous tile): thread t owns row t, reduces its partials
     // with the arithmetic of ln_row_params and leaves (rstd, mean * rstd) in slot 0 of the table, in place.  Read in the epilogue, a
     // whole K loop of workgroup barriers later.  Rows past M hold other rows' numbers and are never stored.
-    if (raw && tid < BM) {
-      float2* rp = reinterpret_cast<float2*>(smem + LNP_OFF + par * LNP_PAR) + tid;
+    if (raw && wave < BM / 64) {
+      int row = lane;
+      asm volatile("" : "+v"(row));   // rebuilt per tile: as a loop invariant the table address cost a VGPR the K loop does not have (it went to scratch)
+      row += wave * 64;
+      float2* rp = reinterpret_cast<float2*>(smem + LNP_OFF + par * LNP_PAR) + row;
       double ps = 0.0, pss = 0.0;
       for (int p = 0; p < a.ln_parts; ++p) {
         const float2 st = rp[p * BM];
@@ -1123,19 +1214,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     constexpr std::true_type yes{};
     using I = std::integral_constant<int, -1>;
     if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 starts one part later
-    kstep(I{}, yes, yes, 0, 1, txo, two);
+    kstep(std::integral_constant<int, 0>{}, yes, yes, 0, 1, txo, two);
 #ifdef CLIPMI_TUNING
     if (stamp) {
       a.stamps[vb * 8 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
       a.stamps[vb * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
     }
 #endif
-    kstep(std::integral_constant<int, 0 < NHELD ? 0 : -1>{}, no, yes, 1, 2, txo, two);   // K-steps 1 .. NHELD carry the held slices
-    kstep(std::integral_constant<int, 1 < NHELD ? 1 : -1>{}, no, yes, 2, 3, txo, two);
-    kstep(std::integral_constant<int, 2 < NHELD ? 2 : -1>{}, no, yes, 3, 4, txo, two);
-    kstep(std::integral_constant<int, 3 < NHELD ? 3 : -1>{}, no, yes, 4, 5, txo, two);
-    kstep(std::integral_constant<int, 4 < NHELD ? 4 : -1>{}, no, yes, 5, 6, txo, two);
-    kstep(std::integral_constant<int, 5 < NHELD ? 5 : -1>{}, no, yes, 6, 7, txo, two);
+    kstep(std::integral_constant<int, 1>{}, no, yes, 1, 2, txo, two);
+    kstep(std::integral_constant<int, 2>{}, no, yes, 2, 3, txo, two);
+    kstep(std::integral_constant<int, 3>{}, no, yes, 3, 4, txo, two);
+    kstep(std::integral_constant<int, 4>{}, no, yes, 4, 5, txo, two);
+    kstep(std::integral_constant<int, 5>{}, no, yes, 5, 6, txo, two);
+    kstep(std::integral_constant<int, 6>{}, no, yes, 6, 7, txo, two);
     for (int kt = 7; kt < nk - 1; ++kt) kstep(I{}, no, yes, kt, kt + 1, txo, two);   // K >= 8 K-steps (checked by the launcher)
 
     // ---- the next tile, before this one's last K-step: its first stage and its parameters are DMA'd during that K-step.  Nothing left to
@@ -1153,9 +1244,13 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       two = n0 * (int)a.ldw * 2;
       params(m0, n0, par ^ 1);
     }
-    kstep(I{}, no, yes, nk - 1, 0, txo, two);
+    kstep(std::integral_constant<int, STREAM_LAST>{}, no, yes, nk - 1, 0, txo, two);
     if (grp == 0) __builtin_amdgcn_s_barrier();   // ... and group 0 waits out group 1's last compute part
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the asm MFMAs' results are read by compiler-scheduled VALU code from here on
+    if constexpr (GELU) {   // the last held slice of the PREVIOUS tile got its activation a moment ago
+      store_piece(7, 0, held[0][7]);
+      store_piece(7, 1, held[1][7]);
+    }
     first_buf = ((first_buf + nk - 1) & 1) ^ 1;         // where the next tile's first stage has just landed
 #ifdef CLIPMI_TUNING
     if (stamp) {
@@ -1175,32 +1270,35 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
       const float2* lnp = reinterpret_cast<const float2*>(smem + LNP_OFF + par * LNP_PAR);
       const float* colp = reinterpret_cast<const float*>(smem + COLP_OFF) + par * 2 * BN;
       f32x4 bb[TN], gg[TN];
-      float2 pr[TM];
+      // the row pairs: all eight up front, or -- QuickGELU, whose 64 held registers leave no room for them -- one slice ahead of their use
+      constexpr int NPR = GELU ? 2 : TM;
+      float2 pr[NPR];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int nl = wave_n * 64 + eg4 * 4 + i * 16;
         bb[i] = *reinterpret_cast<const f32x4*>(colp + nl);
         gg[i] = *reinterpret_cast<const f32x4*>(colp + BN + nl);
-        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) bb[i] = bb[i] * GELU_K;   // the scaled pre-activation: see quick_gelu_scaled
       }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        pr[j] = lnp[wave_m * T::WTM + j * 16 + er16];
-        if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) pr[j] = make_float2(pr[j].x * GELU_K, pr[j].y * GELU_K);
-      }
+      for (int j = 0; j < (GELU ? 1 : TM); ++j) pr[j] = lnp[wave_m * T::WTM + j * 16 + er16];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
 #ifdef CLIPMI_TUNING
         if (a.knob & 8) break;
 #endif
-        const float rs = pr[j].x, mrs = pr[j].y;
+        if constexpr (GELU) {
+          if (j + 1 < TM) pr[(j + 1) & 1] = lnp[wave_m * T::WTM + (j + 1) * 16 + er16];
+        }
+        const float rs = pr[GELU ? (j & 1) : j].x, mrs = pr[GELU ? (j & 1) : j].y;
         f16x4 cv[TN];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          f32x4 v;
-          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) v = quick_gelu_scaled(gelu_preact_scaled(acc[i][j], rs, mrs, bb[i], gg[i]));
-          else v = acc[i][j] * rs + (bb[i] - mrs * gg[i]);
-          cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          if constexpr (EPI == CLIPMI_EPI_BIAS_QUICKGELU) {
+            cv[i] = gelu_preact(acc[i][j], rs, mrs, bb[i], gg[i]);   // held as it is: the activation follows inside the next K loop
+          } else {
+            const f32x4 v = acc[i][j] * rs + (bb[i] - mrs * gg[i]);
+            cv[i] = f16x4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          }
         }
         u32x4 pk[2];
         pack_slice(cv, pk);
@@ -1220,9 +1318,18 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #endif
     if (!has_next) break;
   }
-  // the last tile's held slices: nothing left to hide them behind
+  // the last tile's held slices: nothing left to hide them behind (QuickGELU: nor their activation)
 #pragma unroll
   for (int j = 0; j < NHELD; ++j) {
+    if constexpr (GELU) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const f16x4 lo = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][0], held[p][j][1]}));
+        const f16x4 hi = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][2], held[p][j][3]}));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        held[p][j] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+      }
+    }
     store_piece(HD + j, 0, held[0][j]);
     store_piece(HD + j, 1, held[1][j]);
   }
@@ -1696,7 +1803,7 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 8 K-steps: the streamed-epilogue persistent kernel
   // (the cost model only ranks the one-tile-per-workgroup kernels)
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-    const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) &&
+    const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) && k.ln_rs == 1 &&
                       stream_offsets_ok(k) && stream_whole_matrix_ok(k);
     const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
     if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) {
@@ -1766,7 +1873,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
   k.pos = a.pos; k.patches = a.patches; k.tokens = a.tokens;
   k.im_R = a.im_R; k.im_P = a.im_P; k.im_G = a.im_P > 0 ? a.im_R / a.im_P : 0;
   k.ln_stats = a.ln_stats; k.ln_parts = a.ln_parts; k.ln_g = a.ln_g; k.ln_inv_d = a.ln_dim > 0 ? 1.0f / (float)a.ln_dim : 0.f;
-  k.ln_eps = a.ln_eps; k.ln_M = a.M; k.x16 = a.x16; k.stats_out = a.stats_out;
+  k.ln_eps = a.ln_eps; k.ln_M = a.ln_plane > 0 ? (int)a.ln_plane : a.M; k.ln_rs = a.ln_row_stride; k.x16 = a.x16; k.stats_out = a.stats_out;
+  CLIPMI_REQUIRE(a.ln_row_stride >= 1 && a.ln_plane >= 0 && a.ln_plane < (1ll << 31), CLIPMI_ERR_ARG, "gemm: bad LayerNorm statistics stride");
 #ifdef CLIPMI_TUNING
   k.stamps = g_tuning_stamps.load(std::memory_order_relaxed);   // clipmi_tuning_set_stamps (tools/gemm_stamps.py), tuning build only
   k.knob = g_tuning_knob.load(std::memory_order_relaxed);

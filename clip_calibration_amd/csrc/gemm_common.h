@@ -36,6 +36,7 @@ struct KArgs {
   int per_band; uint32_t mg_per_band, mg_band, mg_gw_last;   // gemm_stream_kernel: tiles per band and the multipliers of its divisions (launch_stream)
   const float* ln_stats; int ln_parts; const float* ln_g; float ln_inv_d; float ln_eps;
   int ln_M;      // rows per partial plane of ln_stats ([parts][ln_M] float2): the producer's M -- not this launch's, when a launch covers a row range of it
+  int ln_rs;     // statistics rows per GEMM row (1; L for the class rows of a token-major buffer): tile kernels only
   half_t* x16; float* stats_out;
 #ifdef CLIPMI_TUNING
   long long* stamps;   // diagnostic build only (make tuning, tools/gemm_stamps.py): per-workgroup s_memrealtime stamps

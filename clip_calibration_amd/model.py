@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -533,8 +534,9 @@ class CLIP(nn.Module):
         """Token rows per prompt the text tower has to compute for this set of tokenised prompts: the blocks mask causally
         (clip/model.py:585-591) and only the EOT row = ``argmax(ids)`` leaves the tower (clip/model.py:611, coop.py:65), so nothing behind the
         last prompt's EOT can reach an output.  ``max(EOT) + 1`` rounded up to a multiple of 8 (few distinct shapes), at least the prompt
-        tokens 1..n_ctx a hook overwrites, at most the context.  Costs one read-back of a scalar per NEW prompt set: the answer is kept with
-        the tensor it was computed for (which keeps that storage -- and so the key -- alive) and re-used while its version counter stands.
+        tokens 1..n_ctx a hook overwrites, at most the context.  Costs one read-back of a scalar per NEW prompt set: the integer is kept under
+        the tensor's (storage, version, shape) with a WEAK reference to the tensor -- while that tensor lives its storage cannot be anybody else's --
+        and re-used while its version counter stands.  Tensors made under ``torch.inference_mode()`` have no version counter: computed per call.
         (Contract: token ids edited IN PLACE through ``tensor.data`` or another route that bypasses autograd's version counter are not seen;
         pass a new tensor, or set ``text_dead_row_elimination = False``.  An EOT index at or beyond the bound is clamped by the library, as an
         index at or beyond the context always was.)"""
@@ -542,16 +544,25 @@ class CLIP(nn.Module):
         if not self.text_dead_row_elimination:
             return L
         t = tokenized_prompts
-        key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.device))
-        with self._copies_lock:                      # (nn.DataParallel's clones ask the owner from their threads)
-            hit = self._live_rows.pop(key, None)
+        try:
+            version = t._version
+        except RuntimeError:                         # a tensor made under torch.inference_mode() has no version counter: nothing to key a cached
+            version = None                           # answer on -- the bound is computed per call (one scalar read-back)
+        key = (t.data_ptr(), version, tuple(t.shape), tuple(t.stride()), str(t.device))
+        hit = None
+        if version is not None:
+            with self._copies_lock:                  # (nn.DataParallel's clones ask the owner from their threads)
+                hit = self._live_rows.pop(key, None)
+            if hit is not None and hit[0]() is None:     # the tensor the entry was made for is gone: its storage may have been handed to another one
+                hit = None
         if hit is None:
             last = int(t.reshape(-1, t.shape[-1]).argmax(dim=-1).max()) if t.numel() else 0
-            hit = (t, min(L, max((last + 1 + 7) // 8 * 8, 1 + int(n_ctx))))
-        with self._copies_lock:
-            self._live_rows[key] = hit               # (re-inserted last: the dict is the LRU order)
-            while len(self._live_rows) > 16:
-                self._live_rows.pop(next(iter(self._live_rows)))
+            hit = (weakref.ref(t), min(L, max((last + 1 + 7) // 8 * 8, 1)))
+        if version is not None:
+            with self._copies_lock:
+                self._live_rows[key] = hit           # (re-inserted last: the dict is the LRU order); only the integer and a weak reference are kept
+                while len(self._live_rows) > 16:
+                    self._live_rows.pop(next(iter(self._live_rows)))
         return max(hit[1], min(L, 1 + int(n_ctx)))
 
     def text_encoder_f32(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor,

@@ -91,9 +91,11 @@ const char* clipmi_last_error(void);
  *                                             dependence (tile and kernel choice follow the row count: <= 2e-4 on normalised features),
  *                                             +8..10 % images/s at 512-1024 images of ViT-B/16; 0 = never split
  * and the process-wide DEFAULTS of the three per-model settings (clipmi_model_set_option overrides them per handle):
- *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  0 (default) = every block computes every token row; 1 = the image tower's LAST block
- *                    runs out-proj, c_fc, c_proj (and ln_2) on the class rows only -- the rows ln_post reads (clip/model.py:419) -- as
- *                    GEMMs with M = batch and row stride L * D; same per-element arithmetic, features equal to 2e-7 in cosine
+ *   cls_only_last_block (CLIPMI_CLS_ONLY_LAST_BLOCK)  1 (default since round 6) = the image tower's LAST block computes what the class row
+ *                    needs and nothing else -- K | V of every token, Q / attention / out-proj / ln_2 / c_fc / c_proj of the class rows, the only
+ *                    rows ln_post reads (clip/model.py:419) -- as GEMMs with M = batch and row stride L * D and a one-query attention kernel;
+ *                    same per-element arithmetic, features equal to the every-row computation to ~1e-6 in cosine, 7 % fewer flops per image of
+ *                    ViT-B/16; 0 = every block computes every token row (what bench.py's headline `value` times)
  *   ln_fold          (CLIPMI_LN_FOLD)         1 = ln_1 / ln_2 inside the GEMM epilogues (default), 0 = LayerNorm kernels
  *   residual_f16     (CLIPMI_RESIDUAL_F16)    0 = fp32 residual stream, 1 = fp16 on both towers, 2 = image tower only
  *                                             (default; env 'v'), 3 = text tower only (env 't') */
@@ -415,7 +417,9 @@ int clipmi_text_blocks(clipmi_model* m, const void* x, void* y, int dtype, int n
  * their [C,L,..] layout; rows >= seq_rows are never read): identical features, L / seq_rows times fewer rows through every GEMM
  * ("X X X X a photo of a <name>." ends at token ~22 of 77).  The CALLER guarantees max(eot) < seq_rows -- it holds the tokenised prompts on the
  * host side and computes the bound once, without a per-call device sync -- and 1 + hook->n_ctx <= seq_rows; an EOT index outside is clamped
- * to seq_rows - 1 as it is to L - 1 today.  seq_rows <= 0 or >= L: the whole context. */
+ * to seq_rows - 1 as it is to L - 1 today.  A VIOLATION IS NOT DETECTED: with a bound that is too small the call returns CLIPMI_OK and the
+ * features of token row seq_rows - 1 for every prompt whose EOT lies behind it (the EOT indices live on the device; checking them would cost the
+ * sync this argument exists to avoid).  Callers that cannot vouch for the bound pass 0.  seq_rows <= 0 or >= L: the whole context. */
 int clipmi_text_encoder(clipmi_model* m, const void* prompts, int dtype, const int32_t* eot, int n_prompts, int seq_rows,
                         const clipmi_prompt_hook* hook, float* out, void* workspace, size_t workspace_bytes,
                         unsigned flags, clipmi_stream_t stream);

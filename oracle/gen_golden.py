@@ -86,11 +86,43 @@ def ref_forward(ref_model, geom_name, seed, n_img, n_cls, capture=False, make_sd
     return sd, model32, out
 
 
+def vitl_goldens(ref_model):
+    """ViT-L geometries (round 6; clip/clip.py:37-38, shape inference clip/model.py:660-665): the reference's fp32 and fp16-on-CPU outputs for
+    ViT-L/14 (257 tokens) and ViT-L/14@336px (577 tokens: BASELINE configs[4]) on seeded weights, plain and with trained-CLIP-like outlier
+    statistics -- what the long-sequence attention kernel and the split-row GEMMs of round 5 are pinned on.  Features + checksum only (weights
+    and images regenerate from the seed).  ~1.5 TFLOP of fp32 CPU work per 336px case:  python oracle/gen_golden.py vitl"""
+    nrm = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    for gname, stem in (("ViT-L/14", "vitl14"), ("ViT-L/14@336px", "vitl14_336")):
+        for make_sd, suffix in ((None, "seed0"), (syn.outlier_state_dict, "outliers")):
+            sd, m32, out = ref_forward(ref_model, gname, seed=0, n_img=2, n_cls=4, make_sd=make_sd)
+            out.pop("images")
+            if make_sd is not None:   # the residual statistics of the image tower, as in vitb16_outliers.npz
+                stats = {}
+                def stat_hook(i):
+                    def f(_m, _i, o):
+                        a = o.detach().abs().mean(dim=(0, 1))
+                        stats[i] = (float(a.median()), float(a.max()), float(o.mean(-1).abs().mean()), float(o.std(-1).mean()))
+                    return f
+                for i, blk in enumerate(m32.visual.transformer.resblocks):
+                    blk.register_forward_hook(stat_hook(i))
+                with torch.no_grad():
+                    m32.encode_image(syn.synthetic_images(1, gname, seed=0))
+                out["residual_stats"] = np.array([stats[i] for i in sorted(stats)])
+            np.savez_compressed(os.path.join(OUT, f"{stem}_{suffix}.npz"), **out)
+            ref = nrm(out["image_features"]) @ nrm(out["text_features"]).T
+            r16 = nrm(out["image_features_fp16"]) @ nrm(out["text_features_fp16"]).T
+            print(f"wrote {stem}_{suffix}.npz; reference fp16-vs-fp32 cosine-logit distance {np.abs(r16 - ref).max():.2e}", flush=True)
+            del sd, m32, out
+
+
 def main():
     from sklearn.metrics import f1_score
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref_model = _load("ref_model", "clip/model.py")
+    if len(sys.argv) > 1 and sys.argv[1] == "vitl":   # the ViT-L fixtures alone (the rest regenerates byte-identically without them)
+        vitl_goldens(ref_model)
+        return
     ref_metrics = _load("ref_metrics", "tools/metrics.py")
     ref_dac = _load("ref_dac", "trainers/calibration/distanse_aware_calibration.py")
 
@@ -336,7 +368,7 @@ def main():
     # ---------------- tokenizer (clip/simple_tokenizer.py; packing of clip/clip.py:207-224) ----------------
     # ftfy is not installed: stubbed to the identity (exact for ASCII).  Every merge-table lookup that HIT during the
     # run is recorded, so the fixture carries a sparse {pair: rank} table instead of OpenAI's 1.3 MB data file.
-    import json, sys, types
+    import json, types
     sys.modules.setdefault("ftfy", types.SimpleNamespace(fix_text=lambda t: t))
     ref_tok_mod = _load("ref_tok", "clip/simple_tokenizer.py")
     tok = ref_tok_mod.SimpleTokenizer(os.path.join(REF, "clip", "bpe_simple_vocab_16e6.txt.gz"))

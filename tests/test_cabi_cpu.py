@@ -394,5 +394,18 @@ def test_live_rows_is_host_logic():
     for k in range(40):
         model.live_rows(syn.synthetic_token_ids(4, "tiny", seed=100 + k))
     assert len(model._live_rows) <= 16
+    # tensors made under inference_mode have no version counter (reading it raises): the bound is computed per call, nothing is cached
+    with torch.inference_mode():
+        inf_ids = syn.synthetic_token_ids(8, "tiny", seed=11, n_ctx_placeholders=4).clone()
+        n_before = len(model._live_rows)
+        assert model.live_rows(inf_ids) == r and model.live_rows(inf_ids) == r and len(model._live_rows) == n_before
+    # an entry does not keep its tensor alive, and an entry whose tensor is gone is not trusted
+    import gc, weakref
+    tmp = syn.synthetic_token_ids(4, "tiny", seed=999)
+    model.live_rows(tmp)
+    wr = weakref.ref(tmp)
+    del tmp
+    gc.collect()
+    assert wr() is None
     model.text_dead_row_elimination = False
     assert model.live_rows(ids) == model.context_length

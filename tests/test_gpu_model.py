@@ -213,6 +213,43 @@ def test_golden_vitb16_outlier_statistics(clipmi_option, mode):
     _feat_close(txt, g["text_features"], "text features (outlier statistics)")
 
 
+@pytest.mark.parametrize("gname,stem", [("ViT-L/14", "vitl14"), ("ViT-L/14@336px", "vitl14_336")])
+@pytest.mark.parametrize("kind", ["seed0", "outliers"])
+def test_golden_vitl(clipmi_option, gname, stem, kind):
+    """The round-5 kernels of the long towers on REFERENCE outputs (tests/golden/vitl14*.npz, oracle/gen_golden.py vitl: clip/model.py's own fp32 and
+    fp16 forwards on seeded weights; geometry by shape inference, clip/model.py:660-665, clip/clip.py:37-38): 257 / 577 tokens go through the ring
+    attention kernel (rescale with slack), width-1024 GEMMs through the streamed kernels with a ragged last tile row launched apart.  Three modes --
+    default, attn_ring = 0 (the streaming attention kernel), gemm_split_rows = 0 (one GEMM launch) -- each within 1e-3 on cosine logits of the
+    reference's fp32 answer and no further from it than twice the reference's own fp16 path; with trained-CLIP-like outlier statistics too."""
+    from clip_calibration_amd.model import build_model
+    g = load_golden(f"{stem}_{kind}.npz")
+    sd = (syn.outlier_state_dict if kind == "outliers" else syn.synthetic_state_dict)(gname, seed=0)
+    model = build_model(dict(sd), dict(PLAIN)).cuda()
+    images = syn.synthetic_images(2, gname, seed=0).cuda()
+    ids = torch.from_numpy(g["ids"]).cuda()
+    ref = _cos(g["image_features"], g["text_features"])
+    ref16_err = np.abs(_cos(g["image_features_fp16"], g["text_features_fp16"]) - ref).max()
+    for mode in ("default", "attn_ring=0", "gemm_split_rows=0", "cls_only_last_block=0"):
+        if mode != "default":
+            name, value = mode.split("=")
+            clipmi_option(name, int(value))
+        with torch.no_grad():
+            img = model.image_features_f32(images).cpu().numpy()
+            txt = model.text_features_f32(ids).cpu().numpy()
+        if mode != "default":
+            clipmi_option(name, 1)
+        assert np.isfinite(img).all() and np.isfinite(txt).all()
+        err_both = np.abs(_cos(img, txt) - ref).max()
+        err_img = np.abs(_cos(img, g["text_features"]) - ref).max()
+        print(f"[{gname} {kind} {mode}] cosine-logit error: both towers {err_both:.2e}, image side {err_img:.2e}; reference fp16 vs fp32 {ref16_err:.2e}")
+        assert max(err_both, err_img) < COS_TOL
+        # twice the reference's own fp16-vs-fp32 distance, with the floor test_golden_vitb16 uses: the distance is a maximum over 2 x 4 logits, and on
+        # the plain ViT-L/14 fixture it happens to be 4.8e-5 (1.5e-4 .. 2.6e-4 on the other three); this path measures 1.2 .. 1.5e-4 there
+        assert err_both <= max(2 * ref16_err + 2e-5, 2e-4)
+        _feat_close(img, g["image_features"], f"{gname} image features ({kind}, {mode})")
+        _feat_close(txt, g["text_features"], f"{gname} text features ({kind}, {mode})")
+
+
 @pytest.mark.parametrize("B", [1, 5, 32])
 def test_zeroshot_pipeline_vs_oracle(B):
     """BASELINE config 1: ViT-B/16, C=100 prompts, synthetic batch; logits, (conf, pred) and ECE vs the CPU path."""
@@ -360,9 +397,13 @@ def test_coop_dac_tempscaling_pipeline_vs_oracle(cached):
     lg_ref_own = orc.dac_predict(lg_ref.numpy(), cal.class_confidence)
     assert np.abs(lg_ref_own - lg_ref_dac).max() < 5e-3 * np.abs(lg_ref_dac).max() * 1.01
     labels = syn.synthetic_labels(torch.from_numpy(lg_ref_dac.argmax(1)), C, seed=1)
-    ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy(), labels.numpy(), conf_ref)
+    # ECE over 16 samples moves by 1/16 per changed prediction: the rows whose top two classes tie within the tolerance (checked above) are
+    # left out on both sides
+    keep = np.setdiff1d(np.arange(B), flipped)
+    assert len(keep) >= B - 2, f"{len(flipped)} tied rows"
+    ece_ref, _, _ = orc.calibrated_ece(lg_ref.numpy()[keep], labels.numpy()[keep], conf_ref)
     from clip_calibration_amd.metrics import ECE
-    assert abs(ECE(conf.cpu().numpy(), pred.cpu().numpy(), labels.numpy()) - ece_ref) < 1e-3
+    assert abs(ECE(conf.cpu().numpy()[keep], pred.cpu().numpy()[keep], labels.numpy()[keep]) - ece_ref) < 1e-3
     # ctx update invalidates the cache
     with torch.no_grad():
         coop_new.prompt_learner.ctx.add_(0.01)
@@ -466,13 +507,18 @@ def test_row_range_residual_kernel_text_tower(n_prompts):
     assert not torch.equal(a, f32)                                # the flag does select the fp16 stream
 
 
-@pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70)])
+@pytest.mark.parametrize("gname,batch", [("tiny", 5), ("ViT-B/16", 8), ("ViT-B/16", 70), ("ViT-L/14", 3), ("ViT-L/14@336px", 2)])
 @pytest.mark.parametrize("fold,f16", [(1, 2), (1, 0), (0, 0)])
 def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
-    """Option cls_only_last_block: the image tower's last block runs out-proj / c_fc / c_proj (and their LayerNorms) on the class
-    rows alone -- the only rows ln_post reads (clip/model.py:419) -- as the same GEMMs with M = batch and row stride L * D.  The
-    features must equal the every-row computation up to the GEMM kernels' tile choice (same per-element arithmetic), in every
-    precision mode, and match the oracle like the default path."""
+    """Option cls_only_last_block (the default since round 6): the image tower's last block computes K | V for every token and everything else --
+    the Q third of the in-projection, attention (one query per head: attention_cls.hip), out-proj, ln_2, c_fc, c_proj -- for the class rows alone,
+    the only rows ln_post reads (clip/model.py:419): the same GEMMs with M = batch and row stride L * D.  The features must equal the every-row
+    computation up to the kernels' tile choice and the attention's summation order (fp32 probabilities here, fp16 on the matrix cores there), in
+    every precision mode, and match the oracle like the every-row path."""
+    if gname.startswith("ViT-L") and (fold, f16) != (1, 2):
+        pytest.skip("the long towers: default precision mode only (suite time)")
+    from clip_calibration_amd import _lib
+    assert _lib.get_option("cls_only_last_block") == 1, "class rows only is the product default"
     clipmi_option("ln_fold", fold)
     clipmi_option("residual_f16", f16)
     sd, model = _build(gname)
@@ -489,11 +535,48 @@ def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
     scale = np.abs(a).max()
     assert np.abs(a - b).max() <= 2e-3 * scale, f"class-rows-only features differ: {np.abs(a - b).max()} vs scale {scale}"
     an, bn = a / np.linalg.norm(a, axis=1, keepdims=True), b / np.linalg.norm(b, axis=1, keepdims=True)
-    assert np.abs((an * bn).sum(1) - 1.0).max() < 2e-6
-    if batch <= 8:
+    assert np.abs((an * bn).sum(1) - 1.0).max() < 5e-6
+    if batch <= 8 and not gname.startswith("ViT-L"):           # (the long towers against the reference: test_golden_vitl)
         with torch.no_grad():
             ref = orc.encode_image(sd, images.cpu()).numpy()
         _feat_close(b, ref, "class-rows-only last block")
+
+
+@pytest.mark.parametrize("tower", ["maple", "ivlp", "vpt"])
+def test_class_rows_only_last_block_hooked_towers(clipmi_option, tower):
+    """The same on the towers that carry prompt tokens (clip/model.py:287-331, 447-478; 191-256): MaPLe's shared context + deep prompts
+    (two tokens appended behind the patches, overwritten per layer), IVLP / VPT's learned per-layer prompts.  The class token stays row 0 of its
+    sequence and every prompt token is a key of the last block's attention; class rows only == every row, and both match the reference's outputs."""
+    from clip_calibration_amd.model import build_model
+    if tower == "maple":
+        g = load_golden("tiny_clip.npz")
+        sd, model = _build("tiny", dict(PLAIN, trainer="MaPLe", maple_length=2))
+        pl = {k[len("maple_pl:"):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("maple_pl:")}
+        _, shared, _, deep_v = orc.maple_prompt_learner(sd, torch.from_numpy(g["maple_ids"]), pl)
+        images = torch.from_numpy(g["images"]).cuda()
+        run = lambda: model.image_features_f32(images, shared.cuda(), [t.cuda() for t in deep_v])
+        want = g["maple_image_features"]
+    else:
+        dd = ({"trainer": "IVLP", "vision_depth": 3, "language_depth": 3, "vision_ctx": 2, "language_ctx": 2} if tower == "ivlp" else
+              {"trainer": "VPT", "vision_depth": 2, "language_depth": 0, "vision_ctx": 4, "language_ctx": 0})
+        g = load_golden("tiny3_clip.npz")
+        model = build_model(dict(syn.synthetic_state_dict("tiny3", seed=0)), dict(dd))
+        own = {k for k in model.state_dict() if "VPT" in k}
+        model.load_state_dict({k: torch.from_numpy(g[f"{tower}_sd:{k}"]) for k in own}, strict=False)
+        model = model.cuda()
+        images = torch.from_numpy(g["images"]).cuda()
+        run = lambda: model.image_features_f32(images)
+        want = g[tower + "_image_features"]
+    with torch.no_grad():
+        clipmi_option("cls_only_last_block", 0)
+        full = run().cpu().numpy()
+        clipmi_option("cls_only_last_block", 1)
+        cls = run().cpu().numpy()
+    assert np.isfinite(cls).all()
+    an, bn = full / np.linalg.norm(full, axis=1, keepdims=True), cls / np.linalg.norm(cls, axis=1, keepdims=True)
+    assert np.abs((an * bn).sum(1) - 1.0).max() < 5e-6
+    _feat_close(cls, want, f"{tower} image tower, class rows only in the last block")
+    _feat_close(full, want, f"{tower} image tower, every row")
 
 
 @pytest.mark.parametrize("gname", ["tiny", "ViT-B/16"])

@@ -166,6 +166,24 @@ def test_live_rows_bookkeeping():
     assert model.live_rows(ids) == model.context_length
 
 
+def test_text_paths_under_inference_mode():
+    """Callers that tokenise or move ids inside torch.inference_mode() hand over tensors without a version counter (reading ``_version`` raises):
+    encode_text / text_features_f32 / text_encoder_f32 compute the row bound per call instead of caching it -- same bits as outside."""
+    sd, model = _build("tiny")
+    ids = _ragged_ids(9, "tiny", seed=21)
+    want = model.encode_text(ids.cuda())
+    with torch.inference_mode():
+        inf = ids.clone().cuda()
+        with pytest.raises(RuntimeError):
+            inf._version
+        got = model.encode_text(inf)
+        f32 = model.text_features_f32(inf)
+        prompts = model.token_embedding(inf).type(model.dtype)
+        enc = model.text_encoder_f32(prompts, inf)
+    assert torch.equal(got, want) and torch.isfinite(f32).all() and torch.isfinite(enc).all()
+    assert torch.equal(f32, model.text_features_f32(ids.cuda()))
+
+
 def test_maple_hook_with_truncated_rows():
     """MaPLe's deep text prompts overwrite tokens 1..n_ctx of every block's input (clip/model.py:287-331): unaffected by the row bound."""
     dd = {"trainer": "MaPLe", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0, "maple_length": 2}

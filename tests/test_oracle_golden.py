@@ -177,6 +177,34 @@ def test_vitb16_outlier_statistics_fixture():
     assert 1e-5 < ref16 < 1e-3
 
 
+@pytest.mark.parametrize("gname,stem", [("ViT-L/14", "vitl14"), ("ViT-L/14@336px", "vitl14_336")])
+@pytest.mark.parametrize("kind", ["seed0", "outliers"])
+def test_vitl_geometries(gname, stem, kind):
+    """Round 6: the ViT-L geometries (clip/clip.py:37-38; shapes inferred as in clip/model.py:660-665) -- 257 and 577 tokens, width 1024, 24 layers --
+    against the reference's own fp32 outputs on seeded weights, plain and with trained-CLIP-like outlier statistics (oracle/gen_golden.py vitl).
+    The oracle here; the HIP towers (ring attention, split-row GEMMs) in tests/test_gpu_model.py::test_golden_vitl."""
+    g = load_golden(f"{stem}_{kind}.npz")
+    sd = (syn.outlier_state_dict if kind == "outliers" else syn.synthetic_state_dict)(gname, seed=0)
+    assert _sd_checksum(sd) == pytest.approx(float(g["sd_checksum"]), rel=1e-12)
+    ids = torch.from_numpy(g["ids"])
+    assert torch.equal(ids, syn.synthetic_token_ids(4, gname, seed=0))
+    txt = orc.encode_text(sd, ids)
+    n = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+    assert np.abs(n(txt.numpy()) @ n(g["text_features"]).T - n(g["text_features"]) @ n(g["text_features"]).T).max() < 5e-5
+    if kind == "outliers":
+        st = g["residual_stats"]
+        assert st.shape == (24, 4) and (st[2:, 1] > 10 * st[2:, 0]).all()
+    if stem == "vitl14_336" and kind == "outliers":
+        return                                        # (one 0.38 TFLOP fp32 image pass per geometry is enough for the CPU suite's budget)
+    img = orc.encode_image(sd, syn.synthetic_images(1, gname, seed=0) if stem == "vitl14_336" else syn.synthetic_images(2, gname, seed=0))
+    ref_img = g["image_features"][: img.shape[0]]
+    ref = n(ref_img) @ n(g["text_features"]).T
+    assert np.abs(n(img.numpy()) @ n(txt.numpy()).T - ref).max() < 5e-5
+    np.testing.assert_allclose(img.numpy(), ref_img, rtol=1e-3, atol=1e-3 * np.abs(ref_img).max())
+    ref16 = np.abs(n(g["image_features_fp16"]) @ n(g["text_features_fp16"]).T - n(g["image_features"]) @ n(g["text_features"]).T).max()
+    assert 1e-6 < ref16 < 1e-3
+
+
 def test_ece_cases():
     g = load_golden("ece_cases.npz")
     names = sorted({k.split(":")[0] for k in g})
