@@ -608,6 +608,12 @@ def main():
         return
     geom = syn.GEOMETRIES[args.model]
     coop = args.workload == "coop_dac"
+    # `value` and every number derived from it time the EVERY-ROW tower (every block computes every token row), as in rounds 1-5.  The product default
+    # since round 6 -- the last image block computes K | V of every token and everything else for the class rows alone (clip/model.py:419 reads
+    # nothing else) -- is timed on the same step as `value_cls_only`, with the flop it really issues.
+    from clip_calibration_amd import _lib
+    assert _lib.get_option("cls_only_last_block") == 1, "class rows only in the last image block is the product default"
+    _lib.set_option("cls_only_last_block", 0)
     B = args.batch
     Cn = args.classes or (500 if coop else 1000)
     E = geom.embed_dim
@@ -743,6 +749,20 @@ def main():
                                   "ratio_to_value": (world * B * n_s / el_s) / (world * B * args.steps / elapsed)}
             if sampler:
                 extra["power"] = sampler.stop()
+        with _lib.option("cls_only_last_block", 1):   # the product default, same step, same K steps
+            for _ in range(max(1, args.warmup // 2)):
+                step(labels)
+            elapsed_cls, _ = run(labels, args.steps)
+        Lv, Dv = geom.vision_tokens, geom.vision_width
+        flops_cls = syn.flops_per_image(args.model) - (Lv * (24 * Dv * Dv + 4 * Lv * Dv) - (4 * Lv * Dv * Dv + 20 * Dv * Dv + 4 * Lv * Dv))
+        extra["value_cls_only"] = world * B * args.steps / elapsed_cls
+        extra["cls_only"] = {
+            "what": "the same step with cls_only_last_block = 1 (product default): the last image block computes K | V for every token, Q / attention / "
+                    "out-proj / MLP for the class rows only (clip/model.py:419: ln_post reads x[:, 0, :])",
+            "images_per_s": world * B * args.steps / elapsed_cls, "ms_per_step": 1e3 * elapsed_cls / args.steps,
+            "gflop_per_image_issued": flops_cls / 1e9, "gflop_per_image_every_row": syn.flops_per_image(args.model) / 1e9,
+            "tower_tflops_issued": flops_cls * world * B * args.steps / elapsed_cls / 1e12,
+            "speedup_vs_value": elapsed / elapsed_cls}
         if coop:
             n_rt = max(2, args.steps // 2)
             for _ in range(2):
@@ -804,6 +824,7 @@ def main():
         "dtype": "f16",
         "data": "synthetic",
         "config": {"workload": workload, "batch_per_gpu": B, "global_batch": world * B, "classes": Cn,
+                   "rows_computed": "every token row of every block (cls_only_last_block = 0); the product default is value_cls_only",
                    "parallelism": (f"dp{world}: batch sharded, one {'RCCL (clipmi_allgather)' if exchange.backend == 'rccl' else ('gloo (same-GPU self-test)' if same_gpu else 'torch.distributed nccl (fallback)')} "
                                    f"all-gather of [B,{E}] fp16 embeddings per step, logits on the gathered batch on every rank")
                    if world > 1 else "single GPU"},
@@ -846,13 +867,12 @@ def main():
             tail_ms = e0.elapsed_time(e1) / n_tail
             # Optional mode, NOT part of `value` (every timed step above computes every row of every block): the last block's
             # out-proj / MLP on the class rows only -- the only rows ln_post reads.  Reported with its feature difference.
-            from clip_calibration_amd import _lib
             with _lib.option("cls_only_last_block", 1):
                 feats_cls = model.image_features_f32(images).clone()
                 cls_ms = timed_ms(lambda: model.image_features_f32(images), 10)
             fn_, cn_ = torch.nn.functional.normalize(feats, dim=1), torch.nn.functional.normalize(feats_cls, dim=1)
             out["class_rows_only_last_block"] = {
-                "option": "cls_only_last_block=1 (off by default and in every number above)", "tower_ms": cls_ms,
+                "option": "cls_only_last_block=1 (the product default; every number above except value_cls_only / cls_only runs option 0)", "tower_ms": cls_ms,
                 "tower_ms_every_row": out["roofline"]["tower"]["ms"], "images_per_s_tower_only": B / (cls_ms * 1e-3),
                 "max_abs_cosine_diff_vs_every_row": float((1.0 - (fn_ * cn_).sum(1)).abs().max())}
         out["tail"] = {"what": "ONE launch (fused_tail_kernel): L2-normalise + scale*img@txt^T" + (" + DAC row scale" if coop else "") +

@@ -34,6 +34,11 @@ __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, c
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, CLIPMI_LDS_PTR(lds), 16, voff, soff, 0, 0);
 }
 #define CLIPMI_BUFFER_LOAD_LDS16(rsrc, lds, voff, soff) ::clipmi::buffer_load_lds16((rsrc), (lds), (voff), (soff))
+// the same with cache-policy bits (1 = sc0, 2 = sc1, 4? = nt on gfx950's buffer instructions: 2 is what __builtin_nontemporal_load emits); build-time A/Bs only
+template <int AUX>
+__device__ __forceinline__ void buffer_load_lds16_aux(__amdgpu_buffer_rsrc_t rsrc, const void* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, CLIPMI_LDS_PTR(lds), 16, voff, soff, 0, AUX);
+}
 
 // A register that VALU instructions have just written (conversions, transcendentals: the softmax's P, the tail's hi / lo split) and that
 // an MFMA reads as a SOURCE operand right behind them needs wait states that hipcc does not insert on gfx950 for these sequences (it

@@ -1,6 +1,11 @@
 // Persistent row-range kernel of the fp16-stream residual GEMMs (out-proj, c_proj; variant 16 of launch_gemm, gemm.hip).
 #include "gemm_common.h"
 
+// build-time A/B of the cache policy of the ACTIVATION operand's LDS-DMA (out-proj reads the attention rows exactly once: profiles/r06_attn_outproj_pair.txt)
+#ifndef CLIPMI_RSTREAM_A_AUX
+#define CLIPMI_RSTREAM_A_AUX 0
+#endif
+
 namespace clipmi {
 namespace gemm {
 namespace {
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rstream_kernel(const KArgs a, con
     constexpr int P = decltype(p_tag)::value;
     if constexpr (P < 5) {
       if (64 * P + wave * 8 < 32 * nbx)   // uniform
-        CLIPMI_BUFFER_LOAD_LDS16(xrs, smem + buf * R::STAGE + P * 8192 + wave * 1024, row_off(xoff0, P * xstep), kt * BK * 2);
+        buffer_load_lds16_aux<CLIPMI_RSTREAM_A_AUX>(xrs, smem + buf * R::STAGE + P * 8192 + wave * 1024, row_off(xoff0, P * xstep), kt * BK * 2);
     } else {
       CLIPMI_BUFFER_LOAD_LDS16(wrs, smem + buf * R::STAGE + R::XB + (P - 5) * 8192 + wave * 1024, row_off(woff0, (P - 5) * wstep), kt * BK * 2);
     }

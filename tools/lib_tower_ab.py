@@ -12,6 +12,9 @@ sys.path.insert(0, %r)
 from clip_calibration_amd import _lib, synthetic as syn
 from clip_calibration_amd.model import build_model
 G = os.environ.get("GEOM", "ViT-B/16"); B = int(os.environ.get("B", "256"))
+_lib.set_option("cls_only_last_block", int(os.environ.get("CLS_ONLY", "0")))   # like with like: libraries before round 6 default to every row
+for kv in filter(None, os.environ.get("OPTIONS", "").split(",")):              # e.g. OPTIONS=attn_loader=1
+    _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 model = build_model(dict(syn.synthetic_state_dict(G, seed=0)), None).cuda()
 images = syn.synthetic_images(B, G, seed=0, device="cuda")
 with torch.no_grad():
