@@ -307,6 +307,32 @@ def test_no_valu_written_mfma_source_closer_than_four_wait_states():
         assert m and int(m.group(1)) >= 1 and int(m.group(2)) >= 32, ln
 
 
+def test_no_kernel_names_a_register_outside_its_allocation():
+    """Round 6 (profiles/r06_hazard_root_cause.txt): damage to a NEIGHBOUR's registers is also what an out-of-allocation register write looks like.
+    The scanner's third pass compares the highest VGPR / AGPR index any instruction of a kernel names with the kernel descriptor's allocation
+    (.amdhsa_next_free_vgpr / .amdhsa_accum_offset), for every kernel of the two translation units with inline-asm MFMAs and tied tuples."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which(os.environ.get("HIPCC", "hipcc")) is None:
+        pytest.skip("no hipcc on this box: the ISA cannot be produced")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_hazard_scan.py"), "gemm_rstream.hip", "attention.hip"],
+                       env=dict(os.environ, WAIT="4"), capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if "name a register outside their allocation" in ln]
+    assert len(lines) == 2, r.stdout[-2000:] + r.stderr[-1000:]
+    for ln in lines:
+        m = re.search(r": 0 kernels name a register outside their allocation \((\d+) kernel descriptors checked", ln)
+        assert m and int(m.group(1)) >= 1, ln
+    hs = _hazard_scan()
+    asm = ("_Z1kv:\n v_mfma_f32_16x16x32_f16 v[8:11], v[0:3], v[4:7], v[8:11]\n v_add_f32 v12, v8, v8\n s_endpgm\n"
+           ".amdhsa_kernel _Z1kv\n .amdhsa_next_free_vgpr 12\n .amdhsa_accum_offset 12\n.end_amdhsa_kernel\n")
+    (b,) = hs.register_bounds(asm, hs.split_kernels(asm))
+    assert b[1] == 12 and not b[5]                      # v12 named, 12 registers allocated: caught
+    (b,) = hs.register_bounds(asm.replace("next_free_vgpr 12", "next_free_vgpr 13").replace("accum_offset 12", "accum_offset 16"), hs.split_kernels(asm))
+    assert b[5]
+
+
 def test_no_close_vector_read_of_an_mfma_result_in_the_round5_kernels():
     """The second co-residency hazard (common.h CLIPMI_MFMA_TO_VALU_FENCE3; profiles/r05_vitl_attention.txt): a register an MFMA has written, read by the
     vector pipe behind hipcc's own `s_nop 10` with another MFMA issued in between -- `l += lacc[0]` right behind every softmax group made the first

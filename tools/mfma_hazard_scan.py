@@ -210,10 +210,41 @@ def scan_kernel_reads(name, insts, labels):
     return [(name, x, m, w) for (x, m), w in sites.items()]
 
 
+def register_bounds(asm, kernels):
+    """Round 6 (verdict r5 item 6a): a co-resident wave's registers being damaged is also what an out-of-allocation register WRITE looks like -- an
+    inline-asm operand or tied tuple reaching past what the kernel descriptor allocates.  For every kernel: the highest VGPR / AGPR index any
+    instruction names against the descriptor (.amdhsa_next_free_vgpr, .amdhsa_accum_offset: arch VGPRs live below the accumulation offset, AGPRs in
+    next_free_vgpr - accum_offset behind it).  Returns [(kernel, max v, max a, next_free_vgpr, accum_offset, ok)]."""
+    desc = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        nf = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
+        ao = re.search(r"\.amdhsa_accum_offset (\d+)", m.group(2))
+        if nf:
+            desc[m.group(1)] = (int(nf.group(1)), int(ao.group(1)) if ao else int(nf.group(1)))
+    out = []
+    for name, insts, _labels in kernels:
+        if name not in desc:
+            continue
+        mv = ma = -1
+        for _op, ops, _text in insts:
+            for o in ops:
+                for kind, r in regs(o):
+                    if kind == "v":
+                        mv = max(mv, r)
+                    else:
+                        ma = max(ma, r)
+        nf, ao = desc[name]
+        ok = mv < min(ao, nf) and (ma < 0 or ma < nf - ao) and nf <= 512 and ao <= 256   # (no AGPRs: next_free_vgpr counts the arch VGPRs alone)
+        out.append((name, mv, ma, nf, ao, ok))
+    return out
+
+
 def scan(src, extra=()):
     """(sites, kernels with MFMAs, MFMA instructions) of one translation unit; raises ScanError when the file does not compile or holds no MFMA
     kernel at all (a guard that scans nothing must not pass)."""
-    kernels = split_kernels(compile_to_isa(src, extra))
+    asm = compile_to_isa(src, extra)
+    kernels = split_kernels(asm)
+    scan.bounds = register_bounds(asm, kernels)
     sites, reads, with_mfma, total = [], [], 0, 0
     for name, insts, labels in kernels:
         s, n = scan_kernel(name, insts, labels)
@@ -251,6 +282,13 @@ def main():
             print(f"   {name}\n      {w}\n      {m}      ({waited} wait states between)")
         if os.environ.get("STRICT_READS", "0") == "1":
             bad += len(reads)
+        bounds = scan.bounds
+        over = [b for b in bounds if not b[5]]
+        print(f"{src}: {len(over)} kernels name a register outside their allocation ({len(bounds)} kernel descriptors checked; the tightest: "
+              + ", ".join(f"v{b[1]} of {min(b[3], b[4])}" for b in sorted(bounds, key=lambda b: min(b[3], b[4]) - b[1])[:3]) + ")")
+        for b in over:
+            print(f"   {b[0][:100]}: max v{b[1]} / a{b[2]} against next_free_vgpr {b[3]}, accum_offset {b[4]}")
+        bad += len(over)
     sys.exit(1 if bad else 0)
 
 
