@@ -284,12 +284,17 @@ def other_configs(dev, syn, model, build_model, images, Cn):
     from clip_calibration_amd import ops
     out = {}
 
+    from clip_calibration_amd import _lib
+
     def tower(m, name, x, iters=6):
         m.image_features_f32(x)
         ms = timed_ms(lambda: m.image_features_f32(x), iters)
         tf = syn.flops_per_image(name) * x.shape[0] / (ms * 1e-3) / 1e12
+        with _lib.option("cls_only_last_block", 1):   # the product default (every number without the suffix: every row of every block, as `value`)
+            m.image_features_f32(x)
+            ms_c = timed_ms(lambda: m.image_features_f32(x), iters)
         return {"model": name, "batch_per_gpu": x.shape[0], "tower_ms": ms, "images_per_s_tower": x.shape[0] / (ms * 1e-3), "tower_tflops": tf,
-                "tower_frac": tf / MFMA_F16_DENSE_PEAK_TFLOPS}
+                "tower_frac": tf / MFMA_F16_DENSE_PEAK_TFLOPS, "tower_ms_cls_only": ms_c, "images_per_s_tower_cls_only": x.shape[0] / (ms_c * 1e-3)}
     with torch.no_grad():
         out["configs[3] per-rank"] = tower(model, "ViT-B/16", images[:128].contiguous())
         # configs[2]: 500 classes, n_ctx 16, DAC factors (any positive vector times the row: the fit is host work outside the loop)
@@ -303,11 +308,15 @@ def other_configs(dev, syn, model, build_model, images, Cn):
             return ops.fused_tail(feats, txt, scale, dac, True, True)
         coop_step()
         ms = timed_ms(coop_step, 6)
+        with _lib.option("cls_only_last_block", 1):
+            coop_step()
+            ms_c = timed_ms(coop_step, 6)
         rows = model.live_rows(coop.tokenized_prompts)
         t_ms = timed_ms(lambda: coop.text_features(), 6)
         out["configs[2] per-batch schedule"] = {
             "model": "ViT-B/16", "batch_per_gpu": images.shape[0], "classes": 500, "n_ctx": 16, "ms_per_batch": ms,
             "images_per_s_text_recomputed_every_batch": images.shape[0] / (ms * 1e-3),
+            "ms_per_batch_cls_only": ms_c, "images_per_s_text_recomputed_every_batch_cls_only": images.shape[0] / (ms_c * 1e-3),
             "text_rows_computed": rows, "text_rows_of_context": model.context_length, "text_tower_ms": t_ms,
             "text_tower_tflops_on_computed_rows": syn.flops_per_prompt("ViT-B/16") * 500 * rows / model.context_length / (t_ms * 1e-3) / 1e12,
             "what": "prompt learner + text tower (fp16 stream, side stream) + image tower + fused tail with DAC row scale, every batch; flop credited "

@@ -1803,10 +1803,34 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
   // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 8 K-steps: the streamed-epilogue persistent kernel
   // (the cost model only ranks the one-tile-per-workgroup kernels)
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
-    const bool fits = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) && k.ln_rs == 1 &&
-                      stream_offsets_ok(k) && stream_whole_matrix_ok(k);
+    const bool fits_shape = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) && k.ln_rs == 1 &&
+                            stream_offsets_ok(k);
+    const bool fits = fits_shape && stream_whole_matrix_ok(k);
     const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
-    if (fits && (variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1))) {
+    const bool wanted = variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1);
+    if (fits_shape && !fits && wanted) {
+      // a matrix beyond the 2 GiB one descriptor addresses (a text tower of several hundred thousand token rows): consecutive launches over row ranges
+      // that fit, each a multiple of the tile height
+      const int64_t per_row = 2 * (k.lda > k.ldo ? k.lda : k.ldo);
+      int64_t rows = (((1ll << 31) - (1ll << 25)) / per_row - 256) & ~255ll;
+      const int64_t max_tiles = (1ll << 16) / ((k.N + 255) / 256) * 256;      // ... and keep the tile ids inside the traversal's multipliers
+      if (rows > max_tiles) rows = max_tiles;
+      KArgs c = k;
+      c.M = (int)rows;
+      if (rows >= 256 && stream_whole_matrix_ok(c)) {
+        for (int64_t r0 = 0; r0 < k.M; r0 += rows) {
+          c = k;
+          c.M = (int)(k.M - r0 < rows ? k.M - r0 : rows);
+          c.A = k.A + r0 * k.lda;
+          c.out = static_cast<half_t*>(k.out) + r0 * k.ldo;
+          if (k.ln_stats) c.ln_stats = k.ln_stats + 2 * r0;
+          const int rc = launch_stream<EPI>(c, ln_rows ? ln_rows + r0 : nullptr, s);
+          if (rc) return rc;
+        }
+        return CLIPMI_OK;
+      }
+    }
+    if (fits && wanted) {
       // A ragged last row of tiles that opens a round of its own -- ViT-L/14@336 at 64 images: c_fc is 145 x 16 tiles = 9.06 rounds of 256 persistent
       // workgroups, the tenth for 64 rows; ViT-L/14 at 128 images: 8.06 and 6.05 rounds -- goes to the one-tile-per-workgroup kernels as a launch of
       // its own (a few tens of tiles, ~10 us) and the persistent kernel runs whole rounds (profiles/r05_gemm_remainder.txt).

@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the GPU suite has a step limit on the driver's box: the slowest tests go into whatever log the run leaves (verdict r5, item 7)
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or "") and not config.getoption("durations"):
+        config.option.durations = 15
 
 
 # ---- the N > 1 path on the hardware there is (tests/test_gpu_multirank.py) -------------------------------------------

@@ -443,22 +443,9 @@ def test_tempscaling_sgd_step_matches_reference_gradient():
     assert all(p.grad is None for p in model.parameters())                      # nothing else is a leaf of that graph
 
 
-@pytest.mark.parametrize("gname,batch", [("ViT-L/14", 2), ("ViT-L/14@336px", 1)])
-def test_vit_large_towers_vs_oracle(gname, batch):
-    """BASELINE config 5 geometry (ViT-L/14 at 224 and 336 px: 24 layers, width 1024, patch 14 -> K padded 588 -> 640,
-    L = 257 / 577 tokens -> multi-block attention, E = 768; text tower width 768) against the CPU oracle."""
-    sd, model = _build(gname)
-    images = syn.synthetic_images(batch, gname, seed=11)
-    ids = syn.synthetic_token_ids(5, gname, seed=11)
-    with torch.no_grad():
-        img = model.image_features_f32(images.cuda())
-        txt = model.text_features_f32(ids.cuda())
-        ref_i = orc.encode_image(sd, images).numpy()
-        ref_t = orc.encode_text(sd, ids).numpy()
-    _feat_close(img.cpu().numpy(), ref_i, f"{gname} image tower")
-    _feat_close(txt.cpu().numpy(), ref_t, f"{gname} text tower")
-    cos = _cos(img.cpu().numpy(), txt.cpu().numpy())
-    assert np.abs(cos - _cos(ref_i, ref_t)).max() < COS_TOL
+# (BASELINE config 5's geometries -- ViT-L/14 at 224 and 336 px -- against the CPU oracle: superseded in round 6 by test_golden_vitl, the same towers
+# against the REFERENCE's outputs on the same seeded weights, with the oracle held to those fixtures in tests/test_oracle_golden.py; 31 s of CPU
+# oracle work less in the GPU suite.)
 
 
 @pytest.mark.parametrize("batch", [256, 300, 160, 131])

@@ -107,6 +107,27 @@ def test_gemm_stream_kernel_race_screen(ops, clipmi_option):
     assert bad == 0, f"{bad} of 60 launches differ"
 
 
+def test_gemm_stream_kernel_beyond_one_descriptor(ops):
+    """gemm_stream_kernel addresses each operand through ONE buffer descriptor per launch (round 6): a matrix beyond 2 GiB -- the hidden
+    activations of a text tower of a few hundred thousand token rows -- runs as consecutive launches over row ranges that fit (gemm.hip launch_one).
+    270 000 x 4096 fp16 outputs = 2.2 GB: checked on rows around every range boundary and at both ends against an fp32 reference, and for
+    untouched memory behind the last row."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 270000, 4096, 512
+    a = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    out = ops.gemm_f16(a, w, bias, epilogue=_lib.EPI_BIAS_QUICKGELU, out_dtype=torch.float16)
+    assert out.shape == (M, N) and out.numel() * 2 > 2 ** 31
+    per_row = 2 * N
+    step = (((2 ** 31 - 2 ** 25) // per_row) - 256) // 256 * 256
+    rows = torch.cat([torch.arange(0, 300)] + [torch.arange(b - 300, min(M, b + 300)) for b in range(step, M, step)] + [torch.arange(M - 300, M)]).unique()
+    ref = torch.nn.functional.linear(a[rows].float(), w.float(), bias)
+    ref = ref * torch.sigmoid(1.702 * ref)
+    assert float((out[rows].float() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    assert torch.isfinite(out[::997]).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(16448, 3072, 768), (36928, 4096, 1024), (32896, 3072, 1024), (33000, 4096, 1024)])
 def test_gemm_ragged_last_tile_row_as_its_own_launch(ops, clipmi_option, M, N, K):
     """gemm_split_rows (default 1): a last row of 256-row tiles with <= 128 live rows that would open a round of its own in the persistent kernel
