@@ -820,6 +820,14 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2*
 #ifndef CLIPMI_STREAM_HD
 #define CLIPMI_STREAM_HD 2
 #endif
+// build-time A/B of the cache policy of the two operands' LDS-DMA (profiles/r06_stream_dma_policy.txt): an activation panel is read by the four
+// workgroups of a band at about the same time and never again in that band, a weight panel by every m-tile of the band
+#ifndef CLIPMI_STREAM_A_AUX
+#define CLIPMI_STREAM_A_AUX 0
+#endif
+#ifndef CLIPMI_STREAM_W_AUX
+#define CLIPMI_STREAM_W_AUX 0
+#endif
 #ifndef CLIPMI_STREAM_PREFETCH
 #define CLIPMI_STREAM_PREFETCH 1
 #endif
@@ -920,8 +928,8 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
     constexpr int P = decltype(p_tag)::value;
     char* xs = smem + buf * T::STAGE + lds_wave_off;
     const int k0 = kt * BK * 2;
-    if constexpr (P < T::XI) CLIPMI_BUFFER_LOAD_LDS16(xrs, xs + P * (NT * 16), row_off(xoff0, xo + P * xstep), k0);
-    else CLIPMI_BUFFER_LOAD_LDS16(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, wo + (P - T::XI) * wstep), k0);
+    if constexpr (P < T::XI) buffer_load_lds16_aux<CLIPMI_STREAM_A_AUX>(xrs, xs + P * (NT * 16), row_off(xoff0, xo + P * xstep), k0);
+    else buffer_load_lds16_aux<CLIPMI_STREAM_W_AUX>(wrs, xs + T::XBYTES + (P - T::XI) * (NT * 16), row_off(woff0, wo + (P - T::XI) * wstep), k0);
   };
   static_assert(T::XI + T::WI == 8, "eight DMA pieces per wave and stage");
   auto stage = [&](int buf, int kt, int xo, int wo) {
