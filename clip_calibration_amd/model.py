@@ -304,13 +304,25 @@ class CLIP(nn.Module):
         home = self._home()
         if device == home.device or device.type != "cuda" or home.device.type != "cuda":   # (a CPU tensor / model is refused further down)
             return home
+        sig = home._param_versions()
         with home._copies_lock:
             twin = home._device_copies.get(device.index)
+            seen = home.__dict__.setdefault("_copy_versions", {})
+            if twin is not None and sig is not None and seen.get(device.index) != sig:
+                twin = None                  # a parameter of the owner was updated in place (IVLP / VPT prompts under training): a copy is a snapshot
             if twin is None:
                 with torch.cuda.device(device):
                     twin = home._copy_to(device)
                 home._device_copies[device.index] = twin
+                seen[device.index] = sig
         return twin
+
+    def _param_versions(self):
+        """Version counters of every parameter and buffer (in-place updates move them); None when some tensor has none (made under inference_mode)."""
+        try:
+            return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+        except RuntimeError:
+            return None
 
     def _elsewhere(self, t) -> Optional["CLIP"]:
         """The resident copy a call on tensor ``t`` must run on, None when this model is the right one."""
@@ -591,6 +603,8 @@ class CLIP(nn.Module):
             hook, keep = self._hook(n_ctx, None, deep_prompts, g.transformer_layers - 1)
             hook_ref = C.byref(hook)
         rows = self.live_rows(tokenized_prompts, n_ctx if deep_prompts else 0) if seq_rows is None else int(seq_rows)
+        if deep_prompts and 0 < rows < g.context_length:
+            rows = max(rows, min(g.context_length, 1 + int(n_ctx)))      # a caller's bound never cuts the prompt tokens 1 .. n_ctx a hook overwrites
         with self._launch_lock:
             ws = self._workspace("text", lib.clipmi_text_workspace_bytes(self._handle, Cn, rows))
             check(lib.clipmi_text_encoder(self._handle, prompts.data_ptr(), _DT[prompts.dtype], eot.data_ptr(), Cn, rows, hook_ref,

@@ -115,7 +115,8 @@ class ModifiedResNet(nn.Module):
 
     def _packed_on(self, device: torch.device) -> dict:
         """The owner's packed operands on ``device`` (copied once per device, dropped when the owner re-packs)."""
-        own = self._ensure_packed()
+        with self._pack_lock:                   # (several replica threads ask at once: the pack runs once)
+            own = self._ensure_packed()
         if device == self.conv1.weight.device:
             return own
 

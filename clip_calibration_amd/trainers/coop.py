@@ -134,7 +134,11 @@ class CustomCLIP(nn.Module):
         if self.cache_text_features and key == self._cache_key and self._cache is not None:
             return self._cache
         prompts, deep, n_ctx = self._text_inputs()
-        tf = ops.l2_normalize(self.text_encoder(prompts, self.tokenized_prompts, deep, n_ctx, flags=self._text_flags()))
+        # the live token rows of the class list, from the OWNER's copy of the ids and the owner's table (one read-back per prompt set, ever): under
+        # nn.DataParallel a replica's buffers are re-broadcast -- new tensors -- on every forward, and a per-forward bound would sync every device
+        m = self.clip_model
+        rows = m._home().live_rows(self.prompt_learner.tokenized_prompts, n_ctx if deep else 0) if hasattr(m, "_home") else None
+        tf = ops.l2_normalize(self.text_encoder(prompts, self.tokenized_prompts, deep, n_ctx, flags=self._text_flags(), seq_rows=rows))
         self._cache_key, self._cache = key, tf
         return tf
 

@@ -88,6 +88,11 @@ def test_calls_are_routed_by_the_activations_device(monkeypatch):
     assert b is not a and made == [d1, d2]
     m.rebind()
     assert m._resident(d1) is not a and made == [d1, d2, d1]
+    c = m._resident(d1)
+    with torch.no_grad():
+        next(m.parameters()).add_(0.0)                                    # an in-place update of ANY owner parameter (IVLP prompts under training) ...
+    assert m._resident(d1) is not c and made == [d1, d2, d1, d1]          # ... retires the snapshot on cuda:1
+    assert m._resident(d1) is m._resident(d1)
     m.load_state_dict(m.state_dict())
     assert m._device_copies == {}
     assert m._resident(torch.device("cpu")) is m                          # refused further down, by the op that sees the CPU tensor
