@@ -126,6 +126,11 @@ __device__ __forceinline__ void gelu_uop(u32x4_t& w4, float& tl, float& th, floa
   if constexpr (Q == 10) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w4[E]) : "v"(tl), "v"(th));
 }
 
+template <int E>
+__device__ __forceinline__ void gelu_swap(u32x4_t& w4) {   // elements E and E + 2: odd 16-lane rows of the first against even rows of the second
+  asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w4[E]), "+v"(w4[E + 2]));
+}
+
 // Tile traversal.  blockIdx % 8 labels the XCD (blocks are dealt round-robin over the 8 XCDs); each label gets a
 // contiguous range of logical tile ids (bijective remap), and logical ids walk the tile grid in BANDS of `band`
 // n-tiles: inside a band m is the slow index and n the fast one.  The ~32 tiles an XCD runs concurrently then share
@@ -822,6 +827,9 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2*
 #endif
 // build-time A/B of the cache policy of the two operands' LDS-DMA (profiles/r06_stream_dma_policy.txt): an activation panel is read by the four
 // workgroups of a band at about the same time and never again in that band, a weight panel by every m-tile of the band
+#ifndef CLIPMI_STREAM_BIAS_SWAP
+#define CLIPMI_STREAM_BIAS_SWAP 1   // build-time A/B: the bias / plain epilogues' store interleave inside the next K loop (1) or in the tile change (0)
+#endif
 #ifndef CLIPMI_STREAM_A_AUX
 #define CLIPMI_STREAM_A_AUX 0
 #endif
@@ -850,16 +858,25 @@ __device__ __forceinline__ int div_magic(int n, int d, uint32_t mg) { return d =
 // instruction per MFMA over K-steps 0 .. 10, every slice stored inside the loop -- measured the same within 0.3 % (c_fc 222.6 against 223.2 us in an
 // interleaved A/B) and cost 256 registers and a scratch slot: not kept.
 constexpr int STREAM_LAST = 100;
-constexpr int GELU_OPS = 64 * 11;
+// The stream works on one held u32x4 at a time -- the 2 + 2 registers of a block pair (i, i + 1) of a slice, NOT yet interleaved for the 16-byte
+// stores --: 22 instructions for registers (0, 1), 22 for (2, 3), then the two v_permlane16_swap that pack_slice would have issued in the tile change
+// (0 against 2, 1 against 3: the activation is element-wise, so it commutes with the swap).  Inside a register pair the second register runs two steps
+// behind the first, so that no two transcendentals are neighbours and nothing reads the result of the instruction in front of it.
+constexpr int GELU_GROUP_OPS = 46, GELU_OPS = 16 * GELU_GROUP_OPS;
+constexpr int gelu_pair_seq(int w) {   // instruction w = 0 .. 21 of a register pair -> (second register ? 16 : 0) | step 0 .. 10
+  constexpr int seq[22] = {0, 1, 2, 16 + 0, 3, 16 + 1, 4, 16 + 2, 5, 16 + 3, 6, 16 + 4, 7, 16 + 5, 8, 16 + 6, 9, 16 + 7, 10, 16 + 8, 16 + 9, 16 + 10};
+  return seq[w];
+}
 template <bool GELU>
 constexpr int stream_store_slice(int ksi, int nheld) {
   if (!GELU) return (ksi >= 1 && ksi <= 6 && ksi - 1 < nheld) ? ksi - 1 : -1;
   return (ksi >= 1 && ksi <= 6) ? ksi - 1 : (ksi == STREAM_LAST ? 6 : -1);
 }
-constexpr int stream_gelu_op(int slot) {   // first instruction of the activation stream that MFMA slot `slot` of the K loop carries
-  const int n = slot * 11 / 8;
+constexpr int stream_gelu_op(int slot) {   // first instruction of the activation stream that MFMA slot `slot` of the K loop carries: 23 per 16 MFMAs
+  const int n = slot * 23 / 16;
   return n < GELU_OPS ? n : GELU_OPS;
 }
+static_assert(stream_gelu_op(64) == 2 * GELU_GROUP_OPS && stream_gelu_op(512) == GELU_OPS, "a slice per K-step, the whole tile in eight");
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, const float2* __restrict__ ln_rows) {
@@ -1147,9 +1164,14 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
         if constexpr (GSLOT >= 0) {
           // instruction n of the stream: register pair n / 22, registers 2 k (even n) and 2 k + 1 (odd n) alternate, step (n % 22) / 2
           auto uop = [&](auto n_tag) {
-            constexpr int N = decltype(n_tag)::value, W = N % 22, R = 2 * (N / 22) + (W & 1), Q = W >> 1;
-            if constexpr (W & 1) gelu_uop<Q, R % 4>(held[(R % 8) / 4][R / 8], gb_l, gb_h, neg_k);
-            else gelu_uop<Q, R % 4>(held[(R % 8) / 4][R / 8], ga_l, ga_h, neg_k);
+            constexpr int N = decltype(n_tag)::value, G = N / GELU_GROUP_OPS, W = N % GELU_GROUP_OPS;   // group G = block pair G % 2 of slice G / 2
+            if constexpr (W >= 44) {
+              gelu_swap<W - 44>(held[G % 2][G / 2]);
+            } else {
+              constexpr int C = gelu_pair_seq(W % 22), E = 2 * (W / 22) + (C >> 4), Q = C & 15;
+              if constexpr (C >> 4) gelu_uop<Q, E>(held[G % 2][G / 2], gb_l, gb_h, neg_k);
+              else gelu_uop<Q, E>(held[G % 2][G / 2], ga_l, ga_h, neg_k);
+            }
           };
           auto group = [&](auto m_tag) {
             constexpr int M = decltype(m_tag)::value;
@@ -1165,6 +1187,17 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
           group(std::integral_constant<int, 9>{});  group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
           group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{});
           group(std::integral_constant<int, 15>{});
+        } else if constexpr (CLIPMI_STREAM_BIAS_SWAP && !GELU && KSI >= 0 && KSI < NHELD) {
+          // bias / plain epilogues: held slice KSI (stored in the next K-step) is interleaved for its 16-byte stores here -- one v_permlane16_swap
+          // per compute part, behind the eighth MFMA -- instead of in the tile change (pack_slice: 24 swaps of 18 cycles per wave and tile)
+          mfma(std::integral_constant<int, 0>{});  mfma(std::integral_constant<int, 1>{});  mfma(std::integral_constant<int, 2>{});
+          mfma(std::integral_constant<int, 3>{});  mfma(std::integral_constant<int, 4>{});  mfma(std::integral_constant<int, 5>{});
+          mfma(std::integral_constant<int, 6>{});  mfma(std::integral_constant<int, 7>{});
+          gelu_swap<(P & 1)>(held[P >> 1][KSI]);
+          mfma(std::integral_constant<int, 8>{});
+          mfma(std::integral_constant<int, 9>{});  mfma(std::integral_constant<int, 10>{}); mfma(std::integral_constant<int, 11>{});
+          mfma(std::integral_constant<int, 12>{}); mfma(std::integral_constant<int, 13>{}); mfma(std::integral_constant<int, 14>{});
+          mfma(std::integral_constant<int, 15>{});
         } else {
           mfma(std::integral_constant<int, 0>{});  mfma(std::integral_constant<int, 1>{});  mfma(std::integral_constant<int, 2>{});
           mfma(std::integral_constant<int, 3>{});  mfma(std::integral_constant<int, 4>{});  mfma(std::integral_constant<int, 5>{});
@@ -1309,7 +1342,15 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
           }
         }
         u32x4 pk[2];
-        pack_slice(cv, pk);
+        if (j >= HD && (GELU || CLIPMI_STREAM_BIAS_SWAP)) {   // held slices as they are: the next K loop interleaves them for the stores (QuickGELU: behind the activation)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const u32x2 lo = __builtin_bit_cast(u32x2, cv[2 * p]), hi = __builtin_bit_cast(u32x2, cv[2 * p + 1]);
+            pk[p] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+        } else {
+          pack_slice(cv, pk);
+        }
         if (j < HD) {
           store_piece(j, 0, pk[0]);
           store_piece(j, 1, pk[1]);
@@ -1330,13 +1371,19 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(const KArgs a, cons
 #pragma unroll
   for (int j = 0; j < NHELD; ++j) {
     if constexpr (GELU) {
+      f16x4 cvl[TN];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        const f16x4 lo = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][0], held[p][j][1]}));
-        const f16x4 hi = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][2], held[p][j][3]}));
-        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-        held[p][j] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+        cvl[2 * p] = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][0], held[p][j][1]}));
+        cvl[2 * p + 1] = quick_gelu_h(__builtin_bit_cast(f16x4, u32x2{held[p][j][2], held[p][j][3]}));
       }
+      u32x4 pkl[2];
+      pack_slice(cvl, pkl);
+      held[0][j] = pkl[0];
+      held[1][j] = pkl[1];
+    } else if constexpr (CLIPMI_STREAM_BIAS_SWAP) {
+      gelu_swap<0>(held[0][j]); gelu_swap<1>(held[0][j]);
+      gelu_swap<0>(held[1][j]); gelu_swap<1>(held[1][j]);
     }
     store_piece(HD + j, 0, held[0][j]);
     store_piece(HD + j, 1, held[1][j]);
@@ -1845,14 +1892,18 @@ int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = 
       const int n_cu = device_cus() & ~7;
       const int64_t tm = (k.M + 255) / 256, tn = (k.N + 255) / 256;
       const int rem = k.M % 256;
-      const bool split = !forced && rem != 0 && rem <= 128 && tm > 2 && n_cu > 0 && options().gemm_split_rows.load(std::memory_order_relaxed) == 1 &&
-                         ((tm - 1) * tn + n_cu - 1) / n_cu < (tm * tn + n_cu - 1) / n_cu;
+      const int split_mode = options().gemm_split_rows.load(std::memory_order_relaxed);
+      bool split = !forced && rem != 0 && rem <= 128 && tm > 2 && n_cu > 0 && split_mode >= 1 &&
+                   ((tm - 1) * tn + n_cu - 1) / n_cu < (tm * tn + n_cu - 1) / n_cu;
+      int64_t head_rows = k.M - rem;
+      // (A SHORT last round of whole tiles -- c_fc of ViT-B/16 at 256 images: 2364 tiles = 9.23 rounds -- sent to the tile kernels the same way was measured
+      // in round 6 and is not done: c_fc 227.3 -> 229.8 us, profiles/r06_stream_small_steps.txt; the last tiles of a persistent launch run on an emptying chip.)
       if (!split) return launch_stream<EPI>(k, ln_rows, s);
       KArgs head = k, tail = k;
-      head.M = k.M - rem;
+      head.M = (int)head_rows;
       int rc = launch_stream<EPI>(head, ln_rows, s);
       if (rc) return rc;
-      tail.M = rem;
+      tail.M = k.M - (int)head_rows;
       tail.A = k.A + (int64_t)head.M * k.lda;
       tail.out = static_cast<half_t*>(k.out) + (int64_t)head.M * k.ldo;
       if (k.ln_stats) tail.ln_stats = k.ln_stats + 2 * (int64_t)head.M;
