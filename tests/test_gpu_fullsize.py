@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 from clip_calibration_amd import _lib, synthetic as syn  # noqa: E402
 from oracle import clip_oracle as orc  # noqa: E402  (checker only)
+from conftest import oracle_text_features  # noqa: E402
 
 COS_TOL = 1e-3
 G, B, C = "ViT-B/16", 256, 1000
@@ -139,7 +140,7 @@ def test_slice_of_the_full_batch_against_the_oracle(full):
     rows = torch.arange(120, 136)
     with torch.no_grad():
         ri = orc.l2_normalize(orc.encode_image(sd, images[rows.cuda()].cpu()))
-        rt = orc.l2_normalize(orc.encode_text(sd, ids))
+        rt = orc.l2_normalize(oracle_text_features(sd, ids))      # (the oracle on the context cut behind the last EOT: conftest.py)
         r_logits = (sd["logit_scale"].exp() * ri) @ rt.t()
     got = logits[rows.cuda()].cpu().numpy()
     scale = float(sd["logit_scale"].exp())

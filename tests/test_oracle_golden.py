@@ -205,6 +205,18 @@ def test_vitl_geometries(gname, stem, kind):
     assert 1e-6 < ref16 < 1e-3
 
 
+def test_oracle_text_on_a_cut_context():
+    """conftest.oracle_text_features (the GPU suite's cheaper text oracle for long class lists) == the oracle on the full 77-token context: causal
+    mask + EOT-row read-out make everything behind the last EOT unreachable."""
+    from conftest import oracle_text_features
+    for gname, n in (("tiny", 9), ("ViT-B/16", 12)):
+        sd = syn.synthetic_state_dict(gname, seed=0)
+        ids = syn.synthetic_token_ids(n, gname, seed=4, n_ctx_placeholders=4)
+        full, cut = orc.encode_text(sd, ids), oracle_text_features(sd, ids)
+        assert int(ids.argmax(-1).max()) + 1 < ids.shape[1]
+        np.testing.assert_allclose(cut.numpy(), full.numpy(), rtol=1e-5, atol=1e-5 * float(full.abs().max()))
+
+
 def test_ece_cases():
     g = load_golden("ece_cases.npz")
     names = sorted({k.split(":")[0] for k in g})
