@@ -305,6 +305,10 @@ def test_no_valu_written_mfma_source_closer_than_four_wait_states():
     for ln in lines:
         m = re.search(r": 0 VALU write .* \((\d+) MFMA kernels, (\d+) MFMA instructions walked\)", ln)
         assert m and int(m.group(1)) >= 1 and int(m.group(2)) >= 32, ln
+    # round 6: the GEMM translation units carry vector instructions BETWEEN their MFMAs now (the activation stream of gemm_stream_kernel): none of them
+    # may read an MFMA result with a younger MFMA in flight (the second co-residency hazard) -- the scanner's second pass over every kernel of the file
+    for src in ("gemm.hip", "gemm_rstream.hip"):
+        assert re.search(re.escape(src) + r": 0 MFMA result -> vector / store read sites", r.stdout), r.stdout[-2000:]
 
 
 def test_no_kernel_names_a_register_outside_its_allocation():
