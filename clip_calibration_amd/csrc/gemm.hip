@@ -804,14 +804,16 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2*
 // loop (1.5 PFLOP/s) + 1.5 us of prologue + 2.6-3.6 us of epilogue + 1-4 us until the CU's next workgroup starts: a third
 // of every tile is spent with the matrix pipe idle, and because every CU reaches its epilogue at the same moment the
 // 32 MB of stores of one round of tiles hit HBM as one burst.  Here the epilogue leaves the critical path:
-//   * after the K loop a wave only CONVERTS its 128 x 64 outputs (bias / LayerNorm fold / QuickGELU) to fp16 and keeps
-//     them in 64 registers (the accumulators themselves are needed for the next tile at once);
-//   * they are stored in eight 16-row slices, one per K-step, inside the NEXT tile's K loop, straight from the
-//     registers (four 8-byte buffer stores per lane and slice; the four stores of a slice fill whole 128-byte lines of
-//     16 rows, which L2 merges) -- no LDS round trip, no wait: the HBM write stream is continuous instead of bursty;
-//   * the next tile's first stage AND its row / column parameters are DMA'd (buffer_load ... lds) before the conversion
-//     starts; the row parameters (rstd, mean * rstd) come from ln_finalize_kernel, which reduces the row partials once
-//     per GEMM instead of once per tile.
+//   * after the K loop a wave only CONVERTS its 128 x 64 outputs (bias / LayerNorm fold) to fp16 and keeps them in registers (the accumulators
+//     themselves are needed for the next tile at once).  QuickGELU (round 6): what is kept is the fp16 PRE-activation; the activation itself -- two
+//     transcendentals per element -- is applied between the MFMAs of the NEXT tile's compute parts (gelu_uop, stream_gelu_op below);
+//   * they are stored in 16-row slices, one per K-step, inside the NEXT tile's K loop, straight from the registers (two 16-byte buffer stores per
+//     lane and slice after a v_permlane16_swap interleave -- itself issued inside that K loop since round 6) -- no LDS round trip, no wait: the
+//     HBM write stream is continuous instead of bursty;
+//   * the next tile's first stage AND its row / column parameters are DMA'd (buffer_load ... lds) during the LAST K-step of the current tile, as every
+//     other stage is during the K-step before it (round 6; until then: between the slices of the conversion, with a vmcnt wait and a workgroup
+//     barrier behind it); the row parameters (rstd, mean * rstd) are finalised from the producer's row partials at the tile start (RAW mode) or come
+//     from ln_finalize_kernel.
 // Ablations on MI355X (tools/stream_ablate.py): a first version that sent each slice through a wave-private LDS patch at
 // the top of its K-step paid 0.9 us per slice (nothing else runs on the SIMD while both of its waves wait for that
 // round trip), computed the parameters of the next tile with ordinary loads (their vmcnt wait also waits for the 64 KB
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const KArgs a, float2*
 // With 8 waves a wave has 256 registers: 128 accumulators + 64 held outputs + 48 operand fragments fit (the 16-wave
 // geometry has 128 per wave: 64 + 32 held + 24 fragments + addresses do not).  The K-steps that carry a store slice are
 // unrolled (straight-line code: hipcc's waitcnt pass keeps counted lgkmcnt waits), the remaining ones run in a loop.
-// Needs K >= 8 * 64 (K-steps 1 .. 6 carry the held slices of the previous tile, the last K-step issues no DMA), an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
+// Needs K >= 8 * 64 (K-steps 1 .. 6 and the last one carry the held slices of the previous tile), a matrix below 2 GiB per launch (one descriptor: launch_one cuts longer ones into row ranges), an 8-column-aligned fp16 output and, with the LayerNorm fold, the finalised row parameters.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef CLIPMI_STREAM_HD
 #define CLIPMI_STREAM_HD 2
