@@ -1857,13 +1857,16 @@ template <int EPI, bool OUT_F32>
 int launch_one(const KArgs& k, hipStream_t s, int* parts_out, float2* ln_rows = nullptr) {
   int variant = pick_variant(k);
   const bool forced = options().gemm_variant.load(std::memory_order_relaxed) >= 0;
-  // fp16-out GEMMs with at least two rounds of 256 x 256 tiles and K >= 8 K-steps: the streamed-epilogue persistent kernel
+  // fp16-out GEMMs with at least 1.4 rounds of 256 x 256 tiles and K >= 8 K-steps: the streamed-epilogue persistent kernel
   // (the cost model only ranks the one-tile-per-workgroup kernels)
   if constexpr (!OUT_F32 && (EPI == CLIPMI_EPI_NONE || EPI == CLIPMI_EPI_BIAS || EPI == CLIPMI_EPI_BIAS_QUICKGELU)) {
     const bool fits_shape = (k.N & 7) == 0 && (k.ldo & 7) == 0 && k.K >= 8 * BK && (!k.ln_stats || ln_rows || k.ln_parts <= STREAM_RAW_PARTS) && k.ln_rs == 1 &&
                             stream_offsets_ok(k);
     const bool fits = fits_shape && stream_whole_matrix_ok(k);
-    const bool pays = (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 2 * (int64_t)device_cus();
+    // from 1.4 rounds of tiles on (round 6; 2 rounds before the tile change was reworked): the text towers' width-512 GEMMs at 12 000-16 000 rows -- fc 376 / 504 tiles:
+    // 37.8 against 39.6 us, 40.6 against 46.0; in-proj 378 tiles: 33.0 against 34.3; 282 tiles (1.1 rounds): 31.8 against 23.4, stays with the tile kernels
+    // (profiles/r06_text_gemm_sweep.txt)
+    const bool pays = 5 * (int64_t)((k.M + 255) / 256) * ((k.N + 255) / 256) >= 7 * (int64_t)device_cus();
     const bool wanted = variant == 13 || (!forced && pays && options().gemm_stream.load(std::memory_order_relaxed) == 1);
     if (fits_shape && !fits && wanted) {
       // a matrix beyond the 2 GiB one descriptor addresses (a text tower of several hundred thousand token rows): consecutive launches over row ranges
