@@ -529,6 +529,33 @@ def test_class_rows_only_last_block(clipmi_option, gname, batch, fold, f16):
         _feat_close(b, ref, "class-rows-only last block")
 
 
+def test_wide_tower_row_parameters_from_the_finalise_kernel(clipmi_option):
+    """A vision width beyond 1024 (here 1280: five 256-column tiles per residual GEMM) gives the LayerNorm fold more row partials than the streamed
+    kernel's LDS table holds (STREAM_RAW_PARTS = 4): the consumer GEMMs then read (rstd, mean * rstd) pairs that ln_finalize_kernel reduced once per GEMM,
+    DMA'd per tile through the whole-array descriptor (gemm.hip `params`, round 6).  No CLIP geometry of the reference is that wide; two blocks of it
+    at 40 images (in-proj 465 tiles, c_fc 620: the streamed kernel) against the tile kernels and against the oracle."""
+    from clip_calibration_amd.model import build_model
+    geom = syn.ClipGeometry(512, 224, 2, 1280, 16, 77, 49408, 512, 8, 1)
+    sd = syn.synthetic_state_dict(geom, seed=0)
+    model = build_model(dict(sd), dict(PLAIN)).cuda()
+    images = syn.synthetic_images(40, geom, seed=4)
+    with torch.no_grad():
+        clipmi_option("cls_only_last_block", 0)
+        clipmi_option("gemm_stream", 0)
+        tile = model.image_features_f32(images.cuda()).clone()
+        clipmi_option("gemm_stream", 1)
+        stream = model.image_features_f32(images.cuda()).clone()
+        clipmi_option("cls_only_last_block", 1)
+        cls = model.image_features_f32(images.cuda()).clone()
+        ref = orc.encode_image(sd, images[:2]).numpy()
+    assert torch.isfinite(stream).all()
+    # (the fold's fp32 expression is contracted differently in the two kernels: an fp16 ulp here and there on the GEMM outputs, as between any two tile shapes)
+    sn, tn = torch.nn.functional.normalize(stream, dim=1), torch.nn.functional.normalize(tile, dim=1)
+    assert float((1 - (sn * tn).sum(1)).abs().max()) < 2e-5 and float((stream - tile).abs().max()) <= 3e-3 * float(tile.abs().max())
+    _feat_close(stream[:2].cpu().numpy(), ref, "wide tower, streamed GEMMs")
+    _feat_close(cls[:2].cpu().numpy(), ref, "wide tower, class rows only")
+
+
 @pytest.mark.parametrize("tower", ["maple", "ivlp", "vpt"])
 def test_class_rows_only_last_block_hooked_towers(clipmi_option, tower):
     """The same on the towers that carry prompt tokens (clip/model.py:287-331, 447-478; 191-256): MaPLe's shared context + deep prompts
