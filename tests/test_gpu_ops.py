@@ -65,7 +65,7 @@ def test_gemm(ops, M, N, K, epi):
 @pytest.mark.parametrize("variant", ["0", "1", "a", "s", "r"])
 @pytest.mark.parametrize("M,N,K,epi", [(200, 192, 128, "gelu"), (1000, 2304, 768, "bias"), (333, 512, 3072, "residual"),
                                         (50432, 768, 768, "residual"), (513, 260, 64, "none"), (5000, 3072, 768, "gelu"),
-                                        (50432, 768, 768, "gelu"), (3000, 520, 640, "bias"), (40000, 2048, 512, "gelu")])
+                                        (50432, 768, 768, "gelu"), (3000, 520, 640, "bias"), (40000, 2048, 512, "gelu"), (3000, 512, 512, "none")])
 def test_gemm_tile_variants(ops, clipmi_option, variant, M, N, K, epi):
     """Every tile/pipeline variant the dispatcher can pick (option gemm_variant) computes the same thing."""
     clipmi_option("gemm_variant", _lib.gemm_variant_id(variant))
